@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Generate WaveGlow golden vectors by running the REFERENCE implementation.
+
+Runs only in the build container (needs /root/reference).  The reference is
+imported read-only with PYTHONDONTWRITEBYTECODE=1; nothing of it is copied:
+the outputs written to tests/golden/*.npz are data (inputs are regenerated from
+seeds by text2speech_amd.synth, so only expected outputs are stored).
+
+Shims applied (device placement only, never arithmetic):
+  * torch.cuda.FloatTensor = torch.FloatTensor for WaveGlow.infer
+    (reference glow.py:261-267,286-288 build their noise on CUDA types).
+
+usage: PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden_waveglow.py [--full]
+"""
+import argparse
+import os
+import sys
+import warnings
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore")
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/waveglow")
+
+import glow as ref_glow  # noqa: E402  (the reference)
+from text2speech_amd import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def build_ref(cfg, sd):
+    torch.manual_seed(0)
+    m = ref_glow.WaveGlow(**cfg)
+    missing = m.load_state_dict(sd, strict=True)
+    m.eval()
+    return m
+
+
+def run_forward(name, cfg, batch, n_samples, seed, store_z=True, grads=False):
+    sd = synth.waveglow_state(cfg)
+    mel, audio = synth.waveglow_inputs(batch, n_samples, seed=seed)
+    m = build_ref(cfg, sd)
+    out = {}
+    if grads:
+        m.train()
+        z, log_s, log_det = m((mel, audio))
+        loss = ref_glow.WaveGlowLoss(1.0)((z, log_s, [d.clone() for d in log_det]))
+        loss.backward()
+        named = dict(m.named_parameters())
+        # torch >= 2 exposes weight_norm params under their original names
+        for key in ["WN.0.in_layers.0.weight_v", "WN.0.in_layers.0.weight_g", "WN.3.cond_layers.7.weight_v",
+                    "WN.11.res_skip_layers.2.weight_v", "WN.5.start.weight_g", "WN.7.end.weight",
+                    "convinv.2.conv.weight", "upsample.weight", "WN.11.in_layers.7.bias"]:
+            gflat = named[key].grad.detach().flatten()
+            step = max(1, gflat.numel() // 32768)       # strided sample keeps fixtures small
+            out["grad::" + key] = gflat[::step].contiguous().numpy()
+            out["gradsum::" + key] = np.float64(gflat.double().sum().item())
+            out["gradsq::" + key] = np.float64((gflat.double() ** 2).sum().item())
+        out["loss"] = np.float64(loss.item())
+    else:
+        with torch.no_grad():
+            z, log_s, log_det = m((mel, audio))
+            loss = ref_glow.WaveGlowLoss(1.0)((z, log_s, [d.clone() for d in log_det]))
+        out["loss"] = np.float64(loss.item())
+    if store_z:
+        out["z"] = z.detach().numpy()
+    out["z_sum"] = np.float64(z.double().sum().item())
+    out["z_sqsum"] = np.float64((z.double() ** 2).sum().item())
+    out["log_det"] = np.array([float(d) for d in log_det], dtype=np.float64)
+    out["log_s_sum"] = np.array([float(ls.double().sum()) for ls in log_s], dtype=np.float64)
+    # a strided sample of every flow's log_s pins each flow individually
+    for k, ls in enumerate(log_s):
+        out[f"log_s_{k}"] = ls.detach()[:, :, ::max(1, ls.size(2) // 64)].contiguous().numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "loss", out["loss"], "z std", float(z.std()))
+
+
+def run_infer(name, cfg, batch, frames, seed, sigma):
+    sd = synth.waveglow_state(cfg)
+    gen = torch.Generator().manual_seed(seed)
+    mel = torch.randn(batch, cfg["n_mel_channels"], frames, generator=gen)
+    m = build_ref(cfg, sd)
+    torch.cuda.FloatTensor = torch.FloatTensor      # device shim only
+    L = frames * 256 // cfg["n_group"]
+    # capture the reference's draws: replay the same global-RNG stream
+    torch.manual_seed(seed + 1)
+    noise_final = torch.FloatTensor(batch, m.n_remaining_channels, L).normal_()
+    noise_early = []
+    for k in reversed(range(cfg["n_flows"])):
+        if k % cfg["n_early_every"] == 0 and k > 0:
+            noise_early.append(torch.FloatTensor(batch, cfg["n_early_size"], L).normal_())
+    torch.manual_seed(seed + 1)
+    with torch.no_grad():
+        audio = m.infer(mel, sigma=sigma)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), audio=audio.numpy(),
+                        noise_final=noise_final.numpy(),
+                        **{f"noise_early_{i}": n.numpy() for i, n in enumerate(noise_early)})
+    print(name, "audio std", float(audio.std()), tuple(audio.shape))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true", help="also run the 512-channel 8x16000 config (~1 min)")
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    run_forward("waveglow_small_fwd", synth.WAVEGLOW_SMALL, 2, 4096, seed=31)
+    run_forward("waveglow_small_ragged_fwd", synth.WAVEGLOW_SMALL, 3, 2400, seed=32)
+    run_forward("waveglow_small_grads", synth.WAVEGLOW_SMALL, 2, 4096, seed=31, store_z=False, grads=True)
+    run_infer("waveglow_small_infer_s0", synth.WAVEGLOW_SMALL, 2, 12, seed=41, sigma=0.0)
+    run_infer("waveglow_small_infer_s0666", synth.WAVEGLOW_SMALL, 2, 12, seed=41, sigma=0.666)
+    if args.full:
+        run_forward("waveglow_full_fwd", synth.WAVEGLOW_DEFAULT, 8, 16000, seed=31)
