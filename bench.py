@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Headline benchmark: WaveGlow forward audio-samples/s at batch 8 x 16000 per GPU
+(BASELINE.json configs[2]; `config.json` defaults: 12 flows, n_group 8, WN 8 layers x 512 channels).
+
+One "step" = one full WaveGlow.forward over one synthetic batch already resident in HBM,
+including the per-forward weight-norm recompute + weight packing the reference also pays
+(torch.nn.utils.weight_norm hooks, reference glow.py:123-151).
+
+    python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; the forward pass of
+independent batches needs no collective, so ranks only meet at the timing barriers ("weak" scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused
+in+cond+gate GEMM), timed live with HIP events on the launch stream; `cpu_baseline` is the CPU
+oracle (a port of the reference's torch op sequence) timed on this host at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from text2speech_amd import _lib, synth  # noqa: E402
+from text2speech_amd.glow import WaveGlow  # noqa: E402
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+
+
+def cpu_baseline(cfg, sd, sample_batch=2, n_samples=16000, reps=3):
+    """The oracle (oracle/waveglow_oracle.py, kind "port") on the host cores, bounded sample."""
+    from oracle import waveglow_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    mel, audio = synth.waveglow_inputs(sample_batch, n_samples, seed=31)
+    times = []
+    with torch.no_grad():
+        O.waveglow_forward(sd, cfg, mel[:1, :, :9], audio[:1, :2048])     # warm-up (thread pool, allocator)
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            O.waveglow_forward(sd, cfg, mel, audio)
+            times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    return {"value": sample_batch * n_samples / t, "unit": "audio samples/s", "cores": cores, "kind": "port",
+            "sample": "oracle forward on batch %d x %d (1/%d of the GPU batch), median of %d, fp32 torch CPU ops"
+                      % (sample_batch, n_samples, 8 // sample_batch, reps)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--segment", type=int, default=16000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    _lib.load()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = synth.WAVEGLOW_DEFAULT
+    sd = synth.waveglow_state(cfg)
+    model = WaveGlow(**cfg)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    mel, audio = synth.waveglow_inputs(args.batch, args.segment, seed=1234 + rank)
+    mel, audio = mel.to(dev), audio.to(dev)
+
+    eng = model._eng()
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            model((mel, audio))
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.gemm_events = [] if rank == 0 else None
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model((mel, audio))
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        evs = eng.gemm_events or []
+        eng.gemm_events = None
+        wn = cfg["WN_config"]
+        C, ks = wn["n_channels"], wn["kernel_size"]
+        n_cond = cfg["n_mel_channels"] * cfg["n_group"]
+        L = args.segment // cfg["n_group"]
+        flops_per_launch = 2.0 * (2 * C) * (ks * C + n_cond) * args.batch * L
+        roof = None
+        if evs:
+            ms = [a.elapsed_time(b) for a, b in evs]
+            avg_ms = sum(ms) / len(ms)
+            achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "conv_gemm_kernel<EPI_GATE> (in_layers+cond_layers+gate)",
+                    "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_ms": avg_ms, "launches": len(ms), "algorithmic_flops_per_launch": flops_per_launch,
+                    "note": "split-bf16: 3 bf16 MFMA products per algorithmic MAC, so frac <= 1/3 by construction"}
+        total_samples = args.gpus * args.batch * args.segment * args.steps
+        out = {
+            "metric": "WaveGlow forward audio samples/sec (batch 8x16000 per GPU)",
+            "value": total_samples / dt, "unit": "audio samples/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3 (split-bf16 products, f32 accumulate)",
+            "data": "synthetic (seeded N(0,1) mel, U(-0.5,0.5) audio; seeded random weights, WN.end ~ N(0,0.02^2))",
+            "config": {"workload": "WaveGlow forward, batch %d x %d samples per GPU, 12 flows, n_group 8, "
+                                   "WN 8 layers x 512 channels (reference waveglow/config.json)" % (args.batch, args.segment),
+                       "per_gpu_batch": args.batch, "segment_length": args.segment, "parallelism": "replicas, no collective"},
+            "roofline": roof,
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,286 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI of
+libt2s_hip.so; the checker is the CPU oracle (oracle/waveglow_oracle.py) and the committed
+golden vectors produced by the reference itself."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from text2speech_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _maxrel(a, b):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return _lib.load()
+
+
+def _pack_layer(C, n_cond, ks, w_in, g_in, b_in, w_c, g_c, b_c, w_rs, g_rs, b_rs):
+    st = _lib.current_stream()
+    Cpad, Spad = -(-C // 32) * 32, -(-n_cond // 32) * 32
+    Mpad1 = -(-C // 128) * 256
+    nk1 = ks * Cpad // 32 + Spad // 32
+    A1h = torch.zeros(nk1, Mpad1, 32, dtype=torch.bfloat16, device=DEV)
+    A1l = torch.zeros_like(A1h)
+    b1 = torch.zeros(Mpad1, device=DEV)
+    _lib.call("t2s_pack_conv_weight", _lib.ptr(w_in), _lib.ptr(g_in), _lib.ptr(b_in), 2 * C, C, ks, 1, C, 0, Mpad1, 0,
+              Cpad, _lib.ptr(A1h), _lib.ptr(A1l), _lib.ptr(b1), 0, st)
+    _lib.call("t2s_pack_conv_weight", _lib.ptr(w_c), _lib.ptr(g_c), _lib.ptr(b_c), 2 * C, n_cond, 1, 1, C, 0, Mpad1,
+              ks * Cpad, Spad, _lib.ptr(A1h), _lib.ptr(A1l), _lib.ptr(b1), 1, st)
+    rows2 = w_rs.size(0)
+    Mpad2 = _lib.padded_rows(rows2)
+    A2h = torch.zeros(Cpad // 32, Mpad2, 32, dtype=torch.bfloat16, device=DEV)
+    A2l = torch.zeros_like(A2h)
+    b2 = torch.zeros(Mpad2, device=DEV)
+    _lib.call("t2s_pack_conv_weight", _lib.ptr(w_rs), _lib.ptr(g_rs), _lib.ptr(b_rs), rows2, C, 1, 0, 0, 0, Mpad2, 0,
+              Cpad, _lib.ptr(A2h), _lib.ptr(A2l), _lib.ptr(b2), 0, st)
+    return (A1h, A1l, b1, Mpad1), (A2h, A2l, b2, Mpad2)
+
+
+@pytest.mark.parametrize("B,C,n_cond,L,dil,last", [
+    (2, 64, 640, 300, 1, False),      # ragged tile, one M tile half empty
+    (1, 128, 96, 256, 4, False),
+    (2, 512, 640, 520, 128, False),   # full-size channels, max dilation
+    (1, 256, 640, 777, 16, True),     # last layer: skip-only res_skip
+])
+def test_wn_layer(lib, B, C, n_cond, L, dil, last):
+    """One WN layer (in+cond+gate, then res/skip) against stock conv1d on the CPU."""
+    from text2speech_amd import planes
+    gen = torch.Generator().manual_seed(C + L)
+    ks = 3
+    x = torch.randn(B, C, L, generator=gen)
+    s = torch.randn(B, n_cond, L, generator=gen)
+    skip0 = torch.randn(B, C, L, generator=gen)
+    rows2 = C if last else 2 * C
+    w_in = torch.randn(2 * C, C, ks, generator=gen) / (C * ks) ** 0.5
+    g_in = torch.rand(2 * C, generator=gen) + 0.5
+    b_in = torch.randn(2 * C, generator=gen) * 0.1
+    w_c = torch.randn(2 * C, n_cond, 1, generator=gen) / n_cond ** 0.5
+    g_c = torch.rand(2 * C, generator=gen) + 0.5
+    b_c = torch.randn(2 * C, generator=gen) * 0.1
+    w_rs = torch.randn(rows2, C, 1, generator=gen) / C ** 0.5
+    g_rs = torch.rand(rows2, generator=gen) + 0.5
+    b_rs = torch.randn(rows2, generator=gen) * 0.1
+
+    def eff(v, g):
+        return v * (g / v.flatten(1).norm(dim=1)).view(-1, 1, 1)
+
+    # CPU expectation (f64 to make the checker itself exact)
+    a = F.conv1d(x.double(), eff(w_in, g_in).double(), b_in.double(), dilation=dil, padding=dil) + \
+        F.conv1d(s.double(), eff(w_c, g_c).double(), b_c.double())
+    acts = torch.tanh(a[:, :C]) * torch.sigmoid(a[:, C:])
+    rs = F.conv1d(acts, eff(w_rs, g_rs).double(), b_rs.double())
+    if last:
+        x_new, skip_new = x.double(), skip0.double() + rs
+    else:
+        x_new, skip_new = x.double() + rs[:, :C], skip0.double() + rs[:, C:]
+
+    halo = 128
+    Lp = _lib.plane_rows(L, halo)
+    d = lambda t: t.to(DEV).contiguous()
+    l1, l2 = _pack_layer(C, n_cond, ks, d(w_in), d(g_in), d(b_in), d(w_c), d(g_c), d(b_c), d(w_rs), d(g_rs), d(b_rs))
+    Xh, Xl = planes.to_planes(d(x), halo, Lp)
+    Sh, Sl = planes.to_planes(d(s), halo, Lp)
+    Ah, Al = torch.zeros_like(Xh), torch.zeros_like(Xl)
+    skip = torch.zeros(B, Xh.size(1), Lp, 32, device=DEV)
+    skip[:, :, halo:halo + L] = d(skip0).view(B, -1, 32, L).permute(0, 1, 3, 2) if C % 32 == 0 else 0
+    st = _lib.current_stream()
+    _lib.call("t2s_wg_in_cond_gate", _lib.ptr(l1[0]), _lib.ptr(l1[1]), _lib.ptr(l1[2]), _lib.ptr(Xh), _lib.ptr(Xl),
+              _lib.ptr(Sh), _lib.ptr(Sl), _lib.ptr(Ah), _lib.ptr(Al), B, C, n_cond, ks, dil, L, Lp, halo, l1[3], st)
+    torch.cuda.synchronize()
+    got_acts = planes.from_planes(Ah, Al, C, L, halo)
+    assert _rel(got_acts, acts) < 2e-5, "gate GEMM"
+    assert _maxrel(got_acts, acts) < 1e-4
+    # the zero halo rows must stay untouched
+    assert float(Ah[:, :, :halo].float().abs().max()) == 0.0
+    assert float(Ah[:, :, halo + L:].float().abs().max()) == 0.0
+    _lib.call("t2s_wg_res_skip", _lib.ptr(l2[0]), _lib.ptr(l2[1]), _lib.ptr(l2[2]), _lib.ptr(Ah), _lib.ptr(Al),
+              _lib.ptr(Xh), _lib.ptr(Xl), _lib.ptr(skip), B, C, 0 if last else C, 0, L, Lp, halo, l2[3], st)
+    torch.cuda.synchronize()
+    got_x = planes.from_planes(Xh, Xl, C, L, halo)
+    got_skip = planes.from_f32_planes(skip, C, L, halo)
+    assert _rel(got_x, x_new) < 2e-5, "residual"
+    assert _rel(got_skip, skip_new) < 2e-5, "skip"
+    assert float(Xh[:, :, :halo].float().abs().max()) == 0.0
+
+
+def test_small_stages(lib):
+    """upsample+squeeze, convinv/logdet/inverse, start, end+affine against torch CPU ops."""
+    from text2speech_amd import planes
+    gen = torch.Generator().manual_seed(3)
+    st = _lib.current_stream()
+    d = lambda t: t.to(DEV).contiguous()
+    # upsample + squeeze
+    B, M, Fr, G = 3, 80, 9, 8
+    T = 2048
+    L = T // G
+    mel = torch.randn(B, M, Fr, generator=gen)
+    W = torch.randn(M, M, 1024, generator=gen) * 0.05
+    bias = torch.randn(M, generator=gen) * 0.1
+    want = F.conv_transpose1d(mel.double(), W.double(), bias.double(), stride=256)[:, :, :T]
+    want = want.reshape(B, M, L, G).permute(0, 1, 3, 2).reshape(B, M * G, L)
+    halo = 128
+    Lp = _lib.plane_rows(L, halo)
+    Sh = torch.zeros(B, M * G // 32, Lp, 32, dtype=torch.bfloat16, device=DEV)
+    Sl = torch.zeros_like(Sh)
+    _lib.call("t2s_wg_upsample_squeeze", _lib.ptr(d(mel)), _lib.ptr(d(W)), _lib.ptr(d(bias)), B, M, Fr, 1024, 256, G,
+              L, Lp, halo, _lib.ptr(Sh), _lib.ptr(Sl), st)
+    torch.cuda.synchronize()
+    assert _rel(planes.from_planes(Sh, Sl, M * G, L, halo), want) < 2e-5
+    # audio squeeze + convinv + logdet + inverse
+    audio = torch.rand(B, T, generator=gen) - 0.5
+    z = torch.empty(B, G, L, device=DEV)
+    _lib.call("t2s_wg_audio_squeeze", _lib.ptr(d(audio)), _lib.ptr(z), B, T, G, L, 0, st)
+    zr = audio.reshape(B, L, G).permute(0, 2, 1)
+    assert torch.equal(z.cpu(), zr)
+    Wc = torch.linalg.qr(torch.randn(6, 6, generator=gen))[0] @ torch.diag(torch.rand(6, generator=gen) + 0.5)
+    if torch.det(Wc) < 0:
+        Wc[:, 0] = -Wc[:, 0]
+    out = torch.empty(1, device=DEV)
+    inv = torch.empty(6, 6, device=DEV)
+    _lib.call("t2s_small_logdet_inv", _lib.ptr(d(Wc)), 6, 100.0, _lib.ptr(out), _lib.ptr(inv), st)
+    _lib.call("t2s_wg_convinv", _lib.ptr(z), _lib.ptr(d(Wc)), B, G, 2, 6, L, st)
+    torch.cuda.synchronize()
+    assert abs(float(out) - 100.0 * float(torch.logdet(Wc.double()))) < 1e-3
+    assert _rel(inv, torch.linalg.inv(Wc.double())) < 1e-5
+    zr2 = zr.clone().double()
+    zr2[:, 2:] = torch.einsum("ij,bjt->bit", Wc.double(), zr[:, 2:].double())
+    assert _rel(z, zr2) < 1e-6
+    # start
+    C, nh = 64, 3
+    ws = torch.randn(C, nh, generator=gen)
+    bs = torch.randn(C, generator=gen)
+    Xh = torch.zeros(B, C // 32, Lp, 32, dtype=torch.bfloat16, device=DEV)
+    Xl = torch.zeros_like(Xh)
+    _lib.call("t2s_wg_start", _lib.ptr(z), _lib.ptr(d(ws)), _lib.ptr(d(bs)), B, G, 2, nh, C, L, Lp, halo, _lib.ptr(Xh),
+              _lib.ptr(Xl), st)
+    torch.cuda.synchronize()
+    want_x = torch.einsum("cj,bjt->bct", ws.double(), zr2[:, 2:5]) + bs.double().view(1, -1, 1)
+    assert _rel(planes.from_planes(Xh, Xl, C, L, halo), want_x) < 2e-5
+    # end + affine (forward and reverse)
+    skipv = torch.randn(B, C, L, generator=gen)
+    skip = torch.zeros(B, C // 32, Lp, 32, device=DEV)
+    skip[:, :, halo:halo + L] = d(skipv).view(B, -1, 32, L).permute(0, 1, 3, 2)
+    we = torch.randn(2 * nh, C, 1, generator=gen) * 0.05
+    be = torch.randn(2 * nh, generator=gen) * 0.05
+    o = F.conv1d(skipv.double(), we.double(), be.double())
+    z_before = z.clone()
+    log_s = torch.empty(B, nh, L, device=DEV)
+    _lib.call("t2s_wg_end_affine", _lib.ptr(skip), _lib.ptr(d(we)), _lib.ptr(d(be)), _lib.ptr(z), _lib.ptr(log_s), B, G,
+              2, nh, C, L, Lp, halo, 0, st)
+    torch.cuda.synchronize()
+    want_a1 = torch.exp(o[:, nh:]) * z_before[:, 5:8].double().cpu() + o[:, :nh]
+    assert _rel(log_s, o[:, nh:]) < 1e-5
+    assert _rel(z[:, 5:8], want_a1) < 1e-5
+    assert torch.equal(z[:, :5], z_before[:, :5])
+    _lib.call("t2s_wg_end_affine", _lib.ptr(skip), _lib.ptr(d(we)), _lib.ptr(d(be)), _lib.ptr(z), None, B, G, 2, nh, C,
+              L, Lp, halo, 1, st)
+    torch.cuda.synchronize()
+    assert _rel(z, z_before) < 1e-5
+
+
+def _build(cfg):
+    from text2speech_amd.glow import WaveGlow
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synth.waveglow_state(cfg), strict=True)
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize("name,batch,n,seed", [
+    ("waveglow_small_fwd", 2, 4096, 31),
+    ("waveglow_small_ragged_fwd", 3, 2400, 32),
+])
+def test_forward_small_vs_golden(lib, golden_dir, name, batch, n, seed):
+    from oracle import waveglow_oracle as O
+    from text2speech_amd.glow import WaveGlowLoss
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = synth.WAVEGLOW_SMALL
+    m = _build(cfg)
+    mel, audio = synth.waveglow_inputs(batch, n, seed=seed)
+    with torch.no_grad():
+        z, log_s, log_det = m((mel.to(DEV), audio.to(DEV)))
+        loss = WaveGlowLoss(1.0)((z, log_s, log_det))
+        zo, lso, ldo = O.waveglow_forward(synth.waveglow_state(cfg), cfg, mel, audio)
+    torch.cuda.synchronize()
+    assert _rel(z, g["z"]) < 1e-3 and _maxrel(z, g["z"]) < 1e-3      # the north-star bar
+    assert _rel(z, g["z"]) < 1e-4                                     # what split-bf16 actually holds
+    assert _rel(z, zo) < 1e-4
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * max(1.0, abs(float(g["loss"])))
+    np.testing.assert_allclose([float(d) for d in log_det], g["log_det"], rtol=1e-4, atol=1e-2)
+    for k, ls in enumerate(log_s):
+        assert _rel(ls, lso[k]) < 1e-3, "flow %d log_s" % k
+
+
+def test_forward_full_vs_golden(lib, golden_dir):
+    """BASELINE config 3: 512 channels, batch 8 x 16000."""
+    g = np.load(os.path.join(golden_dir, "waveglow_full_fwd.npz"))
+    cfg = synth.WAVEGLOW_DEFAULT
+    m = _build(cfg)
+    mel, audio = synth.waveglow_inputs(8, 16000, seed=31)
+    with torch.no_grad():
+        z, log_s, log_det = m((mel.to(DEV), audio.to(DEV)))
+    torch.cuda.synchronize()
+    assert _rel(z, g["z"]) < 1e-3 and _maxrel(z, g["z"]) < 1e-3
+    np.testing.assert_allclose([float(d) for d in log_det], g["log_det"], rtol=1e-4, atol=1e-1)
+    np.testing.assert_allclose([float(ls.double().sum()) for ls in log_s], g["log_s_sum"], rtol=2e-3, atol=2.0)
+    for k, ls in enumerate(log_s):
+        step = max(1, ls.size(2) // 64)
+        assert _rel(ls[:, :, ::step], g[f"log_s_{k}"]) < 1e-3
+
+
+@pytest.mark.parametrize("name,sigma", [("waveglow_small_infer_s0", 0.0), ("waveglow_small_infer_s0666", 0.666)])
+def test_infer_small_vs_golden(lib, golden_dir, name, sigma):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = synth.WAVEGLOW_SMALL
+    m = _build(cfg)
+    gen = torch.Generator().manual_seed(41)
+    mel = torch.randn(2, 80, 12, generator=gen)
+    noise = (torch.from_numpy(g["noise_final"]), [torch.from_numpy(g[f"noise_early_{i}"]) for i in range(2)])
+    audio = m.infer(mel.to(DEV), sigma=sigma, noise=noise)
+    assert tuple(audio.shape) == g["audio"].shape
+    assert _rel(audio, g["audio"]) < 1e-3 and _maxrel(audio, g["audio"]) < 1e-3
+
+
+def test_roundtrip_full_size(lib):
+    """Size-independent property at the full config: forward(infer(noise)) == noise."""
+    cfg = synth.WAVEGLOW_DEFAULT
+    m = _build(cfg)
+    gen = torch.Generator().manual_seed(77)
+    B, frames = 2, 16
+    L = frames * 256 // 8
+    mel = torch.randn(B, 80, frames, generator=gen)
+    nf = torch.randn(B, 4, L, generator=gen)
+    ne = [torch.randn(B, 2, L, generator=gen) for _ in range(2)]
+    audio = m.infer(mel.to(DEV), sigma=1.0, noise=(nf, ne))
+    with torch.no_grad():
+        z, _, _ = m((mel.to(DEV), audio))
+    want = torch.cat([ne[1], ne[0], nf], 1)
+    assert _rel(z, want) < 1e-3
+
+
+def test_fails_loudly_off_gpu(lib):
+    cfg = synth.WAVEGLOW_SMALL
+    from text2speech_amd.glow import WaveGlow
+    m = WaveGlow(**cfg)
+    mel, audio = synth.waveglow_inputs(1, 2048)
+    with pytest.raises(_lib.T2SError):
+        with torch.no_grad():
+            m((mel, audio))

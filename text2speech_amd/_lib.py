@@ -1,0 +1,99 @@
+"""ctypes binding of libt2s_hip.so (the C ABI declared in include/t2s_hip.h).
+
+The product path has NO fallback: if the library is missing or an entry point
+fails, a ``T2SError`` is raised.  PyTorch is used only for device memory and
+streams; every pointer handed to the library is ``tensor.data_ptr()``.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libt2s_hip.so")
+
+c_int, c_float, c_vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes (every function returns int unless listed in _RESTYPE)
+SIGNATURES = {
+    "t2s_abi_version": [],
+    "t2s_error_string": [c_int],
+    "t2s_last_hip_error": [],
+    "t2s_plane_rows": [c_int, c_int],
+    "t2s_padded_rows": [c_int],
+    "t2s_pack_conv_weight": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                             c_vp, c_vp, c_vp, c_int, c_vp],
+    "t2s_weightnorm_small": [c_vp, c_vp, c_int, c_int, c_vp, c_vp],
+    "t2s_wg_upsample_squeeze": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_vp, c_vp, c_vp],
+    "t2s_wg_audio_squeeze": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
+    "t2s_wg_convinv": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
+    "t2s_small_logdet_inv": [c_vp, c_int, c_float, c_vp, c_vp, c_vp],
+    "t2s_wg_start": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
+    "t2s_wg_in_cond_gate": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,
+                            c_int, c_int, c_int, c_int, c_vp],
+    "t2s_wg_res_skip": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int,
+                        c_int, c_int, c_vp],
+    "t2s_wg_end_affine": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                          c_int, c_vp],
+    "t2s_conv_bias_act": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int,
+                          c_int, c_int, c_int, c_int, c_vp],
+}
+_RESTYPE = {"t2s_error_string": ctypes.c_char_p, "t2s_last_hip_error": ctypes.c_char_p}
+
+
+class T2SError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises T2SError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise T2SError(
+            "libt2s_hip.so not found at %s - build it with `python -m text2speech_amd.build` "
+            "(there is no CPU fallback on the product path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise T2SError("libt2s_hip.so does not export %s" % name) from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device (or host) pointer of a tensor, None -> NULL."""
+    if t is None:
+        return None
+    return c_vp(t.data_ptr())
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise on a non-zero code."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.t2s_error_string(rc).decode()
+        hip = lib.t2s_last_hip_error().decode()
+        raise T2SError("%s failed: %s%s" % (name, msg, (" (" + hip + ")") if hip and rc == -2 else ""))
+    return rc
+
+
+def plane_rows(L, halo):
+    return load().t2s_plane_rows(L, halo)
+
+
+def padded_rows(rows):
+    return load().t2s_padded_rows(rows)
+
+
+def current_stream():
+    import torch
+    return c_vp(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,274 @@
+// Split-bf16 conv-as-GEMM for gfx950 (MI355X): the WaveGlow WN hot loop.
+//
+// Computes, per batch element b and time tile,
+//     acc[o][t] = sum_{tap, c} W[o][tap][c] * X[b][c][t + (tap - taps/2) * dil]
+//               + sum_{c}      Wc[o][c]     * S[b][c][t]                     (optional)
+// which restates reference glow.py:159-161 (in_layers[i](audio) +
+// cond_layers[i](spect)) as ONE GEMM with K = taps*C + C_cond, and
+// glow.py:164 (res_skip_layers[i](acts)) as a GEMM with K = C, each with its
+// element-wise tail fused into the epilogue:
+//     EPI_GATE    : acts = tanh(acc[:C]) * sigmoid(acc[C:])   (glow.py:33-40)
+//     EPI_RESSKIP : x += acc[:C]; skip (+)= acc[C:]           (glow.py:165-174)
+//
+// Arithmetic: every operand is a (hi, lo) pair of bf16 planes, and each K-step
+// issues three MFMAs  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  accumulating in f32,
+// i.e. ~16-bit-mantissa products with f32 accumulation.  Plain bf16 misses the
+// 1e-3 parity budget by 10x; this scheme holds ~1e-5 at
+// 3/16 of the cost of the exact-f32 MFMA.
+//
+// Tiling (one workgroup = 512 threads = 8 waves, 2 per SIMD, one WG per CU):
+//   256 (out channels) x 256 (time) output tile, BK = 32 channels per K-step,
+//   waves laid out 2 (M) x 4 (N), each wave 128 x 64 = 8 x 4 MFMA 16x16x32 tiles
+//   (128 accumulator VGPRs).  Per K-step four 16 KiB plane tiles (A_hi, A_lo,
+//   B_hi, B_lo) are DMA'd global->LDS (global_load_lds_dwordx4), double buffered
+//   (2 x 64 KiB LDS).  LDS rows are 64 B; the 16-B slots of a row are XOR-permuted
+//   by s[(row>>2)&3], s = {0,2,3,1}, applied on the DMA *source* address and on
+//   the ds_read_b128 address, which makes every fragment read conflict-free
+//   (bank groups of ds_read_b128: MI355X_MICROARCH.md, LDS table).
+//
+// Grid: (n_mtiles * n_ttiles * B) workgroups, remapped so that the workgroups
+// dealt to one XCD (blockIdx % 8) cover contiguous time tiles x all M tiles and
+// therefore share their activation tiles in that XCD's L2.
+#include "t2s_common.h"
+#include "t2s_kernels.h"
+
+#define STAGE_BYTES 65536
+#define PLANE_BYTES 16384
+
+static __device__ __forceinline__ int swz4(int rb) {      // {0,2,3,1}[rb]
+    return (0x78 >> (rb * 2)) & 3;                        // 0b01'11'10'00
+}
+
+static __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2;          // 0..1  : which 128-row half of the M tile
+    const int wc = wave & 3;           // 0..3  : which 64-column quarter of the N tile
+
+    // ---- XCD-aware, bijective block remap (guide section 5, T1) ----
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int mt = logical % a.n_mtiles;
+    const int tt_all = logical / a.n_mtiles;
+    const int b = tt_all / a.n_ttiles;
+    const int t0 = (tt_all % a.n_ttiles) * T2S_TILE_N;
+
+    // ---- per-thread DMA source offsets (bytes) ----
+    // LDS linear slot p = j*512 + tid (16 B each): row = p>>2 = j*128 + (tid>>2), slot q = tid&3.
+    // The slot holds logical k-chunk q ^ s[(row>>2)&3]; (row>>2)&3 == (tid>>4)&3 for both j.
+    const int thr_off = (tid >> 2) * 64 + (((tid & 3) ^ swz4((tid >> 4) & 3)) * 16);
+    const char* A_hi = (const char*)a.A_hi + (size_t)mt * T2S_TILE_M * 64 + thr_off;
+    const char* A_lo = (const char*)a.A_lo + (size_t)mt * T2S_TILE_M * 64 + thr_off;
+    const size_t a_kstride = (size_t)a.Mpad * 64;
+    const size_t x_cstride = (size_t)a.Lp * 64;            // bytes per 32-channel chunk
+    const char* X_hi = (const char*)a.X_hi + ((size_t)b * a.xc * a.Lp + a.halo + t0) * 64 + thr_off;
+    const char* X_lo = (const char*)a.X_lo + ((size_t)b * a.xc * a.Lp + a.halo + t0) * 64 + thr_off;
+    const char* S_hi = (const char*)a.S_hi + ((size_t)b * a.sc * a.Lp + a.halo + t0) * 64 + thr_off;
+    const char* S_lo = (const char*)a.S_lo + ((size_t)b * a.sc * a.Lp + a.halo + t0) * 64 + thr_off;
+    char* lds_wave = smem + wave * 1024;                   // + lane*16 is implicit in the DMA
+
+    auto stage = [&](int ks, int buf) {
+        char* dst = lds_wave + buf * STAGE_BYTES;
+        const char* ah = A_hi + (size_t)ks * a_kstride;
+        const char* al = A_lo + (size_t)ks * a_kstride;
+        const char *bh, *bl;
+        if (ks < a.nk_x) {
+            const int tap = ks / a.xc;
+            const int kc = ks - tap * a.xc;
+            const long off = (long)kc * (long)x_cstride + (long)((tap - (a.taps >> 1)) * a.dil) * 64;
+            bh = X_hi + off;
+            bl = X_lo + off;
+        } else {
+            const long off = (long)(ks - a.nk_x) * (long)x_cstride;
+            bh = S_hi + off;
+            bl = S_lo + off;
+        }
+        glds16(ah, dst);
+        glds16(ah + 8192, dst + 8192);
+        glds16(al, dst + PLANE_BYTES);
+        glds16(al + 8192, dst + PLANE_BYTES + 8192);
+        glds16(bh, dst + 2 * PLANE_BYTES);
+        glds16(bh + 8192, dst + 2 * PLANE_BYTES + 8192);
+        glds16(bl, dst + 3 * PLANE_BYTES);
+        glds16(bl + 8192, dst + 3 * PLANE_BYTES + 8192);
+    };
+
+    // ---- per-lane fragment read offset: row = lane&15, logical k-chunk = lane>>4 ----
+    const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ swz4((lane >> 2) & 3)) * 16);
+    const int a_frag = wr * 128 * 64 + frag_off;
+    const int b_frag = 2 * PLANE_BYTES + wc * 64 * 64 + frag_off;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = a.nk;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < nk) stage(ks + 1, cur ^ 1);
+        const char* sb = smem + cur * STAGE_BYTES;
+        bf16x8 bh[4], bl[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            bh[n] = *(const bf16x8*)(sb + b_frag + n * 1024);
+            bl[n] = *(const bf16x8*)(sb + b_frag + PLANE_BYTES + n * 1024);
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const bf16x8 ah = *(const bf16x8*)(sb + a_frag + m * 1024);
+            const bf16x8 al = *(const bf16x8*)(sb + a_frag + PLANE_BYTES + m * 1024);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D map of mfma 16x16: col = lane&15 (time), row = 4*(lane>>4) + reg (channel) ----
+    const int tcol = lane & 15;
+    const int rq = (lane >> 4) * 4;
+    if (EPI == EPI_GATE) {
+        // packed rows of this wave: m even = tanh rows, m odd = sigmoid rows of the same 16 channels
+#pragma unroll
+        for (int mp = 0; mp < 4; ++mp) {
+            const int prow = mt * T2S_TILE_M + wr * 128 + mp * 32 + rq;       // tanh rows prow..prow+3
+            const f32x4 bt = *(const f32x4*)(a.bias + prow);
+            const f32x4 bs = *(const f32x4*)(a.bias + prow + 16);
+            const int ch = mt * 128 + wr * 64 + mp * 16 + rq;                  // channels ch..ch+3
+            if (ch >= a.C) continue;
+            u16* ohi = a.O_hi + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+            u16* olo = a.O_lo + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int t = t0 + wc * 64 + n * 16 + tcol;
+                if (t >= a.L) continue;
+                u16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = fast_tanh(acc[2 * mp][n][e] + bt[e]) * fast_sigmoid(acc[2 * mp + 1][n][e] + bs[e]);
+                    u16 h, l;
+                    split_bf16(g, h, l);
+                    hi[e] = h;
+                    lo[e] = l;
+                }
+                *(u16x4*)(ohi + (size_t)t * 32) = hi;
+                *(u16x4*)(olo + (size_t)t * 32) = lo;
+            }
+        }
+    } else if (EPI == EPI_RESSKIP) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int prow = mt * T2S_TILE_M + wr * 128 + m * 16 + rq;
+            const f32x4 bv = *(const f32x4*)(a.bias + prow);
+            if (prow < a.n_res) {
+                const int ch = prow;
+                u16* xhi = a.O_hi + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+                u16* xlo = a.O_lo + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int t = t0 + wc * 64 + n * 16 + tcol;
+                    if (t >= a.L) continue;
+                    const u16x4 oh = *(const u16x4*)(xhi + (size_t)t * 32);
+                    const u16x4 ol = *(const u16x4*)(xlo + (size_t)t * 32);
+                    u16x4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = join_bf16(oh[e], ol[e]) + (acc[m][n][e] + bv[e]);
+                        u16 h, l;
+                        split_bf16(v, h, l);
+                        hi[e] = h;
+                        lo[e] = l;
+                    }
+                    *(u16x4*)(xhi + (size_t)t * 32) = hi;
+                    *(u16x4*)(xlo + (size_t)t * 32) = lo;
+                }
+            } else {
+                const int ch = prow - a.n_res;
+                if (ch >= a.C) continue;
+                float* sk = a.skip + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int t = t0 + wc * 64 + n * 16 + tcol;
+                    if (t >= a.L) continue;
+                    f32x4 v = acc[m][n] + bv;
+                    if (!a.skip_init) v += *(const f32x4*)(sk + (size_t)t * 32);
+                    *(f32x4*)(sk + (size_t)t * 32) = v;
+                }
+            }
+        }
+    } else {   // EPI_BIAS_ACT: out = act(acc + bias) -> planes (and optional f32 [B][C][L] copy)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int ch = mt * T2S_TILE_M + wr * 128 + m * 16 + rq;
+            if (ch >= a.C) continue;
+            const f32x4 bv = *(const f32x4*)(a.bias + ch);
+            u16* ohi = a.O_hi ? a.O_hi + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31) : nullptr;
+            u16* olo = a.O_lo ? a.O_lo + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31) : nullptr;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int t = t0 + wc * 64 + n * 16 + tcol;
+                if (t >= a.L) continue;
+                u16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[m][n][e] + bv[e];
+                    if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (a.act == ACT_TANH) v = fast_tanh(v);
+                    if (a.out_f32) a.out_f32[((size_t)b * a.C + ch + e) * a.L + t] = v;
+                    u16 h, l;
+                    split_bf16(v, h, l);
+                    hi[e] = h;
+                    lo[e] = l;
+                }
+                if (ohi) {
+                    *(u16x4*)(ohi + (size_t)t * 32) = hi;
+                    *(u16x4*)(olo + (size_t)t * 32) = lo;
+                }
+            }
+        }
+    }
+}
+
+static hipError_t launch(const ConvGemmArgs& a, int epi, hipStream_t stream) {
+    const int nwg = a.n_mtiles * a.n_ttiles * a.B;
+    const size_t lds = 2 * STAGE_BYTES;
+    hipError_t e;
+#define T2S_LAUNCH(E)                                                                                            \
+    do {                                                                                                         \
+        static bool attr_set = false;                                                                            \
+        if (!attr_set) {                                                                                         \
+            e = hipFuncSetAttribute((const void*)conv_gemm_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds);                                                                   \
+            if (e != hipSuccess) return e;                                                                       \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        hipLaunchKernelGGL(conv_gemm_kernel<E>, dim3(nwg), dim3(512), lds, stream, a);                           \
+    } while (0)
+    if (epi == EPI_GATE) T2S_LAUNCH(EPI_GATE);
+    else if (epi == EPI_RESSKIP) T2S_LAUNCH(EPI_RESSKIP);
+    else T2S_LAUNCH(EPI_BIAS_ACT);
+#undef T2S_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a, int epi, hipStream_t stream) { return launch(a, epi, stream); }

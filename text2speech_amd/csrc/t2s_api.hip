@@ -1,0 +1,192 @@
+// extern "C" boundary: argument validation + launch.  No torch types, no allocation, no sync.
+#include "../../include/t2s_hip.h"
+#include "t2s_kernels.h"
+
+#include <string.h>
+
+static thread_local char g_hip_err[256] = "";
+
+static int fail_hip(hipError_t e) {
+    strncpy(g_hip_err, hipGetErrorString(e), sizeof(g_hip_err) - 1);
+    g_hip_err[sizeof(g_hip_err) - 1] = 0;
+    return T2S_EHIP;
+}
+#define T2S_CHECK_HIP(expr)                   \
+    do {                                      \
+        hipError_t _e = (expr);               \
+        if (_e != hipSuccess) return fail_hip(_e); \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+extern "C" {
+
+int t2s_abi_version(void) { return 1; }
+
+const char* t2s_error_string(int code) {
+    switch (code) {
+        case T2S_OK: return "ok";
+        case T2S_EINVAL: return "invalid argument";
+        case T2S_EHIP: return "HIP runtime error";
+        default: return "unknown error";
+    }
+}
+const char* t2s_last_hip_error(void) { return g_hip_err; }
+
+int t2s_plane_rows(int L, int halo) { return cdiv(L, 256) * 256 + 2 * halo; }
+int t2s_padded_rows(int rows) { return cdiv(rows, 256) * 256; }
+
+int t2s_pack_conv_weight(const float* v, const float* g, const float* bias_in, int O, int Cin, int Kt, int perm,
+                         int C_gate, int row_off, int Mpad, int koff, int Cin_pad, void* A_hi, void* A_lo,
+                         float* bias_out, int bias_accumulate, void* stream) {
+    if (!v || !A_hi || !A_lo || O <= 0 || Cin <= 0 || Kt <= 0) return T2S_EINVAL;
+    if (Mpad % 256 || koff % 32 || Cin_pad % 32 || Cin_pad < Cin) return T2S_EINVAL;
+    if (perm == T2S_PERM_GATE) {
+        if (O != 2 * C_gate || cdiv(C_gate, 128) * 256 > Mpad) return T2S_EINVAL;
+    } else if (perm == T2S_PERM_NONE) {
+        if (row_off < 0 || row_off + O > Mpad) return T2S_EINVAL;
+    } else {
+        return T2S_EINVAL;
+    }
+    PackArgs a;
+    a.v = v; a.g = g; a.bias_in = bias_in;
+    a.A_hi = (u16*)A_hi; a.A_lo = (u16*)A_lo; a.bias_out = bias_out;
+    a.O = O; a.Cin = Cin; a.Kt = Kt; a.perm = perm; a.C_gate = C_gate; a.Mpad = Mpad; a.koff = koff;
+    a.Cin_pad = Cin_pad; a.bias_accumulate = bias_accumulate; a.row_off = row_off;
+    T2S_CHECK_HIP(t2s_launch_pack(a, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_weightnorm_small(const float* v, const float* g, int O, int K, float* w, void* stream) {
+    if (!v || !w || O <= 0 || K <= 0) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_weightnorm_small(v, g, O, K, w, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_wg_upsample_squeeze(const float* mel, const float* W, const float* bias, int B, int n_mel, int frames,
+                            int ksize, int stride, int n_group, int L, int Lp, int halo, void* S_hi, void* S_lo,
+                            void* stream) {
+    if (!mel || !W || !bias || !S_hi || !S_lo) return T2S_EINVAL;
+    if (B <= 0 || n_mel <= 0 || frames <= 0 || L <= 0 || n_group <= 0 || stride <= 0 || ksize % stride) return T2S_EINVAL;
+    if (!aligned16(W) || !aligned16(S_hi) || !aligned16(S_lo)) return T2S_EINVAL;
+    if (Lp < t2s_plane_rows(L, halo)) return T2S_EINVAL;
+    // every squeezed sample must exist in the transposed-conv output (reference glow.py:216 assert)
+    if ((long)L * n_group > (long)(frames - 1) * stride + ksize) return T2S_EINVAL;
+    if (n_group == 8 && (stride % 8 || ksize % 8)) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_upsample_squeeze(mel, W, bias, B, n_mel, frames, ksize, stride, n_group, L, Lp, halo,
+                                              (u16*)S_hi, (u16*)S_lo, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_wg_audio_squeeze(float* audio, float* z, int B, int T, int n_group, int L, int unsqueeze, void* stream) {
+    if (!audio || !z || B <= 0 || L <= 0 || n_group <= 0 || (long)L * n_group > T) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_audio_squeeze(audio, z, B, T, n_group, L, unsqueeze, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_wg_convinv(float* z, const float* W, int B, int n_group, int c_off, int n_rem, int L, void* stream) {
+    if (!z || !W || B <= 0 || L <= 0 || n_rem <= 0 || n_rem > 16 || c_off < 0 || c_off + n_rem > n_group) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_convinv(z, W, B, n_group, c_off, n_rem, L, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_small_logdet_inv(const float* W, int n, float scale, float* logdet_out, float* inv_out, void* stream) {
+    if (!W || n <= 0 || n > 16 || (!logdet_out && !inv_out)) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_small_logdet_inv(W, n, scale, logdet_out, inv_out, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_wg_start(const float* z, const float* w, const float* bias, int B, int n_group, int c_off, int n_half, int C,
+                 int L, int Lp, int halo, void* X_hi, void* X_lo, void* stream) {
+    if (!z || !w || !bias || !X_hi || !X_lo) return T2S_EINVAL;
+    if (B <= 0 || L <= 0 || C <= 0 || n_half <= 0 || n_half > 8 || c_off < 0 || c_off + n_half > n_group) return T2S_EINVAL;
+    if (!aligned16(X_hi) || !aligned16(X_lo) || Lp < t2s_plane_rows(L, halo)) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_start(z, w, bias, B, n_group, c_off, n_half, C, L, Lp, halo, (u16*)X_hi, (u16*)X_lo,
+                                   (hipStream_t)stream));
+    return T2S_OK;
+}
+
+static int check_planes(const void* a, const void* b) { return a && b && aligned16(a) && aligned16(b); }
+
+int t2s_wg_in_cond_gate(const void* A_hi, const void* A_lo, const float* bias, const void* X_hi, const void* X_lo,
+                        const void* S_hi, const void* S_lo, void* acts_hi, void* acts_lo, int B, int C, int n_cond,
+                        int taps, int dilation, int L, int Lp, int halo, int Mpad, void* stream) {
+    if (!check_planes(A_hi, A_lo) || !check_planes(X_hi, X_lo) || !check_planes(acts_hi, acts_lo) || !bias) return T2S_EINVAL;
+    if (n_cond > 0 && !check_planes(S_hi, S_lo)) return T2S_EINVAL;
+    if (B <= 0 || L <= 0 || C <= 0 || C % 4 || taps <= 0 || !(taps & 1) || dilation <= 0) return T2S_EINVAL;
+    if ((taps / 2) * dilation > halo || Lp != t2s_plane_rows(L, halo)) return T2S_EINVAL;
+    if (Mpad % 256 || Mpad < cdiv(C, 128) * 256 || !aligned16(bias)) return T2S_EINVAL;
+    ConvGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A_hi = (const u16*)A_hi; a.A_lo = (const u16*)A_lo;
+    a.X_hi = (const u16*)X_hi; a.X_lo = (const u16*)X_lo;
+    a.S_hi = (const u16*)S_hi; a.S_lo = (const u16*)S_lo;
+    a.bias = bias; a.O_hi = (u16*)acts_hi; a.O_lo = (u16*)acts_lo;
+    a.xc = cdiv(C, 32); a.sc = cdiv(n_cond, 32); a.oc = cdiv(C, 32);
+    a.taps = taps; a.dil = dilation;
+    a.nk_x = taps * a.xc; a.nk = a.nk_x + a.sc;
+    a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
+    a.n_mtiles = cdiv(C, 128); a.n_ttiles = cdiv(L, 256);
+    a.C = C;
+    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_GATE, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_wg_res_skip(const void* A_hi, const void* A_lo, const float* bias, const void* acts_hi, const void* acts_lo,
+                    void* X_hi, void* X_lo, float* skip, int B, int C, int n_res, int skip_init, int L, int Lp,
+                    int halo, int Mpad, void* stream) {
+    if (!check_planes(A_hi, A_lo) || !check_planes(acts_hi, acts_lo) || !bias || !skip || !aligned16(skip)) return T2S_EINVAL;
+    if (n_res > 0 && !check_planes(X_hi, X_lo)) return T2S_EINVAL;
+    if (B <= 0 || L <= 0 || C <= 0 || C % 4 || (n_res != 0 && n_res != C)) return T2S_EINVAL;
+    if (Lp != t2s_plane_rows(L, halo) || Mpad % 256 || Mpad < n_res + C || !aligned16(bias)) return T2S_EINVAL;
+    ConvGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A_hi = (const u16*)A_hi; a.A_lo = (const u16*)A_lo;
+    a.X_hi = (const u16*)acts_hi; a.X_lo = (const u16*)acts_lo;
+    a.bias = bias; a.O_hi = (u16*)X_hi; a.O_lo = (u16*)X_lo; a.skip = skip;
+    a.xc = cdiv(C, 32); a.sc = 0; a.oc = cdiv(C, 32);
+    a.taps = 1; a.dil = 1;
+    a.nk_x = a.xc; a.nk = a.xc;
+    a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
+    a.n_mtiles = cdiv(n_res + C, 256); a.n_ttiles = cdiv(L, 256);
+    a.C = C; a.n_res = n_res; a.skip_init = skip_init;
+    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_RESSKIP, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_wg_end_affine(const float* skip, const float* w_end, const float* b_end, float* z, float* log_s, int B,
+                      int n_group, int c_off, int n_half, int C, int L, int Lp, int halo, int reverse, void* stream) {
+    if (!skip || !w_end || !b_end || !z) return T2S_EINVAL;
+    if (B <= 0 || L <= 0 || C <= 0 || n_half <= 0 || n_half > 8 || c_off < 0 || c_off + 2 * n_half > n_group) return T2S_EINVAL;
+    if (Lp < t2s_plane_rows(L, halo)) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_end_affine(skip, w_end, b_end, z, log_s, B, n_group, c_off, n_half, C, L, Lp, halo,
+                                        reverse, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_conv_bias_act(const void* A_hi, const void* A_lo, const float* bias, const void* X_hi, const void* X_lo,
+                      void* O_hi, void* O_lo, float* out_f32, int B, int Cin, int Cout, int taps, int dilation,
+                      int act, int L, int Lp, int halo, int Mpad, void* stream) {
+    if (!check_planes(A_hi, A_lo) || !check_planes(X_hi, X_lo) || !bias || !aligned16(bias)) return T2S_EINVAL;
+    if ((O_hi || O_lo) && !check_planes(O_hi, O_lo)) return T2S_EINVAL;
+    if (!O_hi && !out_f32) return T2S_EINVAL;
+    if (B <= 0 || L <= 0 || Cin <= 0 || Cout <= 0 || Cout % 4 || taps <= 0 || !(taps & 1) || dilation <= 0) return T2S_EINVAL;
+    if ((taps / 2) * dilation > halo || Lp != t2s_plane_rows(L, halo) || Mpad % 256 || Mpad < Cout) return T2S_EINVAL;
+    if (act < T2S_ACT_NONE || act > T2S_ACT_TANH) return T2S_EINVAL;
+    ConvGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A_hi = (const u16*)A_hi; a.A_lo = (const u16*)A_lo;
+    a.X_hi = (const u16*)X_hi; a.X_lo = (const u16*)X_lo;
+    a.bias = bias; a.O_hi = (u16*)O_hi; a.O_lo = (u16*)O_lo; a.out_f32 = out_f32;
+    a.xc = cdiv(Cin, 32); a.sc = 0; a.oc = cdiv(Cout, 32);
+    a.taps = taps; a.dil = dilation;
+    a.nk_x = taps * a.xc; a.nk = a.nk_x;
+    a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
+    a.n_mtiles = cdiv(Cout, 256); a.n_ttiles = cdiv(L, 256);
+    a.C = Cout; a.act = act;
+    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_BIAS_ACT, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// Shared device helpers for the gfx950 kernels.
+//
+// Data layout used everywhere on the WaveGlow path ("planes"):
+//   an activation tensor with C channels and L time steps per batch element is
+//   stored channel-last in 32-channel chunks as TWO bf16 planes (hi, lo) with
+//       x  ~=  float(hi) + float(lo)          (split-bf16, ~16 mantissa bits)
+//   plane[b][c / 32][row][c % 32],   row = halo + t,   0 <= row < Lp
+//   Rows outside [halo, halo + L) are zero and are never written: they are the
+//   zero padding of the dilated convolutions (reference glow.py:134-137).
+//   One 32-channel row is 64 B, so a 256-row K-step tile is one contiguous
+//   16 KiB block that is fetched straight into LDS by global_load_lds.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short u16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+
+#define T2S_CHUNK 32            // channels per plane chunk (= one BK step of the GEMM)
+#define T2S_TILE_M 256          // output-channel rows per workgroup
+#define T2S_TILE_N 256          // time steps per workgroup
+
+static __device__ __forceinline__ u16 bf16_bits(float x) {
+    __bf16 h = (__bf16)x;                      // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+    return __builtin_bit_cast(u16, h);
+}
+static __device__ __forceinline__ float bf16_to_f32(u16 b) {
+    return __builtin_bit_cast(float, (uint32_t)b << 16);
+}
+// x -> (hi, lo) with hi = bf16(x), lo = bf16(x - hi); x - hi is exact in f32.
+static __device__ __forceinline__ void split_bf16(float x, u16& hi, u16& lo) {
+    hi = bf16_bits(x);
+    lo = bf16_bits(x - bf16_to_f32(hi));
+}
+static __device__ __forceinline__ float join_bf16(u16 hi, u16 lo) {
+    return bf16_to_f32(hi) + bf16_to_f32(lo);
+}
+
+static __device__ __forceinline__ float fast_sigmoid(float x) {
+    return 1.0f / (1.0f + __expf(-x));
+}
+static __device__ __forceinline__ float fast_tanh(float x) {
+    // tanh(x) = 1 - 2 / (exp(2x) + 1); saturates cleanly at +-1 for large |x|
+    return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f);
+}
+
+// wave-wide sum (64 lanes)
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}

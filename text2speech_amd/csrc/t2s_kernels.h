@@ -1,0 +1,69 @@
+// Internal launcher prototypes shared by the .hip translation units and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short u16;
+
+enum { EPI_GATE = 0, EPI_RESSKIP = 1, EPI_BIAS_ACT = 2 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
+enum { PERM_NONE = 0, PERM_GATE = 1 };
+
+struct ConvGemmArgs {
+    const u16* A_hi;   // packed weights [nk][Mpad][32] bf16
+    const u16* A_lo;
+    const u16* X_hi;   // input planes [B][xc][Lp][32] bf16
+    const u16* X_lo;
+    const u16* S_hi;   // second (conditioning) input planes [B][sc][Lp][32], or null
+    const u16* S_lo;
+    const float* bias; // [Mpad], packed row order
+    u16* O_hi;         // output planes [B][oc][Lp][32] (GATE: acts; RESSKIP: x, updated in place)
+    u16* O_lo;
+    float* skip;       // RESSKIP: f32 skip accumulator planes [B][oc][Lp][32]
+    float* out_f32;    // BIAS_ACT: optional [B][C][L] f32 copy
+    int nk;            // total K-steps = taps*xc + sc
+    int nk_x;          // taps*xc
+    int xc, sc, oc;    // 32-channel chunks of X, S and the output
+    int taps, dil;
+    int Mpad, Lp, halo, L, B;
+    int n_mtiles, n_ttiles;
+    int C;             // valid output channels
+    int n_res;         // RESSKIP: packed rows < n_res are the residual half
+    int skip_init;     // RESSKIP: 1 = store, 0 = accumulate
+    int act;           // BIAS_ACT
+};
+
+hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a, int epi, hipStream_t stream);
+
+struct PackArgs {
+    const float* v;        // [O][Cin][Kt]
+    const float* g;        // [O] weight-norm gain, or null for a plain weight
+    const float* bias_in;  // [O] or null
+    u16* A_hi;             // [nk][Mpad][32]
+    u16* A_lo;
+    float* bias_out;       // [Mpad] packed order, or null
+    int O, Cin, Kt;
+    int perm, C_gate;      // PERM_GATE: rows o<C_gate are tanh rows, o>=C_gate sigmoid rows
+    int Mpad;
+    int koff;              // first packed k index of this block (multiple of 32)
+    int Cin_pad;           // tap stride in packed k (Cin rounded up to 32)
+    int bias_accumulate;   // 1: bias_out[p] += bias_in[o]
+    int row_off;           // PERM_NONE: packed row = o + row_off
+};
+hipError_t t2s_launch_pack(const PackArgs& a, hipStream_t stream);
+hipError_t t2s_launch_weightnorm_small(const float* v, const float* g, int O, int K, float* w, hipStream_t stream);
+
+hipError_t t2s_launch_upsample_squeeze(const float* mel, const float* W, const float* bias, int B, int n_mel,
+                                       int frames, int ksize, int stride, int n_group, int L, int Lp, int halo,
+                                       u16* S_hi, u16* S_lo, hipStream_t stream);
+hipError_t t2s_launch_audio_squeeze(const float* audio, float* z, int B, int T, int n_group, int L, int unsqueeze,
+                                    hipStream_t stream);
+hipError_t t2s_launch_convinv(float* z, const float* W, int B, int n_group, int c_off, int n_rem, int L,
+                              hipStream_t stream);
+hipError_t t2s_launch_small_logdet_inv(const float* W, int n, float scale, float* logdet_out, float* inv_out,
+                                       hipStream_t stream);
+hipError_t t2s_launch_start(const float* z, const float* w, const float* bias, int B, int n_group, int c_off,
+                            int n_half, int C, int L, int Lp, int halo, u16* X_hi, u16* X_lo, hipStream_t stream);
+hipError_t t2s_launch_end_affine(const float* skip, const float* w_end, const float* b_end, float* z, float* log_s,
+                                 int B, int n_group, int c_off, int n_half, int C, int L, int Lp, int halo,
+                                 int reverse, hipStream_t stream);

@@ -1,0 +1,373 @@
+// Bandwidth-bound WaveGlow stages around the WN GEMMs (all VALU, no MFMA):
+// weight-norm + packing, mel upsample + squeeze, audio squeeze, invertible 1x1
+// conv, WN.start, WN.end + affine coupling.  Each kernel cites the reference
+// lines it restates.  Layout of the (hi, lo) bf16 planes: t2s_common.h.
+#include "t2s_common.h"
+#include "t2s_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// weight_norm (w = v * g / ||v||, reference glow.py:123,138,142,151) fused with the packing of the
+// effective weight into the GEMM's A operand: split to (hi, lo) bf16, K reordered tap-major, rows
+// permuted so that a wave owns the tanh row and the sigmoid row of the same channel.
+// One workgroup per output row.
+__global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
+    __shared__ float red[4];
+    const int o = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = a.Cin * a.Kt;
+    const float* vrow = a.v + (size_t)o * n;
+    float scale = 1.0f;
+    if (a.g) {
+        float ss = 0.f;
+        for (int i = tid; i < n; i += 256) {
+            const float x = vrow[i];
+            ss += x * x;
+        }
+        ss = wave_sum(ss);
+        if ((tid & 63) == 0) red[tid >> 6] = ss;
+        __syncthreads();
+        ss = red[0] + red[1] + red[2] + red[3];
+        scale = a.g[o] / sqrtf(ss);
+    }
+    int p;
+    if (a.perm == PERM_GATE) {
+        const int gate = o >= a.C_gate;
+        const int ch = gate ? o - a.C_gate : o;
+        p = (ch >> 7) * 256 + ((ch >> 6) & 1) * 128 + (((ch >> 4) & 3) * 2 + gate) * 16 + (ch & 15);
+    } else {
+        p = o + a.row_off;
+    }
+    for (int i = tid; i < n; i += 256) {
+        const int tap = i / a.Cin;
+        const int c = i - tap * a.Cin;
+        const float w = vrow[c * a.Kt + tap] * scale;
+        const int k = a.koff + tap * a.Cin_pad + c;
+        const size_t idx = ((size_t)(k >> 5) * a.Mpad + p) * 32 + (k & 31);
+        u16 h, l;
+        split_bf16(w, h, l);
+        a.A_hi[idx] = h;
+        a.A_lo[idx] = l;
+    }
+    if (tid == 0 && a.bias_out) {
+        const float bi = a.bias_in ? a.bias_in[o] : 0.f;
+        a.bias_out[p] = a.bias_accumulate ? a.bias_out[p] + bi : bi;
+    }
+}
+
+hipError_t t2s_launch_pack(const PackArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_kernel, dim3(a.O), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// Effective weight of a small weight-normed conv (WN.start, K = n_half): w[o][k] = v*g/||v||.
+__global__ void weightnorm_small_kernel(const float* v, const float* g, int O, int K, float* w) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= O) return;
+    float ss = 0.f;
+    for (int k = 0; k < K; ++k) ss += v[o * K + k] * v[o * K + k];
+    const float s = g ? g[o] / sqrtf(ss) : 1.f;
+    for (int k = 0; k < K; ++k) w[o * K + k] = v[o * K + k] * s;
+}
+hipError_t t2s_launch_weightnorm_small(const float* v, const float* g, int O, int K, float* w, hipStream_t stream) {
+    hipLaunchKernelGGL(weightnorm_small_kernel, dim3((O + 255) / 256), dim3(256), 0, stream, v, g, O, K, w);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// ConvTranspose1d(n_mel, n_mel, ksize, stride) + trim + squeeze-by-n_group, written straight into
+// the conditioning planes (reference glow.py:183-185,215-221; infer: glow.py:252-258).
+//   spect[b][co*G + g][t] = bias[co] + sum_{ci,f} mel[b][ci][f] * W[ci][co][G*t + g - stride*f]
+// One thread = 8 consecutive squeezed channels of one time step for up to BB batch elements, so each
+// weight value fetched is reused BB times; the 8 results are one 16-B store per plane.
+template <int BB>
+__global__ __launch_bounds__(256) void upsample_squeeze_kernel(const float* __restrict__ mel, const float* __restrict__ W,
+                                                               const float* __restrict__ bias, int B, int M, int F,
+                                                               int ksize, int stride, int G, int L, int Lp, int halo,
+                                                               u16* S_hi, u16* S_lo) {
+    const int tid = threadIdx.x;
+    const int q = tid & 3;
+    const int t = blockIdx.x * 64 + (tid >> 2);
+    const int chunk = blockIdx.y;
+    const int b0 = blockIdx.z * BB;
+    const int c8 = chunk * 32 + q * 8;          // first squeezed channel of this thread
+    const int nchan = M * G;
+    if (t >= L || c8 >= nchan) return;
+    float acc[BB][8];
+#pragma unroll
+    for (int bb = 0; bb < BB; ++bb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[bb][j] = 0.f;
+    const int nf = ksize / stride;
+    if (G == 8) {
+        const int co = c8 >> 3;
+        const int s0 = 8 * t;
+        const int fhi = s0 / stride;
+        const int kbase = s0 - fhi * stride;
+        for (int ci = 0; ci < M; ++ci) {
+            const float* wrow = W + ((size_t)ci * M + co) * ksize + kbase;
+            for (int i = 0; i < nf; ++i) {
+                const int f = fhi - i;
+                if (f < 0 || f >= F) continue;
+                const f32x4 w0 = *(const f32x4*)(wrow + i * stride);
+                const f32x4 w1 = *(const f32x4*)(wrow + i * stride + 4);
+#pragma unroll
+                for (int bb = 0; bb < BB; ++bb) {
+                    if (b0 + bb >= B) break;
+                    const float m = mel[((size_t)(b0 + bb) * M + ci) * F + f];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[bb][j] += m * w0[j];
+                        acc[bb][4 + j] += m * w1[j];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int bb = 0; bb < BB; ++bb)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[bb][j] += bias[co];
+    } else {
+        for (int j = 0; j < 8; ++j) {
+            const int cidx = c8 + j;
+            if (cidx >= nchan) break;
+            const int co = cidx / G, g = cidx - co * G;
+            const int s = G * t + g;
+            const int fhi = s / stride;
+            for (int ci = 0; ci < M; ++ci)
+                for (int i = 0; i < nf; ++i) {
+                    const int f = fhi - i;
+                    if (f < 0 || f >= F) continue;
+                    const float w = W[((size_t)ci * M + co) * ksize + (s - f * stride)];
+                    for (int bb = 0; bb < BB; ++bb)
+                        if (b0 + bb < B) acc[bb][j] += mel[((size_t)(b0 + bb) * M + ci) * F + f] * w;
+                }
+            for (int bb = 0; bb < BB; ++bb) acc[bb][j] += bias[co];
+        }
+    }
+    const int nchunks = (nchan + 31) / 32;
+#pragma unroll
+    for (int bb = 0; bb < BB; ++bb) {
+        if (b0 + bb >= B) break;
+        const size_t row = ((size_t)(b0 + bb) * nchunks + chunk) * Lp + halo + t;
+        u16 hi[8], lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = (c8 + j < nchan) ? acc[bb][j] : 0.f;
+            split_bf16(v, hi[j], lo[j]);
+        }
+        uint4 ph, pl;
+        ph.x = hi[0] | ((uint32_t)hi[1] << 16); ph.y = hi[2] | ((uint32_t)hi[3] << 16);
+        ph.z = hi[4] | ((uint32_t)hi[5] << 16); ph.w = hi[6] | ((uint32_t)hi[7] << 16);
+        pl.x = lo[0] | ((uint32_t)lo[1] << 16); pl.y = lo[2] | ((uint32_t)lo[3] << 16);
+        pl.z = lo[4] | ((uint32_t)lo[5] << 16); pl.w = lo[6] | ((uint32_t)lo[7] << 16);
+        *(uint4*)(S_hi + row * 32 + q * 8) = ph;
+        *(uint4*)(S_lo + row * 32 + q * 8) = pl;
+    }
+}
+
+hipError_t t2s_launch_upsample_squeeze(const float* mel, const float* W, const float* bias, int B, int n_mel,
+                                       int frames, int ksize, int stride, int n_group, int L, int Lp, int halo,
+                                       u16* S_hi, u16* S_lo, hipStream_t stream) {
+    const int nchunks = (n_mel * n_group + 31) / 32;
+    constexpr int BB = 8;
+    dim3 grid((L + 63) / 64, nchunks, (B + BB - 1) / BB);
+    hipLaunchKernelGGL(upsample_squeeze_kernel<BB>, grid, dim3(256), 0, stream, mel, W, bias, B, n_mel, frames, ksize,
+                       stride, n_group, L, Lp, halo, S_hi, S_lo);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// audio [B][T] <-> z [B][G][L], z[b][g][t] = audio[b][G*t + g]  (reference glow.py:223 / 291)
+__global__ void audio_squeeze_kernel(const float* audio, float* z, int B, int T, int G, int L, int unsq) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= L) return;
+    for (int g = 0; g < G; ++g) {
+        if (unsq)
+            ((float*)audio)[(size_t)b * T + (size_t)G * t + g] = z[((size_t)b * G + g) * L + t];
+        else
+            z[((size_t)b * G + g) * L + t] = audio[(size_t)b * T + (size_t)G * t + g];
+    }
+}
+hipError_t t2s_launch_audio_squeeze(const float* audio, float* z, int B, int T, int n_group, int L, int unsqueeze,
+                                    hipStream_t stream) {
+    hipLaunchKernelGGL(audio_squeeze_kernel, dim3((L + 255) / 256, B), dim3(256), 0, stream, audio, z, B, T, n_group,
+                       L, unsqueeze);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Invertible 1x1 conv applied in place to channels [c_off, c_off + n_rem) of z [B][G][L]
+// (reference glow.py:82-102; the reverse direction passes W^-1).
+__global__ void convinv_kernel(float* z, const float* __restrict__ W, int G, int c_off, int n, int L) {
+    __shared__ float w[16 * 16];
+    if (threadIdx.x < n * n) w[threadIdx.x] = W[threadIdx.x];
+    __syncthreads();
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= L) return;
+    float* base = z + ((size_t)b * G + c_off) * L + t;
+    float v[16], o[16];
+    for (int j = 0; j < n; ++j) v[j] = base[(size_t)j * L];
+    for (int i = 0; i < n; ++i) {
+        float s = 0.f;
+        for (int j = 0; j < n; ++j) s += w[i * n + j] * v[j];
+        o[i] = s;
+    }
+    for (int i = 0; i < n; ++i) base[(size_t)i * L] = o[i];
+}
+hipError_t t2s_launch_convinv(float* z, const float* W, int B, int n_group, int c_off, int n_rem, int L,
+                              hipStream_t stream) {
+    hipLaunchKernelGGL(convinv_kernel, dim3((L + 255) / 256, B), dim3(256), 0, stream, z, W, n_group, c_off, n_rem, L);
+    return hipGetLastError();
+}
+
+// log(det W) * scale and (optionally) W^-1 for an n x n matrix, n <= 16, by partial-pivot
+// Gauss-Jordan in one thread (reference glow.py:90-91,100: W.inverse(), torch.logdet(W)).
+// A negative determinant yields NaN, as torch.logdet does.
+__global__ void small_logdet_inv_kernel(const float* W, int n, float scale, float* logdet_out, float* inv_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double a[16][32];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            a[i][j] = W[i * n + j];
+            a[i][n + j] = (i == j) ? 1.0 : 0.0;
+        }
+    double logabs = 0.0;
+    int sign = 1;
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        double best = fabs(a[c][c]);
+        for (int r = c + 1; r < n; ++r)
+            if (fabs(a[r][c]) > best) { best = fabs(a[r][c]); piv = r; }
+        if (piv != c) {
+            for (int j = 0; j < 2 * n; ++j) { double tmp = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = tmp; }
+            sign = -sign;
+        }
+        const double d = a[c][c];
+        if (d < 0) sign = -sign;
+        logabs += log(fabs(d));
+        const double inv = 1.0 / d;
+        for (int j = 0; j < 2 * n; ++j) a[c][j] *= inv;
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            const double f = a[r][c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < 2 * n; ++j) a[r][j] -= f * a[c][j];
+        }
+    }
+    if (logdet_out) *logdet_out = sign > 0 ? (float)(logabs * (double)scale) : __builtin_nanf("");
+    if (inv_out)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) inv_out[i * n + j] = (float)a[i][n + j];
+}
+hipError_t t2s_launch_small_logdet_inv(const float* W, int n, float scale, float* logdet_out, float* inv_out,
+                                       hipStream_t stream) {
+    hipLaunchKernelGGL(small_logdet_inv_kernel, dim3(1), dim3(64), 0, stream, W, n, scale, logdet_out, inv_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// WN.start: x[c][t] = bias[c] + sum_j w[c][j] * z[b][c_off + j][t]  -> (hi, lo) planes
+// (reference glow.py:122-124,156).  One thread = 8 channels of one time step = one 16-B store per plane.
+__global__ __launch_bounds__(256) void start_kernel(const float* __restrict__ z, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, int G, int c_off, int nh, int C,
+                                                    int L, int Lp, int halo, u16* X_hi, u16* X_lo) {
+    const int tid = threadIdx.x;
+    const int q = tid & 3;
+    const int t = blockIdx.x * 64 + (tid >> 2);
+    const int chunk = blockIdx.y;
+    const int b = blockIdx.z;
+    const int c8 = chunk * 32 + q * 8;
+    if (t >= L) return;
+    float a0[8];
+    for (int j = 0; j < nh; ++j) a0[j] = z[((size_t)b * G + c_off + j) * L + t];
+    u16 hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c8 + e;
+        float v = 0.f;
+        if (c < C) {
+            v = bias[c];
+            for (int j = 0; j < nh; ++j) v += w[c * nh + j] * a0[j];
+        }
+        split_bf16(v, hi[e], lo[e]);
+    }
+    const int nchunks = (C + 31) / 32;
+    const size_t row = ((size_t)b * nchunks + chunk) * Lp + halo + t;
+    uint4 ph, pl;
+    ph.x = hi[0] | ((uint32_t)hi[1] << 16); ph.y = hi[2] | ((uint32_t)hi[3] << 16);
+    ph.z = hi[4] | ((uint32_t)hi[5] << 16); ph.w = hi[6] | ((uint32_t)hi[7] << 16);
+    pl.x = lo[0] | ((uint32_t)lo[1] << 16); pl.y = lo[2] | ((uint32_t)lo[3] << 16);
+    pl.z = lo[4] | ((uint32_t)lo[5] << 16); pl.w = lo[6] | ((uint32_t)lo[7] << 16);
+    *(uint4*)(X_hi + row * 32 + q * 8) = ph;
+    *(uint4*)(X_lo + row * 32 + q * 8) = pl;
+}
+hipError_t t2s_launch_start(const float* z, const float* w, const float* bias, int B, int n_group, int c_off,
+                            int n_half, int C, int L, int Lp, int halo, u16* X_hi, u16* X_lo, hipStream_t stream) {
+    dim3 grid((L + 63) / 64, (C + 31) / 32, B);
+    hipLaunchKernelGGL(start_kernel, grid, dim3(256), 0, stream, z, w, bias, n_group, c_off, n_half, C, L, Lp, halo,
+                       X_hi, X_lo);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// WN.end (1x1 conv C -> 2*n_half on the f32 skip planes) fused with the affine coupling
+//   forward: a1 = exp(log_s) * a1 + b      (reference glow.py:175,241-246)
+//   reverse: a1 = (a1 - b) / exp(s)        (reference glow.py:276-280)
+// Half a wave (32 lanes = one 128-B skip row) per time step; the 2*n_half dot products are reduced
+// with wavefront shuffles.
+__global__ __launch_bounds__(256) void end_affine_kernel(const float* __restrict__ skip, const float* __restrict__ w_end,
+                                                         const float* __restrict__ b_end, float* z, float* log_s,
+                                                         int G, int c_off, int nh, int C, int L, int Lp, int halo,
+                                                         int reverse) {
+    const int tid = threadIdx.x;
+    const int l32 = tid & 31;
+    const int t = blockIdx.x * 8 + (tid >> 5);
+    const int b = blockIdx.y;
+    const int nj = 2 * nh;
+    const int nchunks = (C + 31) / 32;
+    float part[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) part[j] = 0.f;
+    const bool tv = t < L;
+    if (tv) {
+        for (int ck = 0; ck < nchunks; ++ck) {
+            const int c = ck * 32 + l32;
+            if (c < C) {
+                const float v = skip[(((size_t)b * nchunks + ck) * Lp + halo + t) * 32 + l32];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j < nj) part[j] += v * w_end[j * C + c];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j < nj) {
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) part[j] += __shfl_xor(part[j], off, 64);
+        }
+    }
+    if (tv && l32 < nh) {
+        float bb = 0.f, ls = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (j == l32) bb = part[j];
+            if (j == nh + l32) ls = part[j];
+        }
+        bb += b_end[l32];
+        ls += b_end[nh + l32];
+        float* zp = z + ((size_t)b * G + c_off + nh + l32) * L + t;
+        const float a1 = *zp;
+        *zp = reverse ? (a1 - bb) / expf(ls) : expf(ls) * a1 + bb;
+        if (log_s) log_s[((size_t)b * nh + l32) * L + t] = ls;
+    }
+}
+hipError_t t2s_launch_end_affine(const float* skip, const float* w_end, const float* b_end, float* z, float* log_s,
+                                 int B, int n_group, int c_off, int n_half, int C, int L, int Lp, int halo,
+                                 int reverse, hipStream_t stream) {
+    hipLaunchKernelGGL(end_affine_kernel, dim3((L + 7) / 8, B), dim3(256), 0, stream, skip, w_end, b_end, z, log_s,
+                       n_group, c_off, n_half, C, L, Lp, halo, reverse);
+    return hipGetLastError();
+}

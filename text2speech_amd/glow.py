@@ -1,0 +1,410 @@
+"""MI355X-native WaveGlow with the reference module API.
+
+Drop-in for reference ``waveglow/glow.py``: same class names, constructor
+signatures, attribute names (``upsample``, ``WN``, ``convinv``,
+``n_remaining_channels`` ...) and ``state_dict`` keys, so checkpoints and the
+reference's ``train.py`` / ``inference.py`` / ``denoiser.py`` call sites keep
+working.  The math does not run through these ``nn.Module``
+containers: ``forward`` / ``infer`` drive the hand-written gfx950 kernels of
+``libt2s_hip.so`` through the C ABI (include/t2s_hip.h).  There is no CPU or
+eager-PyTorch fallback: without the library, or off-GPU, the calls raise.
+
+Reference lines are cited per method.
+"""
+import math
+
+import torch
+import torch.nn.functional as F  # noqa: F401  (kept for API parity with the reference module)
+
+from . import _lib
+
+
+class WaveGlowLoss(torch.nn.Module):
+    """Reference glow.py:43-59.  Scalar NLL of the flow output; the reductions
+    run on whatever device the outputs live on (tiny: <= B*8*L elements)."""
+
+    def __init__(self, sigma=1.0):
+        super().__init__()
+        self.sigma = sigma
+
+    def forward(self, model_output):
+        z, log_s_list, log_det_W_list = model_output
+        log_s_total = None
+        log_det_W_total = None
+        for i, log_s in enumerate(log_s_list):
+            s = torch.sum(log_s)
+            log_s_total = s if log_s_total is None else log_s_total + s
+            d = log_det_W_list[i]
+            log_det_W_total = d if log_det_W_total is None else log_det_W_total + d
+        loss = torch.sum(z * z) / (2 * self.sigma * self.sigma) - log_s_total - log_det_W_total
+        return loss / (z.size(0) * z.size(1) * z.size(2))
+
+
+class Invertible1x1Conv(torch.nn.Module):
+    """Parameter container for the invertible 1x1 convolution (reference
+    glow.py:62-80: QR-orthonormal init with det forced to +1).  The conv itself
+    and log|det W| are computed by ``t2s_wg_convinv`` / ``t2s_small_logdet_inv``."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv = torch.nn.Conv1d(c, c, kernel_size=1, stride=1, padding=0, bias=False)
+        W = torch.linalg.qr(torch.randn(c, c))[0]
+        if torch.det(W) < 0:
+            W[:, 0] = -1 * W[:, 0]
+        self.conv.weight.data = W.contiguous().view(c, c, 1)
+
+
+class WN(torch.nn.Module):
+    """Parameter container for the coupling network (reference glow.py:105-152):
+    weight-normed ``start``, zero-initialised ``end``, and per layer a dilated
+    ``in_layers[i]``, a 1x1 ``cond_layers[i]`` and a 1x1 ``res_skip_layers[i]``."""
+
+    def __init__(self, n_in_channels, n_mel_channels, n_layers, n_channels, kernel_size):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        assert n_channels % 2 == 0
+        self.n_layers = n_layers
+        self.n_channels = n_channels
+        self.kernel_size = kernel_size
+        self.in_layers = torch.nn.ModuleList()
+        self.res_skip_layers = torch.nn.ModuleList()
+        self.cond_layers = torch.nn.ModuleList()
+        wn = torch.nn.utils.weight_norm
+        self.start = wn(torch.nn.Conv1d(n_in_channels, n_channels, 1), name="weight")
+        end = torch.nn.Conv1d(n_channels, 2 * n_in_channels, 1)
+        end.weight.data.zero_()
+        end.bias.data.zero_()
+        self.end = end
+        for i in range(n_layers):
+            dilation = 2 ** i
+            padding = (kernel_size * dilation - dilation) // 2
+            self.in_layers.append(wn(torch.nn.Conv1d(n_channels, 2 * n_channels, kernel_size,
+                                                     dilation=dilation, padding=padding), name="weight"))
+            self.cond_layers.append(wn(torch.nn.Conv1d(n_mel_channels, 2 * n_channels, 1), name="weight"))
+            rs = 2 * n_channels if i < n_layers - 1 else n_channels
+            self.res_skip_layers.append(wn(torch.nn.Conv1d(n_channels, rs, 1), name="weight"))
+
+
+def _vg(conv):
+    """(v, g) of a weight-normed conv, or (weight, None) after remove_weightnorm."""
+    if hasattr(conv, "weight_v"):
+        return conv.weight_v, conv.weight_g
+    return conv.weight, None
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _Engine:
+    """Owns the HBM-resident state of one WaveGlow: packed (hi, lo) bf16 weight
+    planes and the activation workspaces, and issues the kernel sequence."""
+
+    def __init__(self, model):
+        self.m = model
+        self.packed = None
+        self.packed_key = None
+        self.ws = {}
+        self.gemm_events = None     # bench.py: list of (start, end) torch.cuda.Event pairs around the gate GEMM
+
+    # ------------------------------------------------------------------ geometry
+    def geom(self):
+        m = self.m
+        wn0 = m.WN[0]
+        C, nl, ks = wn0.n_channels, wn0.n_layers, wn0.kernel_size
+        n_cond = m.upsample.out_channels * m.n_group
+        g = dict(C=C, nl=nl, ks=ks, n_cond=n_cond, Cpad=-(-C // 32) * 32, Spad=-(-n_cond // 32) * 32,
+                 halo=(2 ** (nl - 1)) * (ks // 2), Mpad1=-(-C // 128) * 256)
+        g["nk1"] = ks * g["Cpad"] // 32 + g["Spad"] // 32
+        g["nk2"] = g["Cpad"] // 32
+        return g
+
+    # ------------------------------------------------------------------ weights
+    def pack_weights(self, device, force=True):
+        m = self.m
+        key = tuple(p._version for p in m.parameters()) + (str(device),)
+        if not force and self.packed is not None and self.packed_key == key:
+            return self.packed
+        g = self.geom()
+        C, nl, ks = g["C"], g["nl"], g["ks"]
+        st = _lib.current_stream()
+        if self.packed is None or self.packed["device"] != device:
+            flows = []
+            for k in range(m.n_flows):
+                n_half = m.WN[k].start.in_channels
+                layers = []
+                for i in range(nl):
+                    rows2 = 2 * C if i < nl - 1 else C
+                    Mpad2 = _lib.padded_rows(rows2)
+                    layers.append(dict(
+                        A1h=torch.zeros(g["nk1"], g["Mpad1"], 32, dtype=torch.bfloat16, device=device),
+                        A1l=torch.zeros(g["nk1"], g["Mpad1"], 32, dtype=torch.bfloat16, device=device),
+                        b1=torch.zeros(g["Mpad1"], dtype=torch.float32, device=device),
+                        A2h=torch.zeros(g["nk2"], Mpad2, 32, dtype=torch.bfloat16, device=device),
+                        A2l=torch.zeros(g["nk2"], Mpad2, 32, dtype=torch.bfloat16, device=device),
+                        b2=torch.zeros(Mpad2, dtype=torch.float32, device=device), Mpad2=Mpad2))
+                flows.append(dict(layers=layers, n_half=n_half,
+                                  w_start=torch.empty(C, n_half, dtype=torch.float32, device=device),
+                                  w_inv=None))
+            self.packed = dict(flows=flows, device=device)
+        keep = []   # keep f32 staging copies alive until the kernels have been enqueued
+        for k in range(m.n_flows):
+            wn = m.WN[k]
+            fl = self.packed["flows"][k]
+            v, gg = _vg(wn.start)
+            v, gg = _f32c(v), (None if gg is None else _f32c(gg))
+            keep += [v, gg]
+            _lib.call("t2s_weightnorm_small", _lib.ptr(v), _lib.ptr(gg), C, fl["n_half"], _lib.ptr(fl["w_start"]), st)
+            for i in range(nl):
+                ly = fl["layers"][i]
+                v, gg = _vg(wn.in_layers[i])
+                v, gg, bb = _f32c(v), (None if gg is None else _f32c(gg)), _f32c(wn.in_layers[i].bias)
+                keep += [v, gg, bb]
+                _lib.call("t2s_pack_conv_weight", _lib.ptr(v), _lib.ptr(gg), _lib.ptr(bb), 2 * C, C, ks,
+                          1, C, 0, g["Mpad1"], 0, g["Cpad"], _lib.ptr(ly["A1h"]), _lib.ptr(ly["A1l"]),
+                          _lib.ptr(ly["b1"]), 0, st)
+                v, gg = _vg(wn.cond_layers[i])
+                v, gg, bb = _f32c(v), (None if gg is None else _f32c(gg)), _f32c(wn.cond_layers[i].bias)
+                keep += [v, gg, bb]
+                _lib.call("t2s_pack_conv_weight", _lib.ptr(v), _lib.ptr(gg), _lib.ptr(bb), 2 * C, g["n_cond"], 1,
+                          1, C, 0, g["Mpad1"], ks * g["Cpad"], g["Spad"], _lib.ptr(ly["A1h"]), _lib.ptr(ly["A1l"]),
+                          _lib.ptr(ly["b1"]), 1, st)
+                v, gg = _vg(wn.res_skip_layers[i])
+                v, gg, bb = _f32c(v), (None if gg is None else _f32c(gg)), _f32c(wn.res_skip_layers[i].bias)
+                keep += [v, gg, bb]
+                rows2 = v.size(0)
+                _lib.call("t2s_pack_conv_weight", _lib.ptr(v), _lib.ptr(gg), _lib.ptr(bb), rows2, C, 1,
+                          0, 0, 0, ly["Mpad2"], 0, g["Cpad"], _lib.ptr(ly["A2h"]), _lib.ptr(ly["A2l"]),
+                          _lib.ptr(ly["b2"]), 0, st)
+            fl["w_inv"] = None
+        self.packed_key = key
+        self._keep = keep
+        return self.packed
+
+    # ------------------------------------------------------------------ workspaces
+    def workspace(self, B, L, device):
+        key = (B, L, str(device))
+        w = self.ws.get(key)
+        if w is None:
+            g = self.geom()
+            Lp = _lib.plane_rows(L, g["halo"])
+            bf = dict(dtype=torch.bfloat16, device=device)
+            xc, sc = g["Cpad"] // 32, g["Spad"] // 32
+            w = dict(Lp=Lp,
+                     Xh=torch.zeros(B, xc, Lp, 32, **bf), Xl=torch.zeros(B, xc, Lp, 32, **bf),
+                     Ah=torch.zeros(B, xc, Lp, 32, **bf), Al=torch.zeros(B, xc, Lp, 32, **bf),
+                     Sh=torch.zeros(B, sc, Lp, 32, **bf), Sl=torch.zeros(B, sc, Lp, 32, **bf),
+                     skip=torch.zeros(B, xc, Lp, 32, dtype=torch.float32, device=device))
+            self.ws = {key: w}      # keep one shape resident
+        return w
+
+    # ------------------------------------------------------------------ stages
+    def _check_inputs(self, *tensors):
+        for t in tensors:
+            if not t.is_cuda:
+                raise _lib.T2SError("WaveGlow (MI355X build) needs CUDA/HIP tensors; got a %s tensor - there is no "
+                                    "CPU fallback" % t.device)
+
+    def _upsample(self, mel, B, L, w):
+        m, g = self.m, self.geom()
+        up = m.upsample
+        mel32 = _f32c(mel)
+        W, bias = _f32c(up.weight), _f32c(up.bias)
+        _lib.call("t2s_wg_upsample_squeeze", _lib.ptr(mel32), _lib.ptr(W), _lib.ptr(bias), B, up.in_channels,
+                  mel32.size(2), up.kernel_size[0], up.stride[0], m.n_group, L, w["Lp"], g["halo"],
+                  _lib.ptr(w["Sh"]), _lib.ptr(w["Sl"]), _lib.current_stream())
+        self._keep_up = (mel32, W, bias)
+
+    def _wn(self, k, z, B, L, w, c_off, n_half):
+        """start -> n_layers x (in+cond+gate, res/skip); leaves the skip sum in w['skip']."""
+        m, g = self.m, self.geom()
+        C, nl, ks = g["C"], g["nl"], g["ks"]
+        fl = self.packed["flows"][k]
+        st = _lib.current_stream()
+        wn = m.WN[k]
+        b_start = _f32c(wn.start.bias)
+        self._keep_wn = [b_start]
+        _lib.call("t2s_wg_start", _lib.ptr(z), _lib.ptr(fl["w_start"]), _lib.ptr(b_start), B, m.n_group, c_off, n_half,
+                  C, L, w["Lp"], g["halo"], _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), st)
+        for i in range(nl):
+            ly = fl["layers"][i]
+            if self.gemm_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            _lib.call("t2s_wg_in_cond_gate", _lib.ptr(ly["A1h"]), _lib.ptr(ly["A1l"]), _lib.ptr(ly["b1"]),
+                      _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), _lib.ptr(w["Sh"]), _lib.ptr(w["Sl"]),
+                      _lib.ptr(w["Ah"]), _lib.ptr(w["Al"]), B, C, g["n_cond"], ks, 2 ** i, L, w["Lp"], g["halo"],
+                      g["Mpad1"], st)
+            if self.gemm_events is not None:
+                e1.record()
+                self.gemm_events.append((e0, e1))
+            n_res = C if i < nl - 1 else 0
+            _lib.call("t2s_wg_res_skip", _lib.ptr(ly["A2h"]), _lib.ptr(ly["A2l"]), _lib.ptr(ly["b2"]),
+                      _lib.ptr(w["Ah"]), _lib.ptr(w["Al"]), _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), _lib.ptr(w["skip"]),
+                      B, C, n_res, 1 if i == 0 else 0, L, w["Lp"], g["halo"], ly["Mpad2"], st)
+
+    def _end(self, k, z, log_s, B, L, w, c_off, n_half, reverse):
+        m, g = self.m, self.geom()
+        wn = m.WN[k]
+        w_end, b_end = _f32c(wn.end.weight), _f32c(wn.end.bias)
+        self._keep_end = (w_end, b_end)
+        _lib.call("t2s_wg_end_affine", _lib.ptr(w["skip"]), _lib.ptr(w_end), _lib.ptr(b_end), _lib.ptr(z),
+                  _lib.ptr(log_s), B, m.n_group, c_off, n_half, g["C"], L, w["Lp"], g["halo"], 1 if reverse else 0,
+                  _lib.current_stream())
+
+    def _flow_geom(self, k):
+        m = self.m
+        c_off = m.n_early_size * (k // m.n_early_every)
+        n_rem = m.n_group - c_off
+        return c_off, n_rem, n_rem // 2
+
+    # ------------------------------------------------------------------ forward / infer
+    def forward(self, mel, audio):
+        m = self.m
+        self._check_inputs(mel, audio)
+        dev = audio.device
+        B, T = audio.shape
+        G = m.n_group
+        L = T // G
+        up = m.upsample
+        if (mel.size(2) - 1) * up.stride[0] + up.kernel_size[0] < T:
+            raise AssertionError("upsampled spectrogram shorter than audio (reference glow.py:216)")
+        self.pack_weights(dev, force=True)
+        w = self.workspace(B, L, dev)
+        st = _lib.current_stream()
+        self._upsample(mel, B, L, w)
+        audio32 = _f32c(audio)
+        z = torch.empty(B, G, L, dtype=torch.float32, device=dev)
+        _lib.call("t2s_wg_audio_squeeze", _lib.ptr(audio32), _lib.ptr(z), B, T, G, L, 0, st)
+        log_s_list, log_det_list = [], []
+        log_det = torch.empty(m.n_flows, dtype=torch.float32, device=dev)
+        keep = []
+        for k in range(m.n_flows):
+            c_off, n_rem, n_half = self._flow_geom(k)
+            Wk = _f32c(m.convinv[k].conv.weight)
+            keep.append(Wk)
+            _lib.call("t2s_small_logdet_inv", _lib.ptr(Wk), n_rem, float(B * L), _lib.c_vp(log_det.data_ptr() + 4 * k),
+                      None, st)
+            _lib.call("t2s_wg_convinv", _lib.ptr(z), _lib.ptr(Wk), B, G, c_off, n_rem, L, st)
+            self._wn(k, z, B, L, w, c_off, n_half)
+            log_s = torch.empty(B, n_half, L, dtype=torch.float32, device=dev)
+            self._end(k, z, log_s, B, L, w, c_off, n_half, reverse=False)
+            log_s_list.append(log_s)
+            log_det_list.append(log_det[k])
+        self._keep_fwd = (audio32, keep)
+        return z, log_s_list, log_det_list
+
+    def infer(self, mel, sigma, noise):
+        m = self.m
+        self._check_inputs(mel)
+        dev = mel.device
+        B, _, frames = mel.shape
+        G = m.n_group
+        up = m.upsample
+        # reference glow.py:254-255: drop the last (kernel - stride) upsampled samples
+        T = (frames - 1) * up.stride[0] + up.kernel_size[0] - (up.kernel_size[0] - up.stride[0])
+        L = T // G
+        self.pack_weights(dev, force=False)
+        w = self.workspace(B, L, dev)
+        st = _lib.current_stream()
+        self._upsample(mel, B, L, w)
+        # All Gaussian draws of glow.py:260-267,284-289 live in one [B, G, L] buffer: the final
+        # n_remaining channels, and in front of them the n_early_size channels re-attached at each early flow.
+        z = torch.empty(B, G, L, dtype=torch.float32, device=dev)
+        n_rem_final = m.n_remaining_channels
+        early_ks = [k for k in reversed(range(m.n_flows)) if k % m.n_early_every == 0 and k > 0]
+        if noise is None:
+            noise_final = torch.randn(B, n_rem_final, L, dtype=torch.float32, device=dev)
+            noise_early = [torch.randn(B, m.n_early_size, L, dtype=torch.float32, device=dev) for _ in early_ks]
+        else:
+            noise_final, noise_early = noise
+        z[:, G - n_rem_final:] = sigma * noise_final.to(dev, torch.float32)
+        for k, ne in zip(early_ks, noise_early):
+            c_off = m.n_early_size * (k // m.n_early_every)
+            z[:, c_off - m.n_early_size:c_off] = sigma * ne.to(dev, torch.float32)
+        for k in reversed(range(m.n_flows)):
+            c_off, n_rem, n_half = self._flow_geom(k)
+            fl = self.packed["flows"][k]
+            if fl["w_inv"] is None:
+                Wk = _f32c(m.convinv[k].conv.weight)
+                fl["w_inv"] = torch.empty(n_rem, n_rem, dtype=torch.float32, device=dev)
+                _lib.call("t2s_small_logdet_inv", _lib.ptr(Wk), n_rem, 1.0, None, _lib.ptr(fl["w_inv"]), st)
+                fl["_Wk"] = Wk
+            self._wn(k, z, B, L, w, c_off, n_half)
+            self._end(k, z, None, B, L, w, c_off, n_half, reverse=True)
+            _lib.call("t2s_wg_convinv", _lib.ptr(z), _lib.ptr(fl["w_inv"]), B, G, c_off, n_rem, L, st)
+        audio = torch.empty(B, L * G, dtype=torch.float32, device=dev)
+        _lib.call("t2s_wg_audio_squeeze", _lib.ptr(audio), _lib.ptr(z), B, L * G, G, L, 1, st)
+        return audio
+
+
+class WaveGlow(torch.nn.Module):
+    """Reference glow.py:178-310 API on the MI355X kernels."""
+
+    def __init__(self, n_mel_channels, n_flows, n_group, n_early_every, n_early_size, WN_config):
+        super().__init__()
+        self.upsample = torch.nn.ConvTranspose1d(n_mel_channels, n_mel_channels, 1024, stride=256)
+        assert n_group % 2 == 0
+        self.n_flows = n_flows
+        self.n_group = n_group
+        self.n_early_every = n_early_every
+        self.n_early_size = n_early_size
+        self.WN = torch.nn.ModuleList()
+        self.convinv = torch.nn.ModuleList()
+        n_half = n_group // 2
+        n_remaining_channels = n_group
+        for k in range(n_flows):
+            if k % self.n_early_every == 0 and k > 0:
+                n_half = n_half - self.n_early_size // 2
+                n_remaining_channels = n_remaining_channels - self.n_early_size
+            self.convinv.append(Invertible1x1Conv(n_remaining_channels))
+            self.WN.append(WN(n_half, n_mel_channels * n_group, **WN_config))
+        self.n_remaining_channels = n_remaining_channels
+        self.__dict__["_engine"] = None
+
+    def _eng(self):
+        if self.__dict__.get("_engine") is None:
+            self.__dict__["_engine"] = _Engine(self)
+        return self.__dict__["_engine"]
+
+    def __getstate__(self):            # checkpoints pickle the module object (reference waveglow/train.py:52-60)
+        d = self.__dict__.copy()
+        d["_engine"] = None
+        return d
+
+    def forward(self, forward_input):
+        """forward_input = (mel [B, n_mel, frames], audio [B, T]) -> (z, [log_s], [log_det_W])
+        (reference glow.py:207-249)."""
+        spect, audio = forward_input
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .glow_autograd import waveglow_forward_with_grad
+            return waveglow_forward_with_grad(self, spect, audio)
+        return self._eng().forward(spect, audio)
+
+    def infer(self, spect, sigma=1.0, noise=None):
+        """mel [B, n_mel, frames] -> audio [B, 256*frames] (reference glow.py:251-292).
+        ``noise`` = (final [B, n_remaining, L], [early draws in the reference's order]) makes the
+        Gaussian draws explicit for parity tests; by default they are drawn on the device."""
+        with torch.no_grad():
+            out = self._eng().infer(spect, float(sigma), noise)
+        return out.to(spect.dtype) if spect.dtype in (torch.float16, torch.bfloat16) else out
+
+    @staticmethod
+    def remove_weightnorm(model):
+        """Fold (g, v) into plain ``weight`` tensors (reference glow.py:294-310)."""
+        waveglow = model
+        for wn in waveglow.WN:
+            wn.start = torch.nn.utils.remove_weight_norm(wn.start)
+            wn.in_layers = remove(wn.in_layers)
+            wn.cond_layers = remove(wn.cond_layers)
+            wn.res_skip_layers = remove(wn.res_skip_layers)
+        if waveglow.__dict__.get("_engine") is not None:
+            waveglow.__dict__["_engine"].packed_key = None
+        return waveglow
+
+
+def remove(conv_list):
+    new_conv_list = torch.nn.ModuleList()
+    for old_conv in conv_list:
+        new_conv_list.append(torch.nn.utils.remove_weight_norm(old_conv))
+    return new_conv_list
