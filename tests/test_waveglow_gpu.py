@@ -101,7 +101,7 @@ def test_wn_layer(lib, B, C, n_cond, L, dil, last):
     Sh, Sl = planes.to_planes(d(s), halo, Lp)
     Ah, Al = torch.zeros_like(Xh), torch.zeros_like(Xl)
     skip = torch.zeros(B, Xh.size(1), Lp, 32, device=DEV)
-    skip[:, :, halo:halo + L] = d(skip0).view(B, -1, 32, L).permute(0, 1, 3, 2) if C % 32 == 0 else 0
+    skip[:, :, halo:halo + L] = d(skip0).view(B, -1, 32, L).permute(0, 1, 3, 2)
     st = _lib.current_stream()
     _lib.call("t2s_wg_in_cond_gate", _lib.ptr(l1[0]), _lib.ptr(l1[1]), _lib.ptr(l1[2]), _lib.ptr(Xh), _lib.ptr(Xl),
               _lib.ptr(Sh), _lib.ptr(Sl), _lib.ptr(Ah), _lib.ptr(Al), B, C, n_cond, ks, dil, L, Lp, halo, l1[3], st)
@@ -141,14 +141,16 @@ def test_small_stages(lib):
     Lp = _lib.plane_rows(L, halo)
     Sh = torch.zeros(B, M * G // 32, Lp, 32, dtype=torch.bfloat16, device=DEV)
     Sl = torch.zeros_like(Sh)
-    _lib.call("t2s_wg_upsample_squeeze", _lib.ptr(d(mel)), _lib.ptr(d(W)), _lib.ptr(d(bias)), B, M, Fr, 1024, 256, G,
+    mel_d, W_d, bias_d = d(mel), d(W), d(bias)       # hold references: a freed temporary's block is reused at once
+    _lib.call("t2s_wg_upsample_squeeze", _lib.ptr(mel_d), _lib.ptr(W_d), _lib.ptr(bias_d), B, M, Fr, 1024, 256, G,
               L, Lp, halo, _lib.ptr(Sh), _lib.ptr(Sl), st)
     torch.cuda.synchronize()
     assert _rel(planes.from_planes(Sh, Sl, M * G, L, halo), want) < 2e-5
     # audio squeeze + convinv + logdet + inverse
     audio = torch.rand(B, T, generator=gen) - 0.5
     z = torch.empty(B, G, L, device=DEV)
-    _lib.call("t2s_wg_audio_squeeze", _lib.ptr(d(audio)), _lib.ptr(z), B, T, G, L, 0, st)
+    audio_d = d(audio)
+    _lib.call("t2s_wg_audio_squeeze", _lib.ptr(audio_d), _lib.ptr(z), B, T, G, L, 0, st)
     zr = audio.reshape(B, L, G).permute(0, 2, 1)
     assert torch.equal(z.cpu(), zr)
     Wc = torch.linalg.qr(torch.randn(6, 6, generator=gen))[0] @ torch.diag(torch.rand(6, generator=gen) + 0.5)
@@ -156,8 +158,9 @@ def test_small_stages(lib):
         Wc[:, 0] = -Wc[:, 0]
     out = torch.empty(1, device=DEV)
     inv = torch.empty(6, 6, device=DEV)
-    _lib.call("t2s_small_logdet_inv", _lib.ptr(d(Wc)), 6, 100.0, _lib.ptr(out), _lib.ptr(inv), st)
-    _lib.call("t2s_wg_convinv", _lib.ptr(z), _lib.ptr(d(Wc)), B, G, 2, 6, L, st)
+    Wc_d = d(Wc)
+    _lib.call("t2s_small_logdet_inv", _lib.ptr(Wc_d), 6, 100.0, _lib.ptr(out), _lib.ptr(inv), st)
+    _lib.call("t2s_wg_convinv", _lib.ptr(z), _lib.ptr(Wc_d), B, G, 2, 6, L, st)
     torch.cuda.synchronize()
     assert abs(float(out) - 100.0 * float(torch.logdet(Wc.double()))) < 1e-3
     assert _rel(inv, torch.linalg.inv(Wc.double())) < 1e-5
@@ -170,7 +173,8 @@ def test_small_stages(lib):
     bs = torch.randn(C, generator=gen)
     Xh = torch.zeros(B, C // 32, Lp, 32, dtype=torch.bfloat16, device=DEV)
     Xl = torch.zeros_like(Xh)
-    _lib.call("t2s_wg_start", _lib.ptr(z), _lib.ptr(d(ws)), _lib.ptr(d(bs)), B, G, 2, nh, C, L, Lp, halo, _lib.ptr(Xh),
+    ws_d, bs_d = d(ws), d(bs)
+    _lib.call("t2s_wg_start", _lib.ptr(z), _lib.ptr(ws_d), _lib.ptr(bs_d), B, G, 2, nh, C, L, Lp, halo, _lib.ptr(Xh),
               _lib.ptr(Xl), st)
     torch.cuda.synchronize()
     want_x = torch.einsum("cj,bjt->bct", ws.double(), zr2[:, 2:5]) + bs.double().view(1, -1, 1)
@@ -184,14 +188,15 @@ def test_small_stages(lib):
     o = F.conv1d(skipv.double(), we.double(), be.double())
     z_before = z.clone()
     log_s = torch.empty(B, nh, L, device=DEV)
-    _lib.call("t2s_wg_end_affine", _lib.ptr(skip), _lib.ptr(d(we)), _lib.ptr(d(be)), _lib.ptr(z), _lib.ptr(log_s), B, G,
+    we_d, be_d = d(we), d(be)
+    _lib.call("t2s_wg_end_affine", _lib.ptr(skip), _lib.ptr(we_d), _lib.ptr(be_d), _lib.ptr(z), _lib.ptr(log_s), B, G,
               2, nh, C, L, Lp, halo, 0, st)
     torch.cuda.synchronize()
     want_a1 = torch.exp(o[:, nh:]) * z_before[:, 5:8].double().cpu() + o[:, :nh]
     assert _rel(log_s, o[:, nh:]) < 1e-5
     assert _rel(z[:, 5:8], want_a1) < 1e-5
     assert torch.equal(z[:, :5], z_before[:, :5])
-    _lib.call("t2s_wg_end_affine", _lib.ptr(skip), _lib.ptr(d(we)), _lib.ptr(d(be)), _lib.ptr(z), None, B, G, 2, nh, C,
+    _lib.call("t2s_wg_end_affine", _lib.ptr(skip), _lib.ptr(we_d), _lib.ptr(be_d), _lib.ptr(z), None, B, G, 2, nh, C,
               L, Lp, halo, 1, st)
     torch.cuda.synchronize()
     assert _rel(z, z_before) < 1e-5
