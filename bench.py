@@ -31,11 +31,39 @@ from text2speech_amd.glow import WaveGlow  # noqa: E402
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 
 
+def usable_cores():
+    """CPU cores this process may really use: min(affinity, cgroup quota), not the host's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return min(n, 16) if os.environ.get("T2S_BENCH_ALL_CORES") is None else n
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
 def cpu_baseline(cfg, sd, sample_batch=2, n_samples=16000, reps=3):
     """The oracle (oracle/waveglow_oracle.py, kind "port") on the host cores, bounded sample."""
     from oracle import waveglow_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    log("cpu baseline on %d threads" % cores)
     mel, audio = synth.waveglow_inputs(sample_batch, n_samples, seed=31)
     times = []
     with torch.no_grad():
@@ -44,6 +72,7 @@ def cpu_baseline(cfg, sd, sample_batch=2, n_samples=16000, reps=3):
             t0 = time.perf_counter()
             O.waveglow_forward(sd, cfg, mel, audio)
             times.append(time.perf_counter() - t0)
+            log("cpu baseline rep %.2f s" % times[-1])
     t = sorted(times)[len(times) // 2]
     return {"value": sample_batch * n_samples / t, "unit": "audio samples/s", "cores": cores, "kind": "port",
             "sample": "oracle forward on batch %d x %d (1/%d of the GPU batch), median of %d, fp32 torch CPU ops"
@@ -82,6 +111,7 @@ def main():
     mel, audio = mel.to(dev), audio.to(dev)
 
     eng = model._eng()
+    log("rank %d: model built, starting warm-up" % rank)
     with torch.no_grad():
         for _ in range(args.warmup):
             model((mel, audio))
@@ -98,6 +128,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+    log("rank %d: %d steps in %.3f s" % (rank, args.steps, dt))
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
