@@ -49,10 +49,11 @@ int t2s_padded_rows(int rows);
 
 /* weight_norm + pack one conv weight v[O][Cin][Kt] (gain g[O] or NULL) into the GEMM A planes
  * A_hi/A_lo [nk][Mpad][32] bf16 at packed-K offset `koff` (tap-major, tap stride Cin_pad), and its
- * bias into bias_out[Mpad].  Replaces torch.nn.utils.weight_norm's per-forward recompute
+ * bias into bias_out[Mpad].  g_is_scale=1: g is a plain per-row scale (eval BatchNorm fold) instead of
+ * a weight-norm gain.  Replaces torch.nn.utils.weight_norm's per-forward recompute
  * (reference glow.py:123,138,142,151). */
-int t2s_pack_conv_weight(const float* v, const float* g, const float* bias_in, int O, int Cin, int Kt, int perm,
-                         int C_gate, int row_off, int Mpad, int koff, int Cin_pad, void* A_hi, void* A_lo,
+int t2s_pack_conv_weight(const float* v, const float* g, int g_is_scale, const float* bias_in, int O, int Cin, int Kt,
+                         int perm, int C_gate, int row_off, int Mpad, int koff, int Cin_pad, void* A_hi, void* A_lo,
                          float* bias_out, int bias_accumulate, void* stream);
 
 /* w[O][K] = v * g / ||v||  for a small weight-normed 1x1 conv (WN.start; reference glow.py:122-124) */
@@ -98,12 +99,79 @@ int t2s_wg_end_affine(const float* skip, const float* w_end, const float* b_end,
 
 /* Generic split-bf16 conv1d-as-GEMM with bias + activation epilogue:
  *   out[b][o][t] = act(bias[o] + sum_{tap,c} W[o][c][tap] * x[b][c][t + (tap - taps/2)*dil])
- * A planes packed with T2S_PERM_NONE.  Writes planes O_hi/O_lo (may be NULL) and/or out_f32 [B][C][L]
- * (may be NULL).  Used for the Tacotron-2 encoder / postnet convolutions and LSTM input projections
+ * A planes packed with T2S_PERM_NONE.  Writes planes O_hi/O_lo (may be NULL) and/or out_f32 (may be NULL),
+ * laid out [B][C][L], or [B][L][C] when f32_channel_last=1.  Used for the Tacotron-2 encoder / postnet convolutions and LSTM input projections
  * (reference tacotron.py:177-194, modules.py:94-137). */
 int t2s_conv_bias_act(const void* A_hi, const void* A_lo, const float* bias, const void* X_hi, const void* X_lo,
-                      void* O_hi, void* O_lo, float* out_f32, int B, int Cin, int Cout, int taps, int dilation,
-                      int act, int L, int Lp, int halo, int Mpad, void* stream);
+                      void* O_hi, void* O_lo, float* out_f32, int f32_channel_last, int B, int Cin, int Cout, int taps,
+                      int dilation, int act, int L, int Lp, int halo, int Mpad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tacotron-2 (reference tacotron/tacotron.py, tacotron/modules.py).  All f32, exact.
+ */
+
+/* y[item][row] = act(bias1[row] + bias2[row] + [W1[row] | W2[row]] . [x1 | x2 | x3](item)) * mask * mask_scale
+ * One wave per output row (weights in registers), loop over items.  Replaces the small Linear layers:
+ * query_layer (tacotron.py:137), linear_projection / gate_layer (:387-392), Prenet (modules.py:19-22),
+ * memory_layer (tacotron.py:306).  K = n1+n2+n3 = k1+k2 <= 2560, every n a multiple of 4. */
+int t2s_gemv(const float* W1, int ld1, int k1, const float* W2, int ld2, int k2, const float* x1, int n1, long sx1,
+             const float* x2, int n2, long sx2, const float* x3, int n3, long sx3, const float* bias1,
+             const float* bias2, float* y, long sy_item, long sy_row, int rows, int items, int act,
+             const unsigned char* mask, long smask_item, float mask_scale, void* stream);
+
+/* out[c][r] = in[r][c] */
+int t2s_transpose(const float* in, float* out, int R, int C, void* stream);
+
+/* embedding lookup -> planes: x[b][:, t] = emb[ids[b][t]]  (tacotron.py:40) */
+int t2s_embed_planes(const long* ids, const float* emb, int B, int T, int E, int V, int Lp, int halo, void* X_hi,
+                     void* X_lo, void* stream);
+/* [B][C][L] f32 -> planes */
+int t2s_f32_to_planes(const float* x, int B, int C, int L, int Lp, int halo, void* X_hi, void* X_lo, void* stream);
+/* eval BatchNorm folded into the preceding conv: scale = gamma/sqrt(var+eps), bias' = (bias-mean)*scale+beta */
+int t2s_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, const float* conv_bias,
+                float eps, int C, float* scale, float* bias_out, void* stream);
+
+/* Encoder BiLSTM recurrence with packed-sequence semantics (tacotron.py:199-207).  gx[B][T][8H] = W_ih x + b_ih + b_hh
+ * for both directions (fwd gates then reverse gates), whhT_* = W_hh^T [H][4H]; out[B][T_out][2H]; 4H must be 1024. */
+int t2s_taco_encoder_lstm(const float* gx, const float* whhT_fwd, const float* whhT_rev, const int* lengths, float* out,
+                          int B, int T, int H, int T_out, void* stream);
+
+/* Bernoulli(0.5) bytes (0/1) from a counter hash: the always-on prenet dropout (modules.py:21) when the caller
+ * does not inject masks */
+int t2s_bernoulli_mask(unsigned char* mask, size_t n, unsigned long long seed, unsigned long long offset, void* stream);
+
+/* Decoder state + weights for t2s_taco_decode_steps.  Pointers are device pointers; f32 unless noted. */
+typedef struct t2s_taco_decoder {
+    int B, T_in, n_mel, prenet_dim, enc_dim, att_rnn_dim, dec_rnn_dim, att_dim, loc_filters, loc_kernel;
+    int T_cap;           /* time capacity of mel_gate_out / align_out */
+    int teacher_forced;  /* 1: step input = pre_all[step]; projection hoisted (hc_all); 0: autoregressive */
+    int mask_steps;      /* autoregressive: number of [B][2][prenet] mask slices in prenet_masks */
+    const float *att_w_ih, *att_w_hh, *att_b_ih, *att_b_hh;   /* attention_rnn (tacotron.py:366) */
+    const float *dec_w_ih, *dec_w_hh, *dec_b_ih, *dec_b_hh;   /* decoder_rnn   (tacotron.py:380) */
+    const float *w_query, *w_loc_conv, *w_loc_dense, *w_v;    /* attention_layer (tacotron.py:96-143) */
+    const float *w_proj, *b_proj;        /* [n_mel+1][dec+enc]: linear_projection rows, then the gate_layer row */
+    const float *w_projpre, *b_projpre;  /* [prenet][dec+enc] = W_prenet0 . W_proj[:n_mel], W_prenet0 . b_proj[:n_mel] */
+    const float *w_pre2;                 /* [prenet][prenet] = prenet.layers.1 */
+    const float *memory, *pmem;          /* [B][T_in][enc], [B][T_in][att_dim] */
+    const int *mem_lengths;              /* [B] or NULL */
+    const float *pre_all;                /* teacher forced: [T+1][B][prenet] */
+    const unsigned char *prenet_masks;   /* autoregressive: [mask_steps][B][2][prenet] 0/1, slice s feeds step s */
+    const unsigned char *att_drop, *dec_drop; /* training dropout on the LSTM outputs: [T][B][H] 0/1, or NULL */
+    float att_drop_scale, dec_drop_scale;
+    float *att_h0, *att_h1, *att_c, *dec_h0, *dec_h1, *dec_c;   /* ping-pong h (step parity), c in place */
+    float *att_w, *att_wcum, *ctx, *q, *energies, *pre1, *pre2; /* [B][T_in] x3, [B][enc], [B][att_dim], ... */
+    float *mel_gate_out;                 /* [B][n_mel+1][T_cap] (autoregressive), row n_mel = gate logit */
+    float *align_out;                    /* [B][T_cap][T_in] */
+    float *hc_all;                       /* teacher forced: [T][B][dec+enc] */
+} t2s_taco_decoder;
+
+/* Enqueue decoder steps [step0, step0+n_steps) (Decoder.decode, tacotron.py:355-393, plus in autoregressive mode
+ * the projection and the prenet of the next step, tacotron.py:447-461) on `stream` without host synchronisation. */
+int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, void* stream);
+
+/* stop_step[b] = first step in [step0, step0+n) with sigmoid(gate) > threshold, if still -1 (tacotron.py:455) */
+int t2s_taco_stop_check(const float* mel_gate_out, int B, int n_mel, int T_cap, int step0, int n, float threshold,
+                        int* stop_step, void* stream);
 
 #ifdef __cplusplus
 }

@@ -46,4 +46,4 @@ def test_argument_validation_without_gpu(lib):
     # null pointers / bad geometry are rejected before anything touches the device
     assert lib.t2s_wg_convinv(None, None, 1, 8, 0, 8, 10, None) == -1
     assert lib.t2s_small_logdet_inv(None, 4, 1.0, None, None, None) == -1
-    assert lib.t2s_pack_conv_weight(None, None, None, 4, 4, 1, 0, 0, 0, 256, 0, 32, None, None, None, 0, None) == -1
+    assert lib.t2s_pack_conv_weight(None, None, 0, None, 4, 4, 1, 0, 0, 0, 256, 0, 32, None, None, None, 0, None) == -1

@@ -1,0 +1,165 @@
+"""GPU parity tests for the Tacotron-2 path (run with -m gpu): HIP kernels through the C ABI vs the
+CPU oracle (oracle/tacotron_oracle.py) and the reference-generated golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from text2speech_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HP = synth.TACOTRON_HPARAMS
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _maxrel(a, b):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def unpack(g, key, shape):
+    n = int(np.prod(shape))
+    return torch.from_numpy(np.unpackbits(g[key])[:n].reshape(shape).astype(np.uint8))
+
+
+def ragged_batch(seed=21, B=4, T_in=40, T_out=50):
+    gen = torch.Generator().manual_seed(seed)
+    in_len = torch.tensor([T_in, T_in - 4, T_in - 9, T_in - 20])[:B]
+    out_len = torch.tensor([T_out, T_out - 6, T_out - 13, T_out - 25])[:B]
+    text = torch.randint(2, 80, (B, T_in), generator=gen)
+    mel = torch.randn(B, 80, T_out, generator=gen)
+    for b in range(B):
+        text[b, in_len[b]:] = 0
+        mel[b, :, out_len[b]:] = 0
+    return text, in_len, mel, out_len
+
+
+@pytest.fixture(scope="module")
+def model():
+    assert torch.cuda.is_available()
+    _lib.load()
+    from text2speech_amd.tacotron import Tacotron
+    m = Tacotron(HP, 80, num_speakers=2)
+    m.load_state_dict(synth.tacotron_state(), strict=True)
+    return m.to(DEV).eval()
+
+
+def test_gemv_and_lstm_cell_primitives():
+    """The wave-per-row GEMV and the fused LSTMCell against torch CPU (f64)."""
+    import ctypes
+    from oracle import tacotron_oracle as O
+    _lib.load()
+    gen = torch.Generator().manual_seed(1)
+    st = _lib.current_stream()
+    for (rows, K, items) in [(128, 1024, 3), (81, 1536, 70), (256, 80, 5)]:
+        W = torch.randn(rows, K, generator=gen)
+        x = torch.randn(items, K, generator=gen)
+        b = torch.randn(rows, generator=gen)
+        Wd, xd, bd = W.to(DEV), x.to(DEV), b.to(DEV)
+        y = torch.empty(items, rows, device=DEV)
+        _lib.call("t2s_gemv", _lib.ptr(Wd), K, K, None, 0, 0, _lib.ptr(xd), K, K, None, 0, 0, None, 0, 0, _lib.ptr(bd), None,
+                  _lib.ptr(y), rows, 1, rows, items, 1, None, 0, 1.0, st)
+        want = torch.relu(x.double() @ W.double().t() + b.double())
+        assert _rel(y, want) < 1e-6
+    # LSTM cell through the decoder-step driver is covered below; here a direct 3-segment GEMV
+    n1, n2, n3, rows, items = 256, 512, 1024, 64, 4
+    W1 = torch.randn(rows, n1 + n2, generator=gen)
+    W2 = torch.randn(rows, n3, generator=gen)
+    xs = [torch.randn(items, n, generator=gen) for n in (n1, n2, n3)]
+    d = [t.to(DEV) for t in [W1, W2] + xs]
+    y = torch.empty(items, rows, device=DEV)
+    _lib.call("t2s_gemv", _lib.ptr(d[0]), n1 + n2, n1 + n2, _lib.ptr(d[1]), n3, n3, _lib.ptr(d[2]), n1, n1, _lib.ptr(d[3]), n2,
+              n2, _lib.ptr(d[4]), n3, n3, None, None, _lib.ptr(y), rows, 1, rows, items, 0, None, 0, 1.0, st)
+    want = torch.cat(xs[:2], 1).double() @ W1.double().t() + xs[2].double() @ W2.double().t()
+    assert _rel(y, want) < 1e-6
+
+
+def test_encoder_vs_golden(model, golden_dir):
+    g = np.load(os.path.join(golden_dir, "tacotron_fwd_eval.npz"))
+    text, in_len, _, _ = ragged_batch()
+    eng = model._eng()
+    eng.prepare(torch.device(DEV))
+    memory, _ = eng.encode(text.to(DEV), in_len)
+    assert tuple(memory.shape) == g["enc"].shape
+    assert _rel(memory, g["enc"]) < 1e-3 and _maxrel(memory, g["enc"]) < 1e-3
+    g2 = np.load(os.path.join(golden_dir, "tacotron_infer.npz"))
+    ids = (torch.arange(64) % 78 + 2)[None]
+    memory, _ = eng.encode(ids.to(DEV), None)
+    assert _rel(memory, g2["enc"]) < 1e-3 and _maxrel(memory, g2["enc"]) < 1e-3
+
+
+def test_inference_vs_golden(model, golden_dir):
+    """BASELINE configs[0]: 64 symbols -> 200 forced frames, B=1, the reference's own dropout draws."""
+    g = np.load(os.path.join(golden_dir, "tacotron_infer.npz"))
+    ids = (torch.arange(64) % 78 + 2)[None]
+    masks = unpack(g, "prenet_masks", tuple(g["prenet_masks_shape"]))
+    model.decoder.gate_threshold = 2.0
+    model.decoder.max_decoder_steps = 200
+    try:
+        mel, mel_post, gate, align = model.inference(ids.to(DEV), None, prenet_masks=masks)
+    finally:
+        model.decoder.gate_threshold = HP["gate_threshold"]
+        model.decoder.max_decoder_steps = HP["max_decoder_steps"]
+    assert tuple(mel.shape) == g["mel"].shape and tuple(gate.shape) == g["gate"].shape
+    assert tuple(align.shape) == g["align"].shape
+    for name, got in (("mel", mel), ("mel_post", mel_post), ("gate", gate), ("align", align)):
+        assert _rel(got, g[name]) < 1e-3, name
+        assert _maxrel(got, g[name]) < 1e-3, name
+
+
+def test_forward_ragged_vs_golden(model, golden_dir):
+    g = np.load(os.path.join(golden_dir, "tacotron_fwd_eval.npz"))
+    text, in_len, mel_t, out_len = ragged_batch()
+    masks = unpack(g, "prenet_masks", tuple(g["prenet_masks_shape"]))
+    B = text.size(0)
+    out = model((text.to(DEV), in_len.to(DEV), mel_t.to(DEV), int(in_len.max()), torch.zeros(B, device=DEV),
+                 out_len.to(DEV)), prenet_masks=masks)
+    for name, got in zip(("mel", "mel_post", "gate", "align"), out):
+        assert tuple(got.shape) == g[name].shape, name
+        assert _rel(got, g[name]) < 1e-3, name
+        assert _maxrel(got, g[name]) < 1e-3, name
+    # parse_output semantics (reference tacotron.py:67-76)
+    assert float(out[0][3, :, 25:].abs().max()) == 0.0 and float(out[2][3, 25:].min()) == 1e3
+
+
+def test_stop_condition_and_device_masks(model):
+    """gate threshold stop (tacotron.py:455): with random weights sigmoid(gate) crosses 0.5 early; the
+    result must be a prefix of the forced-length run with the same masks."""
+    ids = (torch.arange(32) % 78 + 2)[None].to(DEV)
+    gen = torch.Generator().manual_seed(3)
+    masks = (torch.rand(60, 1, 2, 256, generator=gen) < 0.5).to(torch.uint8)
+    model.decoder.max_decoder_steps = 60
+    try:
+        model.decoder.gate_threshold = 2.0
+        full = model.inference(ids, None, prenet_masks=masks)
+        probs = torch.sigmoid(full[2][0, :, 0])
+        thr = float(probs[5:].max()) - 1e-4 if probs.numel() > 6 else 0.5
+        first = int((probs > thr).nonzero()[0])
+        model.decoder.gate_threshold = thr
+        part = model.inference(ids, None, prenet_masks=masks)
+        assert part[0].size(2) == first + 1
+        assert _rel(part[0], full[0][:, :, :first + 1]) < 1e-6
+        # device-drawn masks: runs, finite, right shapes
+        model.decoder.gate_threshold = 2.0
+        rnd = model.inference(ids, None)
+        assert rnd[0].shape == full[0].shape and bool(torch.isfinite(rnd[1]).all())
+    finally:
+        model.decoder.gate_threshold = HP["gate_threshold"]
+        model.decoder.max_decoder_steps = HP["max_decoder_steps"]
+
+
+def test_training_mode_fails_loudly(model):
+    model.train()
+    try:
+        with pytest.raises(NotImplementedError):
+            model.inference((torch.arange(8) + 2)[None].to(DEV), None)
+    finally:
+        model.eval()

@@ -41,16 +41,16 @@ def _pack_layer(C, n_cond, ks, w_in, g_in, b_in, w_c, g_c, b_c, w_rs, g_rs, b_rs
     A1h = torch.zeros(nk1, Mpad1, 32, dtype=torch.bfloat16, device=DEV)
     A1l = torch.zeros_like(A1h)
     b1 = torch.zeros(Mpad1, device=DEV)
-    _lib.call("t2s_pack_conv_weight", _lib.ptr(w_in), _lib.ptr(g_in), _lib.ptr(b_in), 2 * C, C, ks, 1, C, 0, Mpad1, 0,
+    _lib.call("t2s_pack_conv_weight", _lib.ptr(w_in), _lib.ptr(g_in), 0, _lib.ptr(b_in), 2 * C, C, ks, 1, C, 0, Mpad1, 0,
               Cpad, _lib.ptr(A1h), _lib.ptr(A1l), _lib.ptr(b1), 0, st)
-    _lib.call("t2s_pack_conv_weight", _lib.ptr(w_c), _lib.ptr(g_c), _lib.ptr(b_c), 2 * C, n_cond, 1, 1, C, 0, Mpad1,
+    _lib.call("t2s_pack_conv_weight", _lib.ptr(w_c), _lib.ptr(g_c), 0, _lib.ptr(b_c), 2 * C, n_cond, 1, 1, C, 0, Mpad1,
               ks * Cpad, Spad, _lib.ptr(A1h), _lib.ptr(A1l), _lib.ptr(b1), 1, st)
     rows2 = w_rs.size(0)
     Mpad2 = _lib.padded_rows(rows2)
     A2h = torch.zeros(Cpad // 32, Mpad2, 32, dtype=torch.bfloat16, device=DEV)
     A2l = torch.zeros_like(A2h)
     b2 = torch.zeros(Mpad2, device=DEV)
-    _lib.call("t2s_pack_conv_weight", _lib.ptr(w_rs), _lib.ptr(g_rs), _lib.ptr(b_rs), rows2, C, 1, 0, 0, 0, Mpad2, 0,
+    _lib.call("t2s_pack_conv_weight", _lib.ptr(w_rs), _lib.ptr(g_rs), 0, _lib.ptr(b_rs), rows2, C, 1, 0, 0, 0, Mpad2, 0,
               Cpad, _lib.ptr(A2h), _lib.ptr(A2l), _lib.ptr(b2), 0, st)
     return (A1h, A1l, b1, Mpad1), (A2h, A2l, b2, Mpad2)
 

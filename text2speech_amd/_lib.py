@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libt2s_hip.so")
 
-c_int, c_float, c_vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+c_int, c_float, c_vp, c_long = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_long
 
 # name -> argtypes (every function returns int unless listed in _RESTYPE)
 SIGNATURES = {
@@ -19,7 +19,7 @@ SIGNATURES = {
     "t2s_last_hip_error": [],
     "t2s_plane_rows": [c_int, c_int],
     "t2s_padded_rows": [c_int],
-    "t2s_pack_conv_weight": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+    "t2s_pack_conv_weight": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                              c_vp, c_vp, c_vp, c_int, c_vp],
     "t2s_weightnorm_small": [c_vp, c_vp, c_int, c_int, c_vp, c_vp],
     "t2s_wg_upsample_squeeze": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -34,8 +34,18 @@ SIGNATURES = {
                         c_int, c_int, c_vp],
     "t2s_wg_end_affine": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                           c_int, c_vp],
-    "t2s_conv_bias_act": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int,
+    "t2s_conv_bias_act": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                           c_int, c_int, c_int, c_int, c_vp],
+    "t2s_gemv": [c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_int, c_long, c_vp, c_int, c_long, c_vp, c_int, c_long,
+                 c_vp, c_vp, c_vp, c_long, c_long, c_int, c_int, c_int, c_vp, c_long, c_float, c_vp],
+    "t2s_transpose": [c_vp, c_vp, c_int, c_int, c_vp],
+    "t2s_embed_planes": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
+    "t2s_f32_to_planes": [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
+    "t2s_bn_fold": [c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_int, c_vp, c_vp, c_vp],
+    "t2s_taco_encoder_lstm": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "t2s_bernoulli_mask": [c_vp, ctypes.c_size_t, ctypes.c_ulonglong, ctypes.c_ulonglong, c_vp],
+    "t2s_taco_decode_steps": [c_vp, c_int, c_int, c_vp],
+    "t2s_taco_stop_check": [c_vp, c_int, c_int, c_int, c_int, c_int, c_float, c_vp, c_vp],
 }
 _RESTYPE = {"t2s_error_string": ctypes.c_char_p, "t2s_last_hip_error": ctypes.c_char_p}
 

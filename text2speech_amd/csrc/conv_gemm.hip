@@ -234,7 +234,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
                     float v = acc[m][n][e] + bv[e];
                     if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
                     else if (a.act == ACT_TANH) v = fast_tanh(v);
-                    if (a.out_f32) a.out_f32[((size_t)b * a.C + ch + e) * a.L + t] = v;
+                    if (a.out_f32) {
+                        if (a.f32_cl) a.out_f32[((size_t)b * a.L + t) * a.C + ch + e] = v;
+                        else a.out_f32[((size_t)b * a.C + ch + e) * a.L + t] = v;
+                    }
                     u16 h, l;
                     split_bf16(v, h, l);
                     hi[e] = h;

@@ -6,7 +6,10 @@
 
 static thread_local char g_hip_err[256] = "";
 
-static int fail_hip(hipError_t e) {
+extern "C" int t2s_internal_fail_hip(int e);
+static int fail_hip(hipError_t e) { return t2s_internal_fail_hip((int)e); }
+extern "C" int t2s_internal_fail_hip(int ei) {
+    hipError_t e = (hipError_t)ei;
     strncpy(g_hip_err, hipGetErrorString(e), sizeof(g_hip_err) - 1);
     g_hip_err[sizeof(g_hip_err) - 1] = 0;
     return T2S_EHIP;
@@ -37,8 +40,8 @@ const char* t2s_last_hip_error(void) { return g_hip_err; }
 int t2s_plane_rows(int L, int halo) { return cdiv(L, 256) * 256 + 2 * halo; }
 int t2s_padded_rows(int rows) { return cdiv(rows, 256) * 256; }
 
-int t2s_pack_conv_weight(const float* v, const float* g, const float* bias_in, int O, int Cin, int Kt, int perm,
-                         int C_gate, int row_off, int Mpad, int koff, int Cin_pad, void* A_hi, void* A_lo,
+int t2s_pack_conv_weight(const float* v, const float* g, int g_is_scale, const float* bias_in, int O, int Cin, int Kt,
+                         int perm, int C_gate, int row_off, int Mpad, int koff, int Cin_pad, void* A_hi, void* A_lo,
                          float* bias_out, int bias_accumulate, void* stream) {
     if (!v || !A_hi || !A_lo || O <= 0 || Cin <= 0 || Kt <= 0) return T2S_EINVAL;
     if (Mpad % 256 || koff % 32 || Cin_pad % 32 || Cin_pad < Cin) return T2S_EINVAL;
@@ -53,7 +56,7 @@ int t2s_pack_conv_weight(const float* v, const float* g, const float* bias_in, i
     a.v = v; a.g = g; a.bias_in = bias_in;
     a.A_hi = (u16*)A_hi; a.A_lo = (u16*)A_lo; a.bias_out = bias_out;
     a.O = O; a.Cin = Cin; a.Kt = Kt; a.perm = perm; a.C_gate = C_gate; a.Mpad = Mpad; a.koff = koff;
-    a.Cin_pad = Cin_pad; a.bias_accumulate = bias_accumulate; a.row_off = row_off;
+    a.Cin_pad = Cin_pad; a.bias_accumulate = bias_accumulate; a.row_off = row_off; a.g_is_scale = g_is_scale;
     T2S_CHECK_HIP(t2s_launch_pack(a, (hipStream_t)stream));
     return T2S_OK;
 }
@@ -166,8 +169,8 @@ int t2s_wg_end_affine(const float* skip, const float* w_end, const float* b_end,
 }
 
 int t2s_conv_bias_act(const void* A_hi, const void* A_lo, const float* bias, const void* X_hi, const void* X_lo,
-                      void* O_hi, void* O_lo, float* out_f32, int B, int Cin, int Cout, int taps, int dilation,
-                      int act, int L, int Lp, int halo, int Mpad, void* stream) {
+                      void* O_hi, void* O_lo, float* out_f32, int f32_channel_last, int B, int Cin, int Cout, int taps,
+                      int dilation, int act, int L, int Lp, int halo, int Mpad, void* stream) {
     if (!check_planes(A_hi, A_lo) || !check_planes(X_hi, X_lo) || !bias || !aligned16(bias)) return T2S_EINVAL;
     if ((O_hi || O_lo) && !check_planes(O_hi, O_lo)) return T2S_EINVAL;
     if (!O_hi && !out_f32) return T2S_EINVAL;
@@ -184,7 +187,7 @@ int t2s_conv_bias_act(const void* A_hi, const void* A_lo, const float* bias, con
     a.nk_x = taps * a.xc; a.nk = a.nk_x;
     a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
     a.n_mtiles = cdiv(Cout, 256); a.n_ttiles = cdiv(L, 256);
-    a.C = Cout; a.act = act;
+    a.C = Cout; a.act = act; a.f32_cl = f32_channel_last;
     T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_BIAS_ACT, (hipStream_t)stream));
     return T2S_OK;
 }

@@ -1,0 +1,184 @@
+// extern "C" boundary of the Tacotron-2 kernels: validation, argument blocks, and the decode-step driver.
+#include "../../include/t2s_hip.h"
+#include "t2s_kernels.h"
+#include "tacotron_ops.h"
+
+#include <string.h>
+
+extern "C" int t2s_internal_fail_hip(int e);   // defined in t2s_api.hip (records the HIP error text)
+
+#define T2S_CHECK_HIP(expr)                                        \
+    do {                                                           \
+        hipError_t _e = (expr);                                    \
+        if (_e != hipSuccess) return t2s_internal_fail_hip((int)_e); \
+    } while (0)
+
+static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+static int gemv_args_ok(const GemvArgs& a) {
+    if (!a.W1 || !a.x1 || !a.y || a.rows <= 0 || a.items <= 0) return 0;
+    const int K = a.n1 + a.n2 + a.n3;
+    if (K != a.k1 + a.k2 || K > 2560) return 0;
+    if ((a.n1 | a.n2 | a.n3 | a.k1 | a.k2 | a.ld1 | a.ld2) & 3) return 0;
+    if ((a.sx1 | a.sx2 | a.sx3) & 3) return 0;
+    if (!al16(a.W1) || !al16(a.x1) || (a.W2 && !al16(a.W2)) || (a.x2 && !al16(a.x2)) || (a.x3 && !al16(a.x3))) return 0;
+    if ((a.n2 > 0 && !a.x2) || (a.n3 > 0 && !a.x3) || (a.k2 > 0 && !a.W2)) return 0;
+    return 1;
+}
+
+extern "C" {
+
+int t2s_gemv(const float* W1, int ld1, int k1, const float* W2, int ld2, int k2, const float* x1, int n1, long sx1,
+             const float* x2, int n2, long sx2, const float* x3, int n3, long sx3, const float* bias1,
+             const float* bias2, float* y, long sy_item, long sy_row, int rows, int items, int act,
+             const unsigned char* mask, long smask_item, float mask_scale, void* stream) {
+    GemvArgs a;
+    a.W1 = W1; a.ld1 = ld1; a.k1 = k1; a.W2 = W2; a.ld2 = ld2; a.k2 = k2;
+    a.x1 = x1; a.n1 = n1; a.sx1 = sx1; a.x2 = x2; a.n2 = n2; a.sx2 = sx2; a.x3 = x3; a.n3 = n3; a.sx3 = sx3;
+    a.bias1 = bias1; a.bias2 = bias2; a.y = y; a.sy_item = sy_item; a.sy_row = sy_row; a.rows = rows; a.items = items;
+    a.act = act; a.mask = mask; a.smask_item = smask_item; a.mask_scale = mask_scale;
+    if (!gemv_args_ok(a) || act < 0 || act > 2) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_gemv(a, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_transpose(const float* in, float* out, int R, int C, void* stream) {
+    if (!in || !out || R <= 0 || C <= 0) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_transpose(in, out, R, C, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_embed_planes(const long* ids, const float* emb, int B, int T, int E, int V, int Lp, int halo, void* X_hi,
+                     void* X_lo, void* stream) {
+    if (!ids || !emb || !X_hi || !X_lo || B <= 0 || T <= 0 || E <= 0 || V <= 0) return T2S_EINVAL;
+    if (Lp < t2s_plane_rows(T, halo)) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_embed_planes(ids, emb, B, T, E, V, Lp, halo, (u16*)X_hi, (u16*)X_lo, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_f32_to_planes(const float* x, int B, int C, int L, int Lp, int halo, void* X_hi, void* X_lo, void* stream) {
+    if (!x || !X_hi || !X_lo || B <= 0 || C <= 0 || L <= 0 || Lp < t2s_plane_rows(L, halo)) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_f32_to_planes(x, B, C, L, Lp, halo, (u16*)X_hi, (u16*)X_lo, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, const float* conv_bias,
+                float eps, int C, float* scale, float* bias_out, void* stream) {
+    if (!gamma || !beta || !mean || !var || !scale || !bias_out || C <= 0) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_bn_fold(gamma, beta, mean, var, conv_bias, eps, C, scale, bias_out, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_taco_encoder_lstm(const float* gx, const float* whhT_fwd, const float* whhT_rev, const int* lengths, float* out,
+                          int B, int T, int H, int T_out, void* stream) {
+    if (!gx || !whhT_fwd || !whhT_rev || !out || B <= 0 || T <= 0 || T_out <= 0 || T_out > T || 4 * H != 1024) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_lstm_seq(gx, whhT_fwd, whhT_rev, lengths, out, B, T, H, T_out, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_bernoulli_mask(unsigned char* mask, size_t n, unsigned long long seed, unsigned long long offset, void* stream) {
+    if (!mask || n == 0) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_bernoulli_mask(mask, n, seed, offset, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_taco_stop_check(const float* mel_gate_out, int B, int n_mel, int T_cap, int step0, int n, float threshold,
+                        int* stop_step, void* stream) {
+    if (!mel_gate_out || !stop_step || B <= 0 || step0 < 0 || n <= 0 || step0 + n > T_cap) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_stop_check(mel_gate_out + (size_t)n_mel * T_cap, B, (n_mel + 1) * T_cap, step0, n, threshold,
+                                        stop_step, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, void* stream_) {
+    if (!d || step0 < 0 || n_steps <= 0) return T2S_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int B = d->B, T = d->T_in, P = d->prenet_dim, E = d->enc_dim, A = d->att_rnn_dim, D = d->dec_rnn_dim;
+    if (B <= 0 || T <= 0 || A != D || (A & 3) || (P & 3) || (E & 3) || d->att_dim > 128 || d->loc_filters > 32 ||
+        d->loc_kernel > 63 || !(d->loc_kernel & 1))
+        return T2S_EINVAL;
+    if (step0 + n_steps > d->T_cap) return T2S_EINVAL;
+    if (!d->att_w_ih || !d->att_w_hh || !d->dec_w_ih || !d->dec_w_hh || !d->w_query || !d->w_loc_conv ||
+        !d->w_loc_dense || !d->w_v || !d->memory || !d->pmem || !d->att_h0 || !d->att_h1 || !d->att_c || !d->dec_h0 ||
+        !d->dec_h1 || !d->dec_c || !d->att_w || !d->att_wcum || !d->ctx || !d->q || !d->energies || !d->align_out)
+        return T2S_EINVAL;
+    if (d->teacher_forced) {
+        if (!d->pre_all || !d->hc_all) return T2S_EINVAL;
+    } else {
+        if (!d->w_proj || !d->b_proj || !d->w_projpre || !d->b_projpre || !d->w_pre2 || !d->pre1 || !d->pre2 ||
+            !d->mel_gate_out || !d->prenet_masks)
+            return T2S_EINVAL;
+    }
+    for (int s = step0; s < step0 + n_steps; ++s) {
+        float* ah_in = (s & 1) ? d->att_h1 : d->att_h0;
+        float* ah_out = (s & 1) ? d->att_h0 : d->att_h1;
+        float* dh_in = (s & 1) ? d->dec_h1 : d->dec_h0;
+        float* dh_out = (s & 1) ? d->dec_h0 : d->dec_h1;
+        // 1. attention LSTMCell on [prenet_out | context]
+        LstmCellArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.W_ih = d->att_w_ih; ca.W_hh = d->att_w_hh; ca.b_ih = d->att_b_ih; ca.b_hh = d->att_b_hh;
+        ca.x1 = d->teacher_forced ? d->pre_all + (size_t)s * B * P : d->pre2;
+        ca.n1 = P; ca.sx1 = P; ca.x2 = d->ctx; ca.n2 = E; ca.sx2 = E;
+        ca.h_in = ah_in; ca.h_out = ah_out; ca.c = d->att_c; ca.B = B; ca.H = A;
+        if (d->att_drop) { ca.drop_mask = d->att_drop + (size_t)s * B * A; ca.drop_scale = d->att_drop_scale; }
+        T2S_CHECK_HIP(t2s_launch_lstm_cell(ca, stream));
+        // 2. query = W_q h_att
+        GemvArgs qa;
+        memset(&qa, 0, sizeof(qa));
+        qa.W1 = d->w_query; qa.ld1 = A; qa.k1 = A; qa.x1 = ah_out; qa.n1 = A; qa.sx1 = A;
+        qa.y = d->q; qa.sy_item = d->att_dim; qa.sy_row = 1; qa.rows = d->att_dim; qa.items = B;
+        T2S_CHECK_HIP(t2s_launch_gemv(qa, stream));
+        // 3./4. location-sensitive energies, softmax, context, cumulative weights
+        AttArgs aa;
+        memset(&aa, 0, sizeof(aa));
+        aa.q = d->q; aa.w_loc_conv = d->w_loc_conv; aa.w_loc_dense = d->w_loc_dense; aa.w_v = d->w_v;
+        aa.pmem = d->pmem; aa.memory = d->memory; aa.lengths = d->mem_lengths;
+        aa.w_prev = d->att_w; aa.w_cum = d->att_wcum; aa.energies = d->energies; aa.ctx = d->ctx;
+        aa.align_out = d->align_out + (size_t)s * T; aa.s_align_b = (long)d->T_cap * T;
+        if (d->teacher_forced) { aa.ctx_copy = d->hc_all + (size_t)s * B * (D + E) + D; aa.s_ctx_copy = D + E; }
+        aa.B = B; aa.T = T; aa.att_dim = d->att_dim; aa.enc_dim = E; aa.loc_f = d->loc_filters; aa.loc_ks = d->loc_kernel;
+        T2S_CHECK_HIP(t2s_launch_att_energy(aa, stream));
+        T2S_CHECK_HIP(t2s_launch_att_softmax_ctx(aa, stream));
+        // 5. decoder LSTMCell on [h_att | context]
+        LstmCellArgs cd;
+        memset(&cd, 0, sizeof(cd));
+        cd.W_ih = d->dec_w_ih; cd.W_hh = d->dec_w_hh; cd.b_ih = d->dec_b_ih; cd.b_hh = d->dec_b_hh;
+        cd.x1 = ah_out; cd.n1 = A; cd.sx1 = A; cd.x2 = d->ctx; cd.n2 = E; cd.sx2 = E;
+        cd.h_in = dh_in; cd.h_out = dh_out; cd.c = d->dec_c; cd.B = B; cd.H = D;
+        if (d->dec_drop) { cd.drop_mask = d->dec_drop + (size_t)s * B * D; cd.drop_scale = d->dec_drop_scale; }
+        if (d->teacher_forced) { cd.h_copy = d->hc_all + (size_t)s * B * (D + E); cd.s_copy = D + E; }
+        T2S_CHECK_HIP(t2s_launch_lstm_cell(cd, stream));
+        if (!d->teacher_forced) {
+            // 6. mel frame + gate logit = W_proj [h_dec | context] + b
+            GemvArgs pa;
+            memset(&pa, 0, sizeof(pa));
+            pa.W1 = d->w_proj; pa.ld1 = D + E; pa.k1 = D + E;
+            pa.x1 = dh_out; pa.n1 = D; pa.sx1 = D; pa.x2 = d->ctx; pa.n2 = E; pa.sx2 = E;
+            pa.bias1 = d->b_proj; pa.y = d->mel_gate_out + s; pa.sy_item = (long)(d->n_mel + 1) * d->T_cap;
+            pa.sy_row = d->T_cap; pa.rows = d->n_mel + 1; pa.items = B;
+            T2S_CHECK_HIP(t2s_launch_gemv(pa, stream));
+            // 7. prenet of the next step's input (always-on dropout, modules.py:21).  Layer 0 is applied to the
+            //    mel frame through the precomposed matrix W_pre0 . W_proj so it needs no extra hop.
+            if (s + 1 < d->mask_steps) {
+                const unsigned char* mk = d->prenet_masks + (size_t)(s + 1) * B * 2 * P;
+                GemvArgs p1;
+                memset(&p1, 0, sizeof(p1));
+                p1.W1 = d->w_projpre; p1.ld1 = D + E; p1.k1 = D + E;
+                p1.x1 = dh_out; p1.n1 = D; p1.sx1 = D; p1.x2 = d->ctx; p1.n2 = E; p1.sx2 = E;
+                p1.bias1 = d->b_projpre; p1.y = d->pre1; p1.sy_item = P; p1.sy_row = 1; p1.rows = P; p1.items = B;
+                p1.act = ACT_RELU; p1.mask = mk; p1.smask_item = 2 * P; p1.mask_scale = 2.0f;
+                T2S_CHECK_HIP(t2s_launch_gemv(p1, stream));
+                GemvArgs p2;
+                memset(&p2, 0, sizeof(p2));
+                p2.W1 = d->w_pre2; p2.ld1 = P; p2.k1 = P; p2.x1 = d->pre1; p2.n1 = P; p2.sx1 = P;
+                p2.y = d->pre2; p2.sy_item = P; p2.sy_row = 1; p2.rows = P; p2.items = B;
+                p2.act = ACT_RELU; p2.mask = mk + P; p2.smask_item = 2 * P; p2.mask_scale = 2.0f;
+                T2S_CHECK_HIP(t2s_launch_gemv(p2, stream));
+            }
+        }
+    }
+    return T2S_OK;
+}
+
+}  // extern "C"

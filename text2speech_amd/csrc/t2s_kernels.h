@@ -31,6 +31,7 @@ struct ConvGemmArgs {
     int n_res;         // RESSKIP: packed rows < n_res are the residual half
     int skip_init;     // RESSKIP: 1 = store, 0 = accumulate
     int act;           // BIAS_ACT
+    int f32_cl;        // BIAS_ACT: out_f32 is [B][L][C] instead of [B][C][L]
 };
 
 hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a, int epi, hipStream_t stream);
@@ -49,6 +50,7 @@ struct PackArgs {
     int Cin_pad;           // tap stride in packed k (Cin rounded up to 32)
     int bias_accumulate;   // 1: bias_out[p] += bias_in[o]
     int row_off;           // PERM_NONE: packed row = o + row_off
+    int g_is_scale;        // 1: g[o] is a plain per-row scale (BatchNorm fold), 0: weight-norm gain
 };
 hipError_t t2s_launch_pack(const PackArgs& a, hipStream_t stream);
 hipError_t t2s_launch_weightnorm_small(const float* v, const float* g, int O, int K, float* w, hipStream_t stream);

@@ -1,0 +1,69 @@
+// Internal argument blocks of the Tacotron-2 kernels (tacotron_ops.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct GemvArgs {
+    const float* W1; int ld1; int k1;     // weight row = [W1[row][:k1] | W2[row][:k2]]
+    const float* W2; int ld2; int k2;
+    const float* x1; int n1; long sx1;    // input vector = [x1 | x2 | x3], per-item strides in floats
+    const float* x2; int n2; long sx2;
+    const float* x3; int n3; long sx3;
+    const float* bias1;
+    const float* bias2;
+    float* y; long sy_item; long sy_row;  // y[item*sy_item + row*sy_row]
+    int rows, items;
+    int act;
+    const unsigned char* mask; long smask_item; float mask_scale;
+};
+
+struct LstmCellArgs {
+    const float* W_ih;   // [4H][n1+n2]
+    const float* W_hh;   // [4H][H]
+    const float* b_ih;
+    const float* b_hh;
+    const float* x1; int n1; long sx1;
+    const float* x2; int n2; long sx2;
+    const float* h_in;   // [B][H]
+    float* h_out;        // [B][H]
+    float* c;            // [B][H], in place
+    float* h_copy; long s_copy;           // optional second copy of h_out (stride per item)
+    const unsigned char* drop_mask; float drop_scale;   // optional dropout on h_out ([B][H] of 0/1)
+    int B, H;
+};
+
+struct AttArgs {
+    const float* q;            // [B][att_dim]
+    const float* w_loc_conv;   // [F][2][KS]
+    const float* w_loc_dense;  // [att_dim][F]
+    const float* w_v;          // [att_dim]
+    const float* pmem;         // [B][T][att_dim]
+    const float* memory;       // [B][T][enc_dim]
+    const int* lengths;        // [B] or null
+    float* w_prev;             // [B][T]  in: previous weights, out: new weights
+    float* w_cum;              // [B][T]
+    float* energies;           // [B][T] scratch
+    float* ctx;                // [B][enc_dim]
+    float* ctx_copy; long s_ctx_copy;
+    float* align_out; long s_align_b;
+    int B, T, att_dim, enc_dim, loc_f, loc_ks;
+};
+
+hipError_t t2s_launch_gemv(const GemvArgs& a, hipStream_t stream);
+hipError_t t2s_launch_lstm_cell(const LstmCellArgs& a, hipStream_t stream);
+hipError_t t2s_launch_att_energy(const AttArgs& a, hipStream_t stream);
+hipError_t t2s_launch_att_softmax_ctx(const AttArgs& a, hipStream_t stream);
+hipError_t t2s_launch_lstm_seq(const float* gx, const float* whhT_f, const float* whhT_r, const int* lengths, float* out,
+                               int B, int T, int H, int T_out, hipStream_t stream);
+hipError_t t2s_launch_transpose(const float* in, float* out, int R, int C, hipStream_t stream);
+hipError_t t2s_launch_embed_planes(const long* ids, const float* emb, int B, int T, int E, int V, int Lp, int halo,
+                                   unsigned short* X_hi, unsigned short* X_lo, hipStream_t stream);
+hipError_t t2s_launch_f32_to_planes(const float* x, int B, int C, int L, int Lp, int halo, unsigned short* X_hi,
+                                    unsigned short* X_lo, hipStream_t stream);
+hipError_t t2s_launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                              const float* conv_bias, float eps, int C, float* scale, float* bias_out,
+                              hipStream_t stream);
+hipError_t t2s_launch_bernoulli_mask(unsigned char* mask, size_t n, unsigned long long seed, unsigned long long offset,
+                                     hipStream_t stream);
+hipError_t t2s_launch_stop_check(const float* gate_out, int B, int s_gate_b, int step0, int n, float threshold,
+                                 int* stop_step, hipStream_t stream);

@@ -1,0 +1,480 @@
+// Tacotron-2 hot path on gfx950: latency- and weight-streaming-bound pieces (exact f32, VALU).
+//
+// The decoder step (reference tacotron.py:355-393) is 71 MB of LSTM weights per step at <= 16 flop/B:
+// it is bound by streaming those weights out of L2 / Infinity Cache, not by math.  Design:
+//   * the 4096 gate rows of each LSTMCell are spread over 256 workgroups (4 hidden units each), one
+//     wave per hidden unit holding its four gate rows in registers and looping over the batch, so every
+//     weight byte is read once per step per chip; the cell update (sigmoid/tanh, c, h) is fused, so one
+//     launch per cell and no inter-workgroup hand-off inside a launch;
+//   * dependent stages are separate launches (a kernel boundary, ~1.5 us, is cheaper than a grid
+//     barrier on this chip - MI355X_MICROARCH.md price list), enqueued back-to-back by a C++ loop
+//     (t2s_taco_decode_steps) so the host never sits on the critical path;
+//   * softmax / dot-product reductions use wavefront shuffles.
+#include "t2s_common.h"
+#include "t2s_kernels.h"
+#include "tacotron_ops.h"
+
+static __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// Input vector of a GEMV = concatenation of up to three segments (e.g. [prenet_out | context | h]).
+struct XSeg {
+    const float* p[3];
+    int n[3];
+    long stride[3];      // per-item stride (floats)
+};
+
+// per-lane float4 slot v covers k = (v*64 + lane)*4 .. +3 of the concatenated vector
+template <int NV4>
+struct LaneMap {
+    const float* xp[NV4];
+    long xs[NV4];
+    bool valid[NV4];
+    __device__ void init(const XSeg& s, int lane) {
+        const int K = s.n[0] + s.n[1] + s.n[2];
+#pragma unroll
+        for (int v = 0; v < NV4; ++v) {
+            int k = (v * 64 + lane) * 4;
+            valid[v] = k < K;
+            int seg = 0;
+            if (k >= s.n[0]) { k -= s.n[0]; seg = 1; if (k >= s.n[1]) { k -= s.n[1]; seg = 2; } }
+            if (!valid[v]) { seg = 0; k = 0; }
+            xp[v] = s.p[seg] + k;
+            xs[v] = s.stride[seg];
+        }
+    }
+};
+
+// weight row = [W1 row (k1 floats) | W2 row (k2 floats)]
+template <int NV4>
+static __device__ __forceinline__ void load_row(f32x4 (&w)[NV4], const float* W1, int ld1, int k1, const float* W2,
+                                                int ld2, int k2, int row, int lane) {
+#pragma unroll
+    for (int v = 0; v < NV4; ++v) {
+        const int k = (v * 64 + lane) * 4;
+        if (k < k1) w[v] = *(const f32x4*)(W1 + (size_t)row * ld1 + k);
+        else if (k < k1 + k2) w[v] = *(const f32x4*)(W2 + (size_t)row * ld2 + (k - k1));
+        else w[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// y[item][row] = act(bias + W[row] . x[item]) * mask   — one wave per output row, weights in registers.
+// Restates every small Linear on the decoder path: query_layer (tacotron.py:137), linear_projection +
+// gate_layer (:387-392), Prenet layers (modules.py:19-22), memory_layer (tacotron.py:306).
+template <int NV4>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const GemvArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    f32x4 w[NV4];
+    load_row<NV4>(w, a.W1, a.ld1, a.k1, a.W2, a.ld2, a.k2, row, lane);
+    XSeg s = {{a.x1, a.x2, a.x3}, {a.n1, a.n2, a.n3}, {a.sx1, a.sx2, a.sx3}};
+    LaneMap<NV4> lm;
+    lm.init(s, lane);
+    const float bias = (a.bias1 ? a.bias1[row] : 0.f) + (a.bias2 ? a.bias2[row] : 0.f);
+    for (int it = blockIdx.y; it < a.items; it += gridDim.y) {
+        float acc = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV4; ++v) {
+            if (lm.valid[v]) {
+                const f32x4 x = *(const f32x4*)(lm.xp[v] + (size_t)it * lm.xs[v]);
+                acc += w[v][0] * x[0] + w[v][1] * x[1] + w[v][2] * x[2] + w[v][3] * x[3];
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            float y = acc + bias;
+            if (a.act == ACT_RELU) y = fmaxf(y, 0.f);
+            else if (a.act == ACT_TANH) y = tanhf(y);
+            if (a.mask) y *= a.mask[(size_t)it * a.smask_item + row] ? a.mask_scale : 0.f;
+            a.y[(size_t)it * a.sy_item + (size_t)row * a.sy_row] = y;
+        }
+    }
+}
+
+hipError_t t2s_launch_gemv(const GemvArgs& a, hipStream_t stream) {
+    const int K = a.n1 + a.n2 + a.n3;
+    const int nv4 = (K + 255) / 256;
+    dim3 grid((a.rows + 3) / 4, a.items < 64 ? 1 : (a.items < 4096 ? 16 : 64));
+#define GL(N) hipLaunchKernelGGL(gemv_rows_kernel<N>, grid, dim3(256), 0, stream, a)
+    if (nv4 <= 1) GL(1);
+    else if (nv4 <= 2) GL(2);
+    else if (nv4 <= 4) GL(4);
+    else if (nv4 <= 7) GL(7);
+    else if (nv4 <= 10) GL(10);
+    else return hipErrorInvalidValue;
+#undef GL
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused LSTMCell (torch gate order i,f,g,o; reference tacotron.py:366-370,380-385):
+//   gates = W_ih [x1|x2] + b_ih + W_hh h + b_hh ;  c' = s(f) c + s(i) tanh(g) ;  h' = s(o) tanh(c')
+// One wave per hidden unit u keeps rows {u, H+u, 2H+u, 3H+u} of [W_ih | W_hh] in registers and loops
+// over the batch; lane (b mod 64) then does the pointwise update for item b.  h is ping-ponged by the
+// caller (h_in read by every workgroup, h_out written by the owner), c is updated in place.
+template <int NV4>
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const LstmCellArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= a.H) return;
+    f32x4 w[4][NV4];
+    float bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        load_row<NV4>(w[g], a.W_ih, a.n1 + a.n2, a.n1 + a.n2, a.W_hh, a.H, a.H, g * a.H + u, lane);
+        bias[g] = a.b_ih[g * a.H + u] + a.b_hh[g * a.H + u];
+    }
+    XSeg s = {{a.x1, a.x2, a.h_in}, {a.n1, a.n2, a.H}, {a.sx1, a.sx2, (long)a.H}};
+    LaneMap<NV4> lm;
+    lm.init(s, lane);
+    for (int b0 = 0; b0 < a.B; b0 += 64) {
+        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
+        const int bn = min(64, a.B - b0);
+        for (int bb = 0; bb < bn; ++bb) {
+            const int it = b0 + bb;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < NV4; ++v) {
+                if (lm.valid[v]) {
+                    const f32x4 x = *(const f32x4*)(lm.xp[v] + (size_t)it * lm.xs[v]);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[g] += w[g][v][0] * x[0] + w[g][v][1] * x[1] + w[g][v][2] * x[2] + w[g][v][3] * x[3];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = wave_sum(acc[g]);
+            if (lane == bb) { gi = acc[0]; gf = acc[1]; gg = acc[2]; go = acc[3]; }
+        }
+        if (lane < bn) {
+            const int it = b0 + lane;
+            const size_t idx = (size_t)it * a.H + u;
+            const float c = a.c[idx];
+            const float c2 = sigmoid_acc(gf + bias[1]) * c + sigmoid_acc(gi + bias[0]) * tanhf(gg + bias[2]);
+            float h2 = sigmoid_acc(go + bias[3]) * tanhf(c2);
+            a.c[idx] = c2;
+            if (a.drop_mask) h2 = a.drop_mask[idx] ? h2 * a.drop_scale : 0.f;
+            a.h_out[idx] = h2;
+            if (a.h_copy) a.h_copy[(size_t)it * a.s_copy + u] = h2;
+        }
+    }
+}
+
+hipError_t t2s_launch_lstm_cell(const LstmCellArgs& a, hipStream_t stream) {
+    const int K = a.n1 + a.n2 + a.H;
+    const int nv4 = (K + 255) / 256;
+    dim3 grid((a.H + 3) / 4);
+#define LL(N) hipLaunchKernelGGL(lstm_cell_kernel<N>, grid, dim3(256), 0, stream, a)
+    if (nv4 <= 4) LL(4);
+    else if (nv4 <= 7) LL(7);
+    else if (nv4 <= 10) LL(10);
+    else return hipErrorInvalidValue;
+#undef LL
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Location-sensitive attention energies (reference tacotron.py:96-107,124-143):
+//   f[t][:]  = conv1d([w ; w_cum], K[32][2][31], pad 15)[:, t]
+//   e[t]     = v . tanh(q + D f[t] + processed_memory[t])          (masked to -inf beyond the length)
+// One workgroup = 16 time steps of one batch element; a wave handles 4 of them with attention_dim on lanes.
+#define ATT_TQ 16
+__global__ __launch_bounds__(256) void att_energy_kernel(const AttArgs a) {
+    __shared__ float s_cat[2][ATT_TQ + 64];
+    __shared__ float s_f[ATT_TQ][33];
+    extern __shared__ float s_k[];                       // loc conv weights [F][2][KS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * ATT_TQ;
+    const int KS = a.loc_ks, F = a.loc_f, pad = KS >> 1;
+    for (int i = tid; i < F * 2 * KS; i += 256) s_k[i] = a.w_loc_conv[i];
+    for (int i = tid; i < 2 * (ATT_TQ + KS - 1); i += 256) {
+        const int c = i / (ATT_TQ + KS - 1), j = i - c * (ATT_TQ + KS - 1);
+        const int t = t0 + j - pad;
+        const float* src = c ? a.w_cum : a.w_prev;
+        s_cat[c][j] = (t >= 0 && t < a.T) ? src[(size_t)b * a.T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < ATT_TQ * F; i += 256) {
+        const int tq = i / F, f = i - tq * F;
+        float acc = 0.f;
+        for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < KS; ++j) acc += s_k[(f * 2 + c) * KS + j] * s_cat[c][tq + j];
+        s_f[tq][f] = acc;
+    }
+    __syncthreads();
+    // attention_dim (<= 128) on lanes: a0 = lane, a1 = lane + 64
+    const int AD = a.att_dim;
+    float d0[32], d1[32];
+#pragma unroll
+    for (int f = 0; f < 32; ++f) {
+        d0[f] = (lane < AD && f < F) ? a.w_loc_dense[lane * F + f] : 0.f;
+        d1[f] = (lane + 64 < AD && f < F) ? a.w_loc_dense[(lane + 64) * F + f] : 0.f;
+    }
+    const float q0 = lane < AD ? a.q[(size_t)b * AD + lane] : 0.f;
+    const float q1 = lane + 64 < AD ? a.q[(size_t)b * AD + lane + 64] : 0.f;
+    const float v0 = lane < AD ? a.w_v[lane] : 0.f;
+    const float v1 = lane + 64 < AD ? a.w_v[lane + 64] : 0.f;
+    const int len = a.lengths ? a.lengths[b] : a.T;
+    for (int tq = wave; tq < ATT_TQ; tq += 4) {
+        const int t = t0 + tq;
+        if (t >= a.T) break;
+        float p0 = q0, p1 = q1;
+#pragma unroll
+        for (int f = 0; f < 32; ++f) {
+            const float ff = s_f[tq][f];
+            p0 += d0[f] * ff;
+            p1 += d1[f] * ff;
+        }
+        const float* pm = a.pmem + ((size_t)b * a.T + t) * AD;
+        float e = 0.f;
+        if (lane < AD) e += v0 * tanhf(p0 + pm[lane]);
+        if (lane + 64 < AD) e += v1 * tanhf(p1 + pm[lane + 64]);
+        e = wave_sum(e);
+        if (lane == 0) a.energies[(size_t)b * a.T + t] = t < len ? e : -INFINITY;
+    }
+}
+
+// softmax over T_in, context = weights . memory, cumulative weights (reference tacotron.py:159-164,379)
+__global__ __launch_bounds__(256) void att_softmax_ctx_kernel(const AttArgs a) {
+    extern __shared__ float s_w[];                       // [T]
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int T = a.T;
+    float m = -INFINITY;
+    for (int t = tid; t < T; t += 256) {
+        const float e = a.energies[(size_t)b * T + t];
+        s_w[t] = e;
+        m = fmaxf(m, e);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int t = tid; t < T; t += 256) {
+        const float p = expf(s_w[t] - m);
+        s_w[t] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int t = tid; t < T; t += 256) {
+        const float w = s_w[t] * inv;
+        s_w[t] = w;
+        a.w_prev[(size_t)b * T + t] = w;
+        a.w_cum[(size_t)b * T + t] += w;
+        if (a.align_out) a.align_out[(size_t)b * a.s_align_b + t] = w;
+    }
+    __syncthreads();
+    for (int c = tid; c < a.enc_dim; c += 256) {
+        const float* mem = a.memory + (size_t)b * T * a.enc_dim + c;
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) acc += s_w[t] * mem[(size_t)t * a.enc_dim];
+        a.ctx[(size_t)b * a.enc_dim + c] = acc;
+        if (a.ctx_copy) a.ctx_copy[(size_t)b * a.s_ctx_copy + c] = acc;
+    }
+}
+
+hipError_t t2s_launch_att_energy(const AttArgs& a, hipStream_t stream) {
+    dim3 grid((a.T + ATT_TQ - 1) / ATT_TQ, a.B);
+    hipLaunchKernelGGL(att_energy_kernel, grid, dim3(256), (size_t)a.loc_f * 2 * a.loc_ks * sizeof(float), stream, a);
+    return hipGetLastError();
+}
+hipError_t t2s_launch_att_softmax_ctx(const AttArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(att_softmax_ctx_kernel, dim3(a.B), dim3(256), (size_t)a.T * sizeof(float), stream, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Encoder BiLSTM recurrence with packed-sequence semantics (reference tacotron.py:199-207; nn.LSTM
+// bidirectional, H per direction).  gx[b][t][dir*4H + j] already holds W_ih x + b_ih + b_hh (one GEMM
+// for all steps).  One workgroup = one direction x BT batch elements; thread j owns gate row j and
+// streams W_hh^T (coalesced) each step; h lives in LDS.
+template <int BT>
+__global__ __launch_bounds__(1024) void lstm_seq_kernel(const float* __restrict__ gx, const float* __restrict__ whhT_f,
+                                                        const float* __restrict__ whhT_r, const int* __restrict__ lengths,
+                                                        float* out, int B, int T, int H, int T_out) {
+    __shared__ float s_h[BT][256];
+    __shared__ float s_g[BT][1024];
+    const int j = threadIdx.x;              // gate row, 4H == blockDim.x
+    const int dir = blockIdx.y;
+    const int b0 = blockIdx.x * BT;
+    const float* WT = dir ? whhT_r : whhT_f;     // [H][4H]
+    int len[BT];
+    int maxlen = 0;
+#pragma unroll
+    for (int i = 0; i < BT; ++i) {
+        len[i] = (b0 + i < B) ? (lengths ? lengths[b0 + i] : T) : 0;
+        maxlen = max(maxlen, len[i]);
+    }
+    float c[BT];
+#pragma unroll
+    for (int i = 0; i < BT; ++i) c[i] = 0.f;
+    if (j < H)
+#pragma unroll
+        for (int i = 0; i < BT; ++i) s_h[i][j] = 0.f;
+    __syncthreads();
+    for (int s = 0; s < maxlen; ++s) {
+        float acc[BT];
+#pragma unroll
+        for (int i = 0; i < BT; ++i) {
+            const int t = dir ? len[i] - 1 - s : s;
+            acc[i] = (s < len[i]) ? gx[((size_t)(b0 + i) * T + t) * (8 * H) + dir * 4 * H + j] : 0.f;
+        }
+#pragma unroll 8
+        for (int k = 0; k < H; ++k) {
+            const float w = WT[(size_t)k * 4 * H + j];
+#pragma unroll
+            for (int i = 0; i < BT; ++i) acc[i] += w * s_h[i][k];
+        }
+#pragma unroll
+        for (int i = 0; i < BT; ++i) s_g[i][j] = acc[i];
+        __syncthreads();
+        if (j < H) {
+#pragma unroll
+            for (int i = 0; i < BT; ++i) {
+                if (s < len[i]) {
+                    const float gi = s_g[i][j], gf = s_g[i][H + j], gg = s_g[i][2 * H + j], go = s_g[i][3 * H + j];
+                    c[i] = sigmoid_acc(gf) * c[i] + sigmoid_acc(gi) * tanhf(gg);
+                    const float h = sigmoid_acc(go) * tanhf(c[i]);
+                    s_h[i][j] = h;
+                    const int t = dir ? len[i] - 1 - s : s;
+                    out[((size_t)(b0 + i) * T_out + t) * (2 * H) + dir * H + j] = h;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // zero the padded tail (pad_packed_sequence semantics)
+    if (j < H)
+#pragma unroll
+        for (int i = 0; i < BT; ++i)
+            if (b0 + i < B)
+                for (int t = len[i]; t < T_out; ++t) out[((size_t)(b0 + i) * T_out + t) * (2 * H) + dir * H + j] = 0.f;
+}
+
+hipError_t t2s_launch_lstm_seq(const float* gx, const float* whhT_f, const float* whhT_r, const int* lengths, float* out,
+                               int B, int T, int H, int T_out, hipStream_t stream) {
+    if (4 * H != 1024) return hipErrorInvalidValue;
+    if (B >= 8) hipLaunchKernelGGL(lstm_seq_kernel<4>, dim3((B + 3) / 4, 2), dim3(1024), 0, stream, gx, whhT_f, whhT_r, lengths, out, B, T, H, T_out);
+    else hipLaunchKernelGGL(lstm_seq_kernel<1>, dim3(B, 2), dim3(1024), 0, stream, gx, whhT_f, whhT_r, lengths, out, B, T, H, T_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+__global__ void transpose_kernel(const float* in, float* out, int R, int C) {      // out[c][r] = in[r][c]
+    __shared__ float tile[32][33];
+    const int c = blockIdx.x * 32 + threadIdx.x, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8)
+        if (r0 + i < R && c < C) tile[i][threadIdx.x] = in[(size_t)(r0 + i) * C + c];
+    __syncthreads();
+    const int r = r0 + threadIdx.x, c0 = blockIdx.x * 32;
+    for (int i = threadIdx.y; i < 32; i += 8)
+        if (c0 + i < C && r < R) out[(size_t)(c0 + i) * R + r] = tile[threadIdx.x][i];
+}
+hipError_t t2s_launch_transpose(const float* in, float* out, int R, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, stream, in, out, R, C);
+    return hipGetLastError();
+}
+
+// Embedding lookup written straight into (hi, lo) planes: x[b][:, t] = emb[ids[b][t]]  (tacotron.py:40)
+__global__ void embed_planes_kernel(const long* ids, const float* emb, int B, int T, int E, int V, int Lp, int halo,
+                                    u16* X_hi, u16* X_lo) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    long id = ids[(size_t)b * T + t];
+    if (id < 0 || id >= V) id = 0;
+    const int nch = (E + 31) / 32;
+    for (int e = threadIdx.x; e < nch * 32; e += blockDim.x) {
+        const float v = e < E ? emb[(size_t)id * E + e] : 0.f;
+        u16 h, l;
+        split_bf16(v, h, l);
+        const size_t idx = (((size_t)b * nch + (e >> 5)) * Lp + halo + t) * 32 + (e & 31);
+        X_hi[idx] = h;
+        X_lo[idx] = l;
+    }
+}
+hipError_t t2s_launch_embed_planes(const long* ids, const float* emb, int B, int T, int E, int V, int Lp, int halo,
+                                   u16* X_hi, u16* X_lo, hipStream_t stream) {
+    hipLaunchKernelGGL(embed_planes_kernel, dim3(T, B), dim3(256), 0, stream, ids, emb, B, T, E, V, Lp, halo, X_hi, X_lo);
+    return hipGetLastError();
+}
+
+// [B][C][L] f32 -> planes (the decoder's mel output feeding the postnet, modules.py:131)
+__global__ void f32_to_planes_kernel(const float* x, int C, int L, int Lp, int halo, u16* X_hi, u16* X_lo) {
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int b = blockIdx.z;
+    const int nch = (C + 31) / 32;
+    if (t >= L) return;
+    for (int c = blockIdx.y * 32 + (threadIdx.x >> 6); c < blockIdx.y * 32 + 32; c += 4) {
+        const float v = c < C ? x[((size_t)b * C + c) * L + t] : 0.f;
+        u16 h, l;
+        split_bf16(v, h, l);
+        const size_t idx = (((size_t)b * nch + (c >> 5)) * Lp + halo + t) * 32 + (c & 31);
+        X_hi[idx] = h;
+        X_lo[idx] = l;
+    }
+}
+hipError_t t2s_launch_f32_to_planes(const float* x, int B, int C, int L, int Lp, int halo, u16* X_hi, u16* X_lo,
+                                    hipStream_t stream) {
+    hipLaunchKernelGGL(f32_to_planes_kernel, dim3((L + 63) / 64, (C + 31) / 32, B), dim3(256), 0, stream, x, C, L, Lp,
+                       halo, X_hi, X_lo);
+    return hipGetLastError();
+}
+
+// eval-mode BatchNorm folded into the preceding conv: scale[o] = gamma/sqrt(var+eps),
+// bias'[o] = (bias[o] - mean[o]) * scale[o] + beta[o]      (tacotron.py:183-184, modules.py:105-129)
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var,
+                               const float* conv_bias, float eps, int C, float* scale, float* bias_out) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= C) return;
+    const float s = gamma[o] / sqrtf(var[o] + eps);
+    scale[o] = s;
+    bias_out[o] = ((conv_bias ? conv_bias[o] : 0.f) - mean[o]) * s + beta[o];
+}
+hipError_t t2s_launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                              const float* conv_bias, float eps, int C, float* scale, float* bias_out,
+                              hipStream_t stream) {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, gamma, beta, mean, var, conv_bias,
+                       eps, C, scale, bias_out);
+    return hipGetLastError();
+}
+
+// Bernoulli(0.5) prenet masks from a counter hash (used when the caller does not inject masks)
+__global__ void bernoulli_mask_kernel(unsigned char* mask, size_t n, unsigned long long seed, unsigned long long offset) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long x = (i + offset) * 0x9E3779B97F4A7C15ull + seed;
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    mask[i] = (unsigned char)(x & 1);
+}
+hipError_t t2s_launch_bernoulli_mask(unsigned char* mask, size_t n, unsigned long long seed, unsigned long long offset,
+                                     hipStream_t stream) {
+    hipLaunchKernelGGL(bernoulli_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mask, n, seed, offset);
+    return hipGetLastError();
+}
+
+// first step (per batch element) at which sigmoid(gate) > threshold (reference tacotron.py:455)
+__global__ void stop_check_kernel(const float* gate_out, int B, int s_gate_b, int step0, int n, float threshold,
+                                  int* stop_step) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || stop_step[b] >= 0) return;
+    for (int s = step0; s < step0 + n; ++s) {
+        const float g = gate_out[(size_t)b * s_gate_b + s];
+        if (1.0f / (1.0f + expf(-g)) > threshold) { stop_step[b] = s; return; }
+    }
+}
+hipError_t t2s_launch_stop_check(const float* gate_out, int B, int s_gate_b, int step0, int n, float threshold,
+                                 int* stop_step, hipStream_t stream) {
+    hipLaunchKernelGGL(stop_check_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, gate_out, B, s_gate_b, step0, n,
+                       threshold, stop_step);
+    return hipGetLastError();
+}

@@ -17,7 +17,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
     const int n = a.Cin * a.Kt;
     const float* vrow = a.v + (size_t)o * n;
     float scale = 1.0f;
-    if (a.g) {
+    if (a.g && a.g_is_scale) {
+        scale = a.g[o];
+    } else if (a.g) {
         float ss = 0.f;
         for (int i = tid; i < n; i += 256) {
             const float x = vrow[i];
@@ -226,8 +228,8 @@ hipError_t t2s_launch_convinv(float* z, const float* W, int B, int n_group, int 
 // Gauss-Jordan in one thread (reference glow.py:90-91,100: W.inverse(), torch.logdet(W)).
 // A negative determinant yields NaN, as torch.logdet does.
 __global__ void small_logdet_inv_kernel(const float* W, int n, float scale, float* logdet_out, float* inv_out) {
+    __shared__ double a[16][32];        // one thread; LDS (not scratch) keeps the pivot loop fast
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double a[16][32];
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
             a[i][j] = W[i * n + j];

@@ -160,20 +160,20 @@ class _Engine:
                 v, gg = _vg(wn.in_layers[i])
                 v, gg, bb = _f32c(v), (None if gg is None else _f32c(gg)), _f32c(wn.in_layers[i].bias)
                 keep += [v, gg, bb]
-                _lib.call("t2s_pack_conv_weight", _lib.ptr(v), _lib.ptr(gg), _lib.ptr(bb), 2 * C, C, ks,
+                _lib.call("t2s_pack_conv_weight", _lib.ptr(v), _lib.ptr(gg), 0, _lib.ptr(bb), 2 * C, C, ks,
                           1, C, 0, g["Mpad1"], 0, g["Cpad"], _lib.ptr(ly["A1h"]), _lib.ptr(ly["A1l"]),
                           _lib.ptr(ly["b1"]), 0, st)
                 v, gg = _vg(wn.cond_layers[i])
                 v, gg, bb = _f32c(v), (None if gg is None else _f32c(gg)), _f32c(wn.cond_layers[i].bias)
                 keep += [v, gg, bb]
-                _lib.call("t2s_pack_conv_weight", _lib.ptr(v), _lib.ptr(gg), _lib.ptr(bb), 2 * C, g["n_cond"], 1,
+                _lib.call("t2s_pack_conv_weight", _lib.ptr(v), _lib.ptr(gg), 0, _lib.ptr(bb), 2 * C, g["n_cond"], 1,
                           1, C, 0, g["Mpad1"], ks * g["Cpad"], g["Spad"], _lib.ptr(ly["A1h"]), _lib.ptr(ly["A1l"]),
                           _lib.ptr(ly["b1"]), 1, st)
                 v, gg = _vg(wn.res_skip_layers[i])
                 v, gg, bb = _f32c(v), (None if gg is None else _f32c(gg)), _f32c(wn.res_skip_layers[i].bias)
                 keep += [v, gg, bb]
                 rows2 = v.size(0)
-                _lib.call("t2s_pack_conv_weight", _lib.ptr(v), _lib.ptr(gg), _lib.ptr(bb), rows2, C, 1,
+                _lib.call("t2s_pack_conv_weight", _lib.ptr(v), _lib.ptr(gg), 0, _lib.ptr(bb), rows2, C, 1,
                           0, 0, 0, ly["Mpad2"], 0, g["Cpad"], _lib.ptr(ly["A2h"]), _lib.ptr(ly["A2l"]),
                           _lib.ptr(ly["b2"]), 0, st)
             fl["w_inv"] = None

@@ -1,0 +1,57 @@
+"""Parameter containers with the reference's names and ``state_dict`` keys
+(reference tacotron/modules.py:11-22,94-137,248-284).  They hold weights; the math runs in
+libt2s_hip.so (see tacotron.py).  Only the live classes are provided — the Tacotron-1 leftovers
+(CBHG, Highway, ...) are never instantiated by the reference model."""
+import torch
+from torch import nn
+
+
+class LinearNorm(nn.Module):
+    def __init__(self, in_dim, out_dim, bias=True, w_init_gain="linear"):
+        super().__init__()
+        self.linear_layer = nn.Linear(in_dim, out_dim, bias=bias)
+        nn.init.xavier_uniform_(self.linear_layer.weight, gain=nn.init.calculate_gain(w_init_gain))
+
+
+class ConvNorm(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=None, dilation=1, bias=True,
+                 w_init_gain="linear"):
+        super().__init__()
+        if padding is None:
+            assert kernel_size % 2 == 1
+            padding = int(dilation * (kernel_size - 1) / 2)
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                              dilation=dilation, bias=bias)
+        nn.init.xavier_uniform_(self.conv.weight, gain=nn.init.calculate_gain(w_init_gain))
+
+
+class Prenet(nn.Module):
+    def __init__(self, in_dim, sizes):
+        super().__init__()
+        in_sizes = [in_dim] + sizes[:-1]
+        self.layers = nn.ModuleList([LinearNorm(i, o, bias=False) for i, o in zip(in_sizes, sizes)])
+
+
+class Postnet(nn.Module):
+    """Five 1-d convolutions + BatchNorm (reference modules.py:94-129)."""
+
+    def __init__(self, hparams):
+        super().__init__()
+        n_mel, emb, ks, n = (hparams["n_mel_channels"], hparams["postnet_embedding_dim"],
+                             hparams["postnet_kernel_size"], hparams["postnet_n_convolutions"])
+        dims = [n_mel] + [emb] * (n - 1) + [n_mel]
+        self.convolutions = nn.ModuleList()
+        for i in range(n):
+            gain = "tanh" if i < n - 1 else "linear"
+            self.convolutions.append(nn.Sequential(
+                ConvNorm(dims[i], dims[i + 1], kernel_size=ks, stride=1, padding=(ks - 1) // 2, dilation=1,
+                         w_init_gain=gain),
+                nn.BatchNorm1d(dims[i + 1])))
+
+
+def get_mask_from_lengths(lengths):
+    """True on valid positions (reference modules.py:280-284 returns the same mask as uint8 and is
+    CUDA-only; callers negate it)."""
+    max_len = int(torch.max(lengths).item())
+    ids = torch.arange(0, max_len, device=lengths.device)
+    return ids < lengths.unsqueeze(1)

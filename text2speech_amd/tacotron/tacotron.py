@@ -1,0 +1,453 @@
+"""MI355X-native Tacotron-2 with the reference module API.
+
+Drop-in for reference ``tacotron/tacotron.py``: ``Tacotron(hparams, n_vocab, ..., num_speakers)``
+with ``forward(inputs)``, ``inference(inputs, speaker_id)``, ``parse_batch``, ``parse_output`` and
+the same ``state_dict`` keys.  ``Encoder`` / ``Decoder`` / ``Attention`` /
+``LocationLayer`` are parameter containers; the math is issued by ``_TacoEngine`` through the C ABI
+of ``libt2s_hip.so`` (include/t2s_hip.h).  No CPU / eager fallback.
+
+Dropout: the prenet's dropout is always on in the reference (modules.py:21).  Masks can be injected
+(``prenet_masks=`` {0,1} bytes) for parity tests; otherwise they are drawn on the device.
+Training-mode forward (BatchNorm batch statistics, encoder / LSTM / postnet dropout, backward) is
+not built yet and raises.
+"""
+import ctypes
+from math import sqrt
+
+import torch
+from torch import nn
+
+from .. import _lib
+from .modules import ConvNorm, LinearNorm, Postnet, Prenet, get_mask_from_lengths
+
+BN_EPS = 1e-5
+
+
+class LocationLayer(nn.Module):
+    def __init__(self, attention_n_filters, attention_kernel_size, attention_dim):
+        super().__init__()
+        padding = int((attention_kernel_size - 1) / 2)
+        self.location_conv = ConvNorm(2, attention_n_filters, kernel_size=attention_kernel_size, padding=padding,
+                                      bias=False, stride=1, dilation=1)
+        self.location_dense = LinearNorm(attention_n_filters, attention_dim, bias=False, w_init_gain="tanh")
+
+
+class Attention(nn.Module):
+    def __init__(self, attention_rnn_dim, embedding_dim, attention_dim, attention_location_n_filters,
+                 attention_location_kernel_size):
+        super().__init__()
+        self.query_layer = LinearNorm(attention_rnn_dim, attention_dim, bias=False, w_init_gain="tanh")
+        self.memory_layer = LinearNorm(embedding_dim, attention_dim, bias=False, w_init_gain="tanh")
+        self.v = LinearNorm(attention_dim, 1, bias=False)
+        self.location_layer = LocationLayer(attention_location_n_filters, attention_location_kernel_size,
+                                            attention_dim)
+        self.score_mask_value = -float("inf")
+
+
+class Encoder(nn.Module):
+    """3 x (Conv1d k5 + BatchNorm1d) + BiLSTM (reference tacotron.py:167-190)."""
+
+    def __init__(self, hparams):
+        super().__init__()
+        C, ks = hparams["enc_conv_channels"], hparams["enc_conv_kernel_size"]
+        self.convolutions = nn.ModuleList([
+            nn.Sequential(ConvNorm(C, C, kernel_size=ks, stride=1, padding=(ks - 1) // 2, dilation=1,
+                                   w_init_gain="relu"), nn.BatchNorm1d(C))
+            for _ in range(hparams["enc_conv_num_layers"])])
+        self.lstm = nn.LSTM(C, C // 2, 1, batch_first=True, bidirectional=True)
+
+
+class Decoder(nn.Module):
+    """Prenet, attention LSTMCell, attention, decoder LSTMCell, projection, gate (reference tacotron.py:223-260)."""
+
+    def __init__(self, hparams):
+        super().__init__()
+        hp = hparams
+        self.n_mel_channels = hp["n_mel_channels"]
+        self.n_frames_per_step = hp["n_frames_per_step"]
+        self.encoder_embedding_dim = hp["enc_conv_channels"]
+        self.attention_rnn_dim = hp["attention_rnn_dim"]
+        self.decoder_rnn_dim = hp["decoder_rnn_dim"]
+        self.prenet_dim = hp["prenet_dim"]
+        self.max_decoder_steps = hp["max_decoder_steps"]
+        self.gate_threshold = hp["gate_threshold"]
+        self.p_attention_dropout = hp["p_attention_dropout"]
+        self.p_decoder_dropout = hp["p_decoder_dropout"]
+        n_out = hp["n_mel_channels"] * hp["n_frames_per_step"]
+        self.prenet = Prenet(n_out, [hp["prenet_dim"], hp["prenet_dim"]])
+        self.attention_rnn = nn.LSTMCell(hp["prenet_dim"] + hp["enc_conv_channels"], hp["attention_rnn_dim"])
+        self.attention_layer = Attention(hp["attention_rnn_dim"], hp["enc_conv_channels"], hp["attention_dim"],
+                                         hp["attention_location_n_filters"], hp["attention_location_kernel_size"])
+        self.decoder_rnn = nn.LSTMCell(hp["attention_rnn_dim"] + hp["enc_conv_channels"], hp["decoder_rnn_dim"], 1)
+        self.linear_projection = LinearNorm(hp["decoder_rnn_dim"] + hp["enc_conv_channels"], n_out)
+        self.gate_layer = LinearNorm(hp["decoder_rnn_dim"] + hp["enc_conv_channels"], 1, bias=True,
+                                     w_init_gain="sigmoid")
+
+
+class _DecoderStruct(ctypes.Structure):
+    """Mirror of ``t2s_taco_decoder`` (include/t2s_hip.h)."""
+    _I = ["B", "T_in", "n_mel", "prenet_dim", "enc_dim", "att_rnn_dim", "dec_rnn_dim", "att_dim", "loc_filters",
+          "loc_kernel", "T_cap", "teacher_forced", "mask_steps"]
+    _P1 = ["att_w_ih", "att_w_hh", "att_b_ih", "att_b_hh", "dec_w_ih", "dec_w_hh", "dec_b_ih", "dec_b_hh",
+           "w_query", "w_loc_conv", "w_loc_dense", "w_v", "w_proj", "b_proj", "w_projpre", "b_projpre", "w_pre2",
+           "memory", "pmem", "mem_lengths", "pre_all", "prenet_masks", "att_drop", "dec_drop"]
+    _F = ["att_drop_scale", "dec_drop_scale"]
+    _P2 = ["att_h0", "att_h1", "att_c", "dec_h0", "dec_h1", "dec_c", "att_w", "att_wcum", "ctx", "q", "energies",
+           "pre1", "pre2", "mel_gate_out", "align_out", "hc_all"]
+    _fields_ = ([(n, ctypes.c_int) for n in _I] + [(n, ctypes.c_void_p) for n in _P1] +
+                [(n, ctypes.c_float) for n in _F] + [(n, ctypes.c_void_p) for n in _P2])
+
+
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _TacoEngine:
+    def __init__(self, model):
+        self.m = model
+        self.prep = None
+        self.prep_key = None
+
+    # ------------------------------------------------------------------ weight preparation
+    def _pack_conv_bn(self, seq, dev, halo):
+        """ConvNorm + eval BatchNorm1d -> packed GEMM planes with the BN affine folded in."""
+        conv, bn = seq[0].conv, seq[1]
+        st = _lib.current_stream()
+        O, Cin, Kt = conv.weight.shape
+        Cpad = -(-Cin // 32) * 32
+        Mpad = _lib.padded_rows(O)
+        A_hi = torch.zeros(Kt * Cpad // 32, Mpad, 32, dtype=torch.bfloat16, device=dev)
+        A_lo = torch.zeros_like(A_hi)
+        bias = torch.zeros(Mpad, dtype=torch.float32, device=dev)
+        scale = torch.empty(O, dtype=torch.float32, device=dev)
+        bfold = torch.empty(O, dtype=torch.float32, device=dev)
+        w, cb = _f32(conv.weight), (None if conv.bias is None else _f32(conv.bias))
+        g, be, mu, var = _f32(bn.weight), _f32(bn.bias), _f32(bn.running_mean), _f32(bn.running_var)
+        _lib.call("t2s_bn_fold", _lib.ptr(g), _lib.ptr(be), _lib.ptr(mu), _lib.ptr(var), _lib.ptr(cb), float(bn.eps), O,
+                  _lib.ptr(scale), _lib.ptr(bfold), st)
+        _lib.call("t2s_pack_conv_weight", _lib.ptr(w), _lib.ptr(scale), 1, _lib.ptr(bfold), O, Cin, Kt, 0, 0, 0, Mpad, 0,
+                  Cpad, _lib.ptr(A_hi), _lib.ptr(A_lo), _lib.ptr(bias), 0, st)
+        return dict(A_hi=A_hi, A_lo=A_lo, bias=bias, Mpad=Mpad, Cin=Cin, Cout=O, taps=Kt, keep=(w, cb, g, be, mu, var, scale, bfold))
+
+    def prepare(self, dev):
+        m = self.m
+        key = tuple(p._version for p in m.parameters()) + tuple(b._version for b in m.buffers()) + (str(dev),)
+        if self.prep is not None and self.prep_key == key:
+            return self.prep
+        st = _lib.current_stream()
+        enc, dec = m.encoder, m.decoder
+        P = {}
+        P["emb"] = _f32(m.embedding.weight)
+        P["enc_convs"] = [self._pack_conv_bn(seq, dev, 2) for seq in enc.convolutions]
+        # BiLSTM: one input-projection GEMM for both directions, bias = b_ih + b_hh
+        H = enc.lstm.hidden_size
+        w_ih = torch.cat([_f32(enc.lstm.weight_ih_l0), _f32(enc.lstm.weight_ih_l0_reverse)], 0).contiguous()
+        b_ih = torch.cat([_f32(enc.lstm.bias_ih_l0), _f32(enc.lstm.bias_ih_l0_reverse)], 0).contiguous()
+        b_hh = torch.cat([_f32(enc.lstm.bias_hh_l0), _f32(enc.lstm.bias_hh_l0_reverse)], 0).contiguous()
+        Cin = w_ih.size(1)
+        Cpad, Mpad = -(-Cin // 32) * 32, _lib.padded_rows(8 * H)
+        A_hi = torch.zeros(Cpad // 32, Mpad, 32, dtype=torch.bfloat16, device=dev)
+        A_lo = torch.zeros_like(A_hi)
+        bias = torch.zeros(Mpad, dtype=torch.float32, device=dev)
+        for bvec, accum in ((b_ih, 0), (b_hh, 1)):
+            _lib.call("t2s_pack_conv_weight", _lib.ptr(w_ih), None, 0, _lib.ptr(bvec), 8 * H, Cin, 1, 0, 0, 0, Mpad, 0, Cpad,
+                      _lib.ptr(A_hi), _lib.ptr(A_lo), _lib.ptr(bias), accum, st)
+        P["lstm_in"] = dict(A_hi=A_hi, A_lo=A_lo, bias=bias, Mpad=Mpad, Cin=Cin, Cout=8 * H, keep=(w_ih, b_ih, b_hh))
+        P["H"] = H
+        P["whhT"] = []
+        for w in (enc.lstm.weight_hh_l0, enc.lstm.weight_hh_l0_reverse):
+            w = _f32(w)
+            wt = torch.empty(H, 4 * H, dtype=torch.float32, device=dev)
+            _lib.call("t2s_transpose", _lib.ptr(w), _lib.ptr(wt), 4 * H, H, st)
+            P["whhT"].append((wt, w))
+        P["post_convs"] = [self._pack_conv_bn(seq, dev, 2) for seq in m.postnet.convolutions]
+        # decoder
+        al = dec.attention_layer
+        P["w_mem"] = _f32(al.memory_layer.linear_layer.weight)
+        for name, t in [("att_w_ih", dec.attention_rnn.weight_ih), ("att_w_hh", dec.attention_rnn.weight_hh),
+                        ("att_b_ih", dec.attention_rnn.bias_ih), ("att_b_hh", dec.attention_rnn.bias_hh),
+                        ("dec_w_ih", dec.decoder_rnn.weight_ih), ("dec_w_hh", dec.decoder_rnn.weight_hh),
+                        ("dec_b_ih", dec.decoder_rnn.bias_ih), ("dec_b_hh", dec.decoder_rnn.bias_hh),
+                        ("w_query", al.query_layer.linear_layer.weight),
+                        ("w_loc_conv", al.location_layer.location_conv.conv.weight),
+                        ("w_loc_dense", al.location_layer.location_dense.linear_layer.weight),
+                        ("w_v", al.v.linear_layer.weight),
+                        ("w_pre1", dec.prenet.layers[0].linear_layer.weight),
+                        ("w_pre2", dec.prenet.layers[1].linear_layer.weight)]:
+            P[name] = _f32(t)
+        n_mel = dec.n_mel_channels * dec.n_frames_per_step
+        P["w_proj"] = torch.cat([_f32(dec.linear_projection.linear_layer.weight),
+                                 _f32(dec.gate_layer.linear_layer.weight)], 0).contiguous()
+        P["b_proj"] = torch.cat([_f32(dec.linear_projection.linear_layer.bias),
+                                 _f32(dec.gate_layer.linear_layer.bias)], 0).contiguous()
+        # w_projpre = W_pre1 . W_proj[:n_mel]  (prenet layer 0 applied straight to [h_dec | ctx])
+        DE = P["w_proj"].size(1)
+        Pd = dec.prenet_dim
+        projT = torch.empty(DE, n_mel, dtype=torch.float32, device=dev)
+        _lib.call("t2s_transpose", _lib.ptr(P["w_proj"]), _lib.ptr(projT), n_mel, DE, st)
+        P["w_projpre"] = torch.empty(Pd, DE, dtype=torch.float32, device=dev)
+        _lib.call("t2s_gemv", _lib.ptr(P["w_pre1"]), n_mel, n_mel, None, 0, 0, _lib.ptr(projT), n_mel, n_mel, None, 0, 0,
+                  None, 0, 0, None, None, _lib.ptr(P["w_projpre"]), 1, DE, Pd, DE, 0, None, 0, 1.0, st)
+        P["b_projpre"] = torch.empty(Pd, dtype=torch.float32, device=dev)
+        _lib.call("t2s_gemv", _lib.ptr(P["w_pre1"]), n_mel, n_mel, None, 0, 0, _lib.ptr(P["b_proj"]), n_mel, n_mel, None, 0,
+                  0, None, 0, 0, None, None, _lib.ptr(P["b_projpre"]), Pd, 1, Pd, 1, 0, None, 0, 1.0, st)
+        P["_projT"] = projT
+        self.prep, self.prep_key = P, key
+        return P
+
+    # ------------------------------------------------------------------ building blocks
+    def _conv(self, layer, Xh, Xl, B, L, Lp, halo, act, out_planes=True, out_f32=None, f32_cl=0):
+        dev = Xh.device
+        oc = -(-layer["Cout"] // 32)
+        Oh = Ol = None
+        if out_planes:
+            Oh = torch.zeros(B, oc, Lp, 32, dtype=torch.bfloat16, device=dev)
+            Ol = torch.zeros_like(Oh)
+        _lib.call("t2s_conv_bias_act", _lib.ptr(layer["A_hi"]), _lib.ptr(layer["A_lo"]), _lib.ptr(layer["bias"]),
+                  _lib.ptr(Xh), _lib.ptr(Xl), _lib.ptr(Oh), _lib.ptr(Ol), _lib.ptr(out_f32), f32_cl, B, layer["Cin"],
+                  layer["Cout"], layer.get("taps", 1), 1, act, L, Lp, halo, layer["Mpad"], _lib.current_stream())
+        return Oh, Ol
+
+    def encode(self, ids, lengths):
+        """Embedding + Encoder.forward / .inference (reference tacotron.py:40,192-220)."""
+        m, P = self.m, self.prep
+        dev = ids.device
+        st = _lib.current_stream()
+        B, T = ids.shape
+        E = m.embedding.embedding_dim
+        halo = 2
+        Lp = _lib.plane_rows(T, halo)
+        ids64 = ids.to(torch.int64).contiguous()
+        Xh = torch.zeros(B, -(-E // 32), Lp, 32, dtype=torch.bfloat16, device=dev)
+        Xl = torch.zeros_like(Xh)
+        _lib.call("t2s_embed_planes", _lib.ptr(ids64), _lib.ptr(P["emb"]), B, T, E, m.embedding.num_embeddings, Lp, halo,
+                  _lib.ptr(Xh), _lib.ptr(Xl), st)
+        for layer in P["enc_convs"]:
+            Xh, Xl = self._conv(layer, Xh, Xl, B, T, Lp, halo, 1)
+        H = P["H"]
+        gx = torch.empty(B, T, 8 * H, dtype=torch.float32, device=dev)
+        self._conv(P["lstm_in"], Xh, Xl, B, T, Lp, halo, 0, out_planes=False, out_f32=gx, f32_cl=1)
+        if lengths is not None:
+            len32 = lengths.to(device=dev, dtype=torch.int32).contiguous()
+            T_out = int(lengths.max().item())
+        else:
+            len32, T_out = None, T
+        memory = torch.empty(B, T_out, 2 * H, dtype=torch.float32, device=dev)
+        _lib.call("t2s_taco_encoder_lstm", _lib.ptr(gx), _lib.ptr(P["whhT"][0][0]), _lib.ptr(P["whhT"][1][0]),
+                  _lib.ptr(len32), _lib.ptr(memory), B, T, H, T_out, st)
+        return memory, len32
+
+    def _gemv(self, W, x, rows, items, K, y, act=0, mask=None, smask=0, mask_scale=1.0, bias=None, sy_item=None,
+              sx=None):
+        _lib.call("t2s_gemv", _lib.ptr(W), K, K, None, 0, 0, _lib.ptr(x), K, K if sx is None else sx, None, 0, 0, None, 0,
+                  0, _lib.ptr(bias), None, _lib.ptr(y), rows if sy_item is None else sy_item, 1, rows, items, act,
+                  _lib.ptr(mask), smask, mask_scale, _lib.current_stream())
+
+    def _decoder_struct(self, memory, len32, T_cap, teacher, extra):
+        m, P = self.m, self.prep
+        dec = m.decoder
+        dev = memory.device
+        B, T_in, E = memory.shape
+        A, D, Pd = dec.attention_rnn_dim, dec.decoder_rnn_dim, dec.prenet_dim
+        al = dec.attention_layer
+        ad = al.query_layer.linear_layer.out_features
+        n_mel = dec.n_mel_channels * dec.n_frames_per_step
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        S = dict(att_h0=z(B, A), att_h1=z(B, A), att_c=z(B, A), dec_h0=z(B, D), dec_h1=z(B, D), dec_c=z(B, D),
+                 att_w=z(B, T_in), att_wcum=z(B, T_in), ctx=z(B, E), q=z(B, ad), energies=z(B, T_in),
+                 pre1=z(B, Pd), pre2=z(B, Pd), align_out=z(B, T_cap, T_in))
+        pmem = torch.empty(B, T_in, ad, dtype=torch.float32, device=dev)
+        self._gemv(P["w_mem"], memory, ad, B * T_in, E, pmem)
+        S["pmem"], S["memory"] = pmem, memory
+        d = _DecoderStruct()
+        for k, v in dict(B=B, T_in=T_in, n_mel=n_mel, prenet_dim=Pd, enc_dim=E, att_rnn_dim=A, dec_rnn_dim=D, att_dim=ad,
+                         loc_filters=al.location_layer.location_conv.conv.out_channels,
+                         loc_kernel=al.location_layer.location_conv.conv.kernel_size[0], T_cap=T_cap,
+                         teacher_forced=1 if teacher else 0, mask_steps=0).items():
+            setattr(d, k, v)
+        for name in ["att_w_ih", "att_w_hh", "att_b_ih", "att_b_hh", "dec_w_ih", "dec_w_hh", "dec_b_ih", "dec_b_hh",
+                     "w_query", "w_loc_conv", "w_loc_dense", "w_v", "w_proj", "b_proj", "w_projpre", "b_projpre",
+                     "w_pre2"]:
+            setattr(d, name, P[name].data_ptr())
+        for name, t in S.items():
+            setattr(d, name, t.data_ptr())
+        d.mem_lengths = None if len32 is None else len32.data_ptr()
+        d.att_drop_scale = d.dec_drop_scale = 1.0
+        for name, t in extra.items():
+            setattr(d, name, None if t is None else t.data_ptr())
+            S[name] = t
+        return d, S
+
+    def postnet(self, mel):
+        """Postnet.forward in eval mode (reference modules.py:131-137): 5 x conv+BN, tanh on the first four."""
+        P = self.prep
+        B, C, T = mel.shape
+        halo = 2
+        Lp = _lib.plane_rows(T, halo)
+        dev = mel.device
+        mel = mel.contiguous()
+        Xh = torch.zeros(B, -(-C // 32), Lp, 32, dtype=torch.bfloat16, device=dev)
+        Xl = torch.zeros_like(Xh)
+        _lib.call("t2s_f32_to_planes", _lib.ptr(mel), B, C, T, Lp, halo, _lib.ptr(Xh), _lib.ptr(Xl), _lib.current_stream())
+        n = len(P["post_convs"])
+        out = torch.empty(B, C, T, dtype=torch.float32, device=dev)
+        for i, layer in enumerate(P["post_convs"]):
+            if i < n - 1:
+                Xh, Xl = self._conv(layer, Xh, Xl, B, T, Lp, halo, 2)
+            else:
+                self._conv(layer, Xh, Xl, B, T, Lp, halo, 0, out_planes=False, out_f32=out)
+        return out
+
+    def _masks(self, prenet_masks, n, B, Pd, dev, seed):
+        if prenet_masks is not None:
+            mk = prenet_masks.to(device=dev, dtype=torch.uint8).contiguous()
+            assert mk.numel() >= n * B * 2 * Pd, "prenet_masks too short"
+            return mk
+        mk = torch.empty(n, B, 2, Pd, dtype=torch.uint8, device=dev)
+        _lib.call("t2s_bernoulli_mask", _lib.ptr(mk), mk.numel(), int(seed), 0, _lib.current_stream())
+        return mk
+
+    # ------------------------------------------------------------------ whole-model paths
+    def inference(self, ids, prenet_masks=None, seed=0, chunk=64):
+        m = self.m
+        dec = m.decoder
+        dev = ids.device
+        self.prepare(dev)
+        memory, _ = self.encode(ids, None)
+        B = ids.size(0)
+        T_cap = int(dec.max_decoder_steps)
+        n_mel = dec.n_mel_channels * dec.n_frames_per_step
+        mk = self._masks(prenet_masks, T_cap, B, dec.prenet_dim, dev, seed)
+        mel_gate = torch.zeros(B, n_mel + 1, T_cap, dtype=torch.float32, device=dev)
+        d, S = self._decoder_struct(memory, None, T_cap, False, dict(prenet_masks=mk, mel_gate_out=mel_gate))
+        d.mask_steps = mk.numel() // (B * 2 * dec.prenet_dim)
+        stop = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        st = _lib.current_stream()
+        s0 = 0
+        n_done = T_cap
+        while s0 < T_cap:
+            n = min(chunk, T_cap - s0)
+            _lib.call("t2s_taco_decode_steps", ctypes.byref(d), s0, n, st)
+            _lib.call("t2s_taco_stop_check", _lib.ptr(mel_gate), B, n_mel, T_cap, s0, n, float(dec.gate_threshold),
+                      _lib.ptr(stop), st)
+            s0 += n
+            sv = stop.cpu()                     # sparse poll: one host sync per chunk, not per frame
+            if bool((sv >= 0).all()):
+                n_done = int(sv.max().item()) + 1
+                break
+        else:
+            print("Warning! Reached max decoder steps")
+        mel = mel_gate[:, :n_mel, :n_done].contiguous()
+        gate = mel_gate[:, n_mel, :n_done].unsqueeze(-1).contiguous()          # [B, T, 1] as the reference returns
+        align = S["align_out"][:, :n_done].contiguous()
+        mel_post = mel + self.postnet(mel)
+        return [mel, mel_post, gate, align]
+
+    def forward(self, text, text_lengths, mels, output_lengths, prenet_masks=None, seed=0):
+        m = self.m
+        dec = m.decoder
+        dev = text.device
+        self.prepare(dev)
+        memory, len32 = self.encode(text, text_lengths)
+        B, n_mel, T_out = mels.shape
+        Pd, D, E = dec.prenet_dim, dec.decoder_rnn_dim, memory.size(2)
+        P = self.prep
+        # teacher forcing: prenet hoisted over [go frame ; all target frames] (reference tacotron.py:409-412)
+        frames = torch.cat((torch.zeros(1, B, n_mel, dtype=torch.float32, device=dev),
+                            mels.to(torch.float32).permute(2, 0, 1)), 0).contiguous()
+        mk = self._masks(prenet_masks, T_out + 1, B, Pd, dev, seed)
+        items = (T_out + 1) * B
+        p1 = torch.empty(items, Pd, dtype=torch.float32, device=dev)
+        pre_all = torch.empty(items, Pd, dtype=torch.float32, device=dev)
+        self._gemv(P["w_pre1"], frames, Pd, items, n_mel, p1, act=1, mask=mk, smask=2 * Pd, mask_scale=2.0)
+        mk1 = mk.view(-1)[Pd:]
+        self._gemv(P["w_pre2"], p1, Pd, items, Pd, pre_all, act=1, mask=mk1, smask=2 * Pd, mask_scale=2.0)
+        hc_all = torch.empty(T_out, B, D + E, dtype=torch.float32, device=dev)
+        d, S = self._decoder_struct(memory, len32, T_out, True, dict(pre_all=pre_all, hc_all=hc_all))
+        _lib.call("t2s_taco_decode_steps", ctypes.byref(d), 0, T_out, _lib.current_stream())
+        # hoisted projection + gate over all steps (reference tacotron.py:387-392)
+        proj = torch.empty(T_out * B, n_mel + 1, dtype=torch.float32, device=dev)
+        self._gemv(P["w_proj"], hc_all, n_mel + 1, T_out * B, D + E, proj, bias=P["b_proj"])
+        proj = proj.view(T_out, B, n_mel + 1)
+        mel = proj[:, :, :n_mel].permute(1, 2, 0).contiguous()
+        gate = proj[:, :, n_mel].permute(1, 0).contiguous()
+        mel_post = mel + self.postnet(mel)
+        return [mel, mel_post, gate, S["align_out"]]
+
+
+class Tacotron(nn.Module):
+    def __init__(self, hparams, n_vocab, mel_dim=80, linear_dim=1025, r=5, padding_idx=None, num_speakers=1):
+        super().__init__()
+        self.hparams = hparams
+        self.mel_dim = mel_dim
+        self.linear_dim = linear_dim
+        embedding_dim = hparams["embedding_size"]
+        self.embedding = nn.Embedding(n_vocab, embedding_dim)
+        std = sqrt(2.0 / (n_vocab + embedding_dim))
+        val = sqrt(3.0) * std
+        self.embedding.weight.data.uniform_(-val, val)
+        # dead weights the reference keeps in its state_dict (tacotron.py:27-29; speaker_id is unused by the math)
+        self.speaker_embed_table = nn.Embedding(num_speakers, hparams["speaker_embedding_size"])
+        self.deep_linear = nn.Linear(hparams["speaker_embedding_size"], 512)
+        self.encoder = Encoder(hparams)
+        self.decoder = Decoder(hparams)
+        self.postnet = Postnet(hparams)
+        self.__dict__["_engine"] = None
+
+    def _eng(self):
+        if self.__dict__.get("_engine") is None:
+            self.__dict__["_engine"] = _TacoEngine(self)
+        return self.__dict__["_engine"]
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_engine"] = None
+        return d
+
+    def _check(self, t):
+        if not t.is_cuda:
+            raise _lib.T2SError("Tacotron (MI355X build) needs CUDA/HIP tensors; got %s - there is no CPU fallback" % t.device)
+        if self.training:
+            raise NotImplementedError("training-mode Tacotron forward (BatchNorm batch statistics, dropout, backward) "
+                                      "is not built yet on the MI355X path; call .eval()")
+
+    def forward(self, inputs, prenet_masks=None):
+        """Teacher-forced forward (reference tacotron.py:36-49)."""
+        text_inputs, text_lengths, mels, max_len, speaker_id, output_lengths = inputs
+        self._check(text_inputs)
+        with torch.no_grad():
+            out = self._eng().forward(text_inputs, text_lengths.data, mels, output_lengths.data, prenet_masks)
+        return self.parse_output(out, output_lengths.data)
+
+    def inference(self, inputs, speaker_id=None, prenet_masks=None):
+        """Autoregressive decode (reference tacotron.py:51-65)."""
+        self._check(inputs)
+        with torch.no_grad():
+            out = self._eng().inference(inputs, prenet_masks)
+        return self.parse_output(out)
+
+    def parse_output(self, outputs, output_lengths=None):
+        """Reference tacotron.py:67-76: zero mel / 1e3 gate beyond each output length."""
+        if self.hparams["mask_padding"] and output_lengths is not None:
+            mask = ~get_mask_from_lengths(output_lengths.to(outputs[0].device))
+            T = outputs[0].size(2)
+            if mask.size(1) < T:
+                mask = torch.cat([mask, mask.new_ones(mask.size(0), T - mask.size(1))], 1)
+            outputs[0].masked_fill_(mask.unsqueeze(1), 0.0)
+            outputs[1].masked_fill_(mask.unsqueeze(1), 0.0)
+            outputs[2].masked_fill_(mask, 1e3)
+        return outputs
+
+    def parse_batch(self, batch):
+        """Reference tacotron.py:78-89."""
+        text_padded, input_lengths, mel_padded, gate_padded, speaker_id, output_lengths = batch
+        dev = self.embedding.weight.device
+        text_padded = text_padded.to(dev).long()
+        input_lengths = input_lengths.to(dev).long()
+        max_len = torch.max(input_lengths.data).item()
+        mel_padded = mel_padded.to(dev).float()
+        gate_padded = gate_padded.to(dev).float()
+        speaker_id = speaker_id.to(dev).float()
+        output_lengths = output_lengths.to(dev).long()
+        return ((text_padded, input_lengths, mel_padded, max_len, speaker_id, output_lengths),
+                (mel_padded, gate_padded))
