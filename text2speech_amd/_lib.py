@@ -21,6 +21,7 @@ SIGNATURES = {
     "t2s_padded_rows": [c_int],
     "t2s_pack_conv_weight": [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                              c_vp, c_vp, c_vp, c_int, c_vp],
+    "t2s_pack_conv_weight_table": [c_vp, c_int, c_long, c_vp],
     "t2s_weightnorm_small": [c_vp, c_vp, c_int, c_int, c_vp, c_vp],
     "t2s_wg_upsample_squeeze": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_vp, c_vp, c_vp],

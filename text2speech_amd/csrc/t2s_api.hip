@@ -61,6 +61,13 @@ int t2s_pack_conv_weight(const float* v, const float* g, int g_is_scale, const f
     return T2S_OK;
 }
 
+int t2s_pack_conv_weight_table(const t2s_pack_job* jobs, int n_jobs, long total_rows, void* stream) {
+    if (!jobs || n_jobs <= 0 || total_rows <= 0 || total_rows > 0x7fffffffL) return T2S_EINVAL;
+    static_assert(sizeof(t2s_pack_job) == sizeof(PackJob), "t2s_pack_job layout");
+    T2S_CHECK_HIP(t2s_launch_pack_table((const PackJob*)jobs, n_jobs, total_rows, (hipStream_t)stream));
+    return T2S_OK;
+}
+
 int t2s_weightnorm_small(const float* v, const float* g, int O, int K, float* w, void* stream) {
     if (!v || !w || O <= 0 || K <= 0) return T2S_EINVAL;
     T2S_CHECK_HIP(t2s_launch_weightnorm_small(v, g, O, K, w, (hipStream_t)stream));

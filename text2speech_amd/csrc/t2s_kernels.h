@@ -53,6 +53,14 @@ struct PackArgs {
     int g_is_scale;        // 1: g[o] is a plain per-row scale (BatchNorm fold), 0: weight-norm gain
 };
 hipError_t t2s_launch_pack(const PackArgs& a, hipStream_t stream);
+// table-driven: one launch packs every weight of the model; jobs live in device memory
+struct PackJob {               // mirrors t2s_pack_job in include/t2s_hip.h (all 8-byte fields)
+    const float* v; const float* g; const float* bias_in; const float* bias_in2;
+    u16* A_hi; u16* A_lo; float* bias_out;
+    long row_start;            // first block index of this job (prefix sum of O)
+    long O, Cin, Kt, perm, C_gate, Mpad, koff, Cin_pad, row_off, g_is_scale;
+};
+hipError_t t2s_launch_pack_table(const PackJob* jobs, int n_jobs, long total_rows, hipStream_t stream);
 hipError_t t2s_launch_weightnorm_small(const float* v, const float* g, int O, int K, float* w, hipStream_t stream);
 
 hipError_t t2s_launch_upsample_squeeze(const float* mel, const float* W, const float* bias, int B, int n_mel,

@@ -10,16 +10,17 @@
 // effective weight into the GEMM's A operand: split to (hi, lo) bf16, K reordered tap-major, rows
 // permuted so that a wave owns the tanh row and the sigmoid row of the same channel.
 // One workgroup per output row.
-__global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
+static __device__ __forceinline__ void pack_row(const float* __restrict__ vrow, const float* g, int g_is_scale, int o,
+                                                 int Cin, int Kt, int perm, int C_gate, int row_off, int Mpad, int koff,
+                                                 int Cin_pad, u16* A_hi, u16* A_lo, const float* bias_in,
+                                                 const float* bias_in2, float* bias_out, int bias_accumulate) {
     __shared__ float red[4];
-    const int o = blockIdx.x;
     const int tid = threadIdx.x;
-    const int n = a.Cin * a.Kt;
-    const float* vrow = a.v + (size_t)o * n;
+    const int n = Cin * Kt;
     float scale = 1.0f;
-    if (a.g && a.g_is_scale) {
-        scale = a.g[o];
-    } else if (a.g) {
+    if (g && g_is_scale) {
+        scale = g[o];
+    } else if (g) {
         float ss = 0.f;
         for (int i = tid; i < n; i += 256) {
             const float x = vrow[i];
@@ -29,31 +30,60 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
         if ((tid & 63) == 0) red[tid >> 6] = ss;
         __syncthreads();
         ss = red[0] + red[1] + red[2] + red[3];
-        scale = a.g[o] / sqrtf(ss);
+        scale = g[o] / sqrtf(ss);
     }
     int p;
-    if (a.perm == PERM_GATE) {
-        const int gate = o >= a.C_gate;
-        const int ch = gate ? o - a.C_gate : o;
+    if (perm == PERM_GATE) {
+        const int gate = o >= C_gate;
+        const int ch = gate ? o - C_gate : o;
         p = (ch >> 7) * 256 + ((ch >> 6) & 1) * 128 + (((ch >> 4) & 3) * 2 + gate) * 16 + (ch & 15);
     } else {
-        p = o + a.row_off;
+        p = o + row_off;
     }
-    for (int i = tid; i < n; i += 256) {
-        const int tap = i / a.Cin;
-        const int c = i - tap * a.Cin;
-        const float w = vrow[c * a.Kt + tap] * scale;
-        const int k = a.koff + tap * a.Cin_pad + c;
-        const size_t idx = ((size_t)(k >> 5) * a.Mpad + p) * 32 + (k & 31);
-        u16 h, l;
-        split_bf16(w, h, l);
-        a.A_hi[idx] = h;
-        a.A_lo[idx] = l;
+    // two consecutive channels per thread -> one 4-byte store per plane
+    const int half = (Cin + 1) >> 1;
+    for (int i = tid; i < half * Kt; i += 256) {
+        const int tap = i / half;
+        const int c = (i - tap * half) * 2;
+        const float w0 = vrow[c * Kt + tap] * scale;
+        const float w1 = (c + 1 < Cin) ? vrow[(c + 1) * Kt + tap] * scale : 0.f;
+        const int k = koff + tap * Cin_pad + c;
+        const size_t idx = ((size_t)(k >> 5) * Mpad + p) * 32 + (k & 31);
+        u16 h0, l0, h1, l1;
+        split_bf16(w0, h0, l0);
+        split_bf16(w1, h1, l1);
+        *(uint32_t*)(A_hi + idx) = h0 | ((uint32_t)h1 << 16);
+        *(uint32_t*)(A_lo + idx) = l0 | ((uint32_t)l1 << 16);
     }
-    if (tid == 0 && a.bias_out) {
-        const float bi = a.bias_in ? a.bias_in[o] : 0.f;
-        a.bias_out[p] = a.bias_accumulate ? a.bias_out[p] + bi : bi;
+    if (tid == 0 && bias_out) {
+        float bi = bias_in ? bias_in[o] : 0.f;
+        if (bias_in2) bi += bias_in2[o];
+        bias_out[p] = bias_accumulate ? bias_out[p] + bi : bi;
     }
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
+    const int o = blockIdx.x;
+    pack_row(a.v + (size_t)o * a.Cin * a.Kt, a.g, a.g_is_scale, o, a.Cin, a.Kt, a.perm, a.C_gate, a.row_off, a.Mpad,
+             a.koff, a.Cin_pad, a.A_hi, a.A_lo, a.bias_in, nullptr, a.bias_out, a.bias_accumulate);
+}
+
+// One launch for the whole model: block -> (job, row) by binary search over the jobs' row_start prefix.
+__global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restrict__ jobs, int n_jobs) {
+    const long blk = blockIdx.x;
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].row_start <= blk) lo = mid; else hi = mid - 1;
+    }
+    const PackJob j = jobs[lo];
+    const int o = (int)(blk - j.row_start);
+    pack_row(j.v + (size_t)o * j.Cin * j.Kt, j.g, (int)j.g_is_scale, o, (int)j.Cin, (int)j.Kt, (int)j.perm, (int)j.C_gate,
+             (int)j.row_off, (int)j.Mpad, (int)j.koff, (int)j.Cin_pad, j.A_hi, j.A_lo, j.bias_in, j.bias_in2, j.bias_out, 0);
+}
+hipError_t t2s_launch_pack_table(const PackJob* jobs, int n_jobs, long total_rows, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_table_kernel, dim3((unsigned)total_rows), dim3(256), 0, stream, jobs, n_jobs);
+    return hipGetLastError();
 }
 
 hipError_t t2s_launch_pack(const PackArgs& a, hipStream_t stream) {

@@ -147,7 +147,41 @@ class _Engine:
                                   w_start=torch.empty(C, n_half, dtype=torch.float32, device=device),
                                   w_inv=None))
             self.packed = dict(flows=flows, device=device)
-        keep = []   # keep f32 staging copies alive until the kernels have been enqueued
+        # One table-driven launch packs all 3 * n_layers * n_flows convolutions (weight-norm + split + permute).
+        srcs = []       # f32 source tensors, in job order; their data_ptrs key the cached job table
+        specs = []
+        for k in range(m.n_flows):
+            wn = m.WN[k]
+            fl = self.packed["flows"][k]
+            for i in range(nl):
+                ly = fl["layers"][i]
+                v, gg = _vg(wn.in_layers[i])
+                vc, gc = _vg(wn.cond_layers[i])
+                vr, gr = _vg(wn.res_skip_layers[i])
+                t = [_f32c(v), None if gg is None else _f32c(gg), _f32c(wn.in_layers[i].bias), _f32c(wn.cond_layers[i].bias),
+                     _f32c(vc), None if gc is None else _f32c(gc),
+                     _f32c(vr), None if gr is None else _f32c(gr), _f32c(wn.res_skip_layers[i].bias)]
+                srcs += t
+                # (v, g, bias, bias2, A_hi, A_lo, bias_out, O, Cin, Kt, perm, C_gate, Mpad, koff, Cin_pad)
+                specs.append((t[0], t[1], t[2], t[3], ly["A1h"], ly["A1l"], ly["b1"], 2 * C, C, ks, 1, C, g["Mpad1"], 0, g["Cpad"]))
+                specs.append((t[4], t[5], None, None, ly["A1h"], ly["A1l"], None, 2 * C, g["n_cond"], 1, 1, C, g["Mpad1"],
+                              ks * g["Cpad"], g["Spad"]))
+                specs.append((t[6], t[7], t[8], None, ly["A2h"], ly["A2l"], ly["b2"], t[6].size(0), C, 1, 0, 0, ly["Mpad2"], 0,
+                              g["Cpad"]))
+        ptr_key = tuple(0 if t is None else t.data_ptr() for t in srcs)
+        if self.packed.get("job_key") != ptr_key:
+            rows, row_start = [], 0
+            dp = lambda t: 0 if t is None else t.data_ptr()
+            for (v, gg, b1, b2, Ah, Al, bo, O, Cin, Kt, perm, Cg, Mpad, koff, Cin_pad) in specs:
+                rows.append([dp(v), dp(gg), dp(b1), dp(b2), dp(Ah), dp(Al), dp(bo), row_start,
+                             O, Cin, Kt, perm, Cg, Mpad, koff, Cin_pad, 0, 0])
+                row_start += O
+            self.packed["jobs"] = torch.tensor(rows, dtype=torch.int64).to(device)
+            self.packed["n_jobs"], self.packed["total_rows"] = len(rows), row_start
+            self.packed["job_key"] = ptr_key
+        _lib.call("t2s_pack_conv_weight_table", _lib.ptr(self.packed["jobs"]), self.packed["n_jobs"],
+                  self.packed["total_rows"], st)
+        keep = srcs
         for k in range(m.n_flows):
             wn = m.WN[k]
             fl = self.packed["flows"][k]
@@ -155,27 +189,6 @@ class _Engine:
             v, gg = _f32c(v), (None if gg is None else _f32c(gg))
             keep += [v, gg]
             _lib.call("t2s_weightnorm_small", _lib.ptr(v), _lib.ptr(gg), C, fl["n_half"], _lib.ptr(fl["w_start"]), st)
-            for i in range(nl):
-                ly = fl["layers"][i]
-                v, gg = _vg(wn.in_layers[i])
-                v, gg, bb = _f32c(v), (None if gg is None else _f32c(gg)), _f32c(wn.in_layers[i].bias)
-                keep += [v, gg, bb]
-                _lib.call("t2s_pack_conv_weight", _lib.ptr(v), _lib.ptr(gg), 0, _lib.ptr(bb), 2 * C, C, ks,
-                          1, C, 0, g["Mpad1"], 0, g["Cpad"], _lib.ptr(ly["A1h"]), _lib.ptr(ly["A1l"]),
-                          _lib.ptr(ly["b1"]), 0, st)
-                v, gg = _vg(wn.cond_layers[i])
-                v, gg, bb = _f32c(v), (None if gg is None else _f32c(gg)), _f32c(wn.cond_layers[i].bias)
-                keep += [v, gg, bb]
-                _lib.call("t2s_pack_conv_weight", _lib.ptr(v), _lib.ptr(gg), 0, _lib.ptr(bb), 2 * C, g["n_cond"], 1,
-                          1, C, 0, g["Mpad1"], ks * g["Cpad"], g["Spad"], _lib.ptr(ly["A1h"]), _lib.ptr(ly["A1l"]),
-                          _lib.ptr(ly["b1"]), 1, st)
-                v, gg = _vg(wn.res_skip_layers[i])
-                v, gg, bb = _f32c(v), (None if gg is None else _f32c(gg)), _f32c(wn.res_skip_layers[i].bias)
-                keep += [v, gg, bb]
-                rows2 = v.size(0)
-                _lib.call("t2s_pack_conv_weight", _lib.ptr(v), _lib.ptr(gg), 0, _lib.ptr(bb), rows2, C, 1,
-                          0, 0, 0, ly["Mpad2"], 0, g["Cpad"], _lib.ptr(ly["A2h"]), _lib.ptr(ly["A2l"]),
-                          _lib.ptr(ly["b2"]), 0, st)
             fl["w_inv"] = None
         self.packed_key = key
         self._keep = keep
