@@ -114,62 +114,90 @@ hipError_t t2s_launch_gemv(const GemvArgs& a, hipStream_t stream) {
 // One wave per hidden unit u keeps rows {u, H+u, 2H+u, 3H+u} of [W_ih | W_hh] in registers and loops
 // over the batch; lane (b mod 64) then does the pointwise update for item b.  h is ping-ponged by the
 // caller (h_in read by every workgroup, h_out written by the owner), c is updated in place.
-template <int NV4>
-__global__ __launch_bounds__(256) void lstm_cell_kernel(const LstmCellArgs a) {
+// Work split: a workgroup owns 4 hidden units; each unit's K range is split over 4 waves (16 waves per
+// workgroup, so every CU has 16 waves streaming weights instead of 4 - the cell is latency-bound at B=1).
+// Wave (unit, kq) keeps float4 slots v = kq, kq+4, ... of its four gate rows in registers; partial sums
+// meet in LDS and thread (unit, item) applies the cell update.
+template <int NVW>
+__global__ __launch_bounds__(1024) void lstm_cell_kernel(const LstmCellArgs a) {
+    __shared__ float s_part[4][4][4][64];            // [unit][kq][gate][item]
     const int lane = threadIdx.x & 63;
-    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (u >= a.H) return;
-    f32x4 w[4][NV4];
-    float bias[4];
+    const int wave = threadIdx.x >> 6;
+    const int ul = wave >> 2, kq = wave & 3;
+    const int u = blockIdx.x * 4 + ul;               // H % 4 == 0 is checked by the caller
+    const int K1 = a.n1 + a.n2, K = K1 + a.H;
+    f32x4 w[4][NVW];
+    const float* xp[NVW];
+    long xs[NVW];
+    bool valid[NVW];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        load_row<NV4>(w[g], a.W_ih, a.n1 + a.n2, a.n1 + a.n2, a.W_hh, a.H, a.H, g * a.H + u, lane);
-        bias[g] = a.b_ih[g * a.H + u] + a.b_hh[g * a.H + u];
+    for (int j = 0; j < NVW; ++j) {
+        const int v = kq + 4 * j;
+        int k = (v * 64 + lane) * 4;
+        valid[j] = k < K;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const size_t row = (size_t)g * a.H + u;
+            if (!valid[j]) w[g][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            else if (k < K1) w[g][j] = *(const f32x4*)(a.W_ih + row * K1 + k);
+            else w[g][j] = *(const f32x4*)(a.W_hh + row * a.H + (k - K1));
+        }
+        if (!valid[j]) { xp[j] = a.x1; xs[j] = 0; }
+        else if (k < a.n1) { xp[j] = a.x1 + k; xs[j] = a.sx1; }
+        else if (k < K1) { xp[j] = a.x2 + (k - a.n1); xs[j] = a.sx2; }
+        else { xp[j] = a.h_in + (k - K1); xs[j] = a.H; }
     }
-    XSeg s = {{a.x1, a.x2, a.h_in}, {a.n1, a.n2, a.H}, {a.sx1, a.sx2, (long)a.H}};
-    LaneMap<NV4> lm;
-    lm.init(s, lane);
     for (int b0 = 0; b0 < a.B; b0 += 64) {
-        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f;
         const int bn = min(64, a.B - b0);
         for (int bb = 0; bb < bn; ++bb) {
             const int it = b0 + bb;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int v = 0; v < NV4; ++v) {
-                if (lm.valid[v]) {
-                    const f32x4 x = *(const f32x4*)(lm.xp[v] + (size_t)it * lm.xs[v]);
+            for (int j = 0; j < NVW; ++j) {
+                if (valid[j]) {
+                    const f32x4 x = *(const f32x4*)(xp[j] + (size_t)it * xs[j]);
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        acc[g] += w[g][v][0] * x[0] + w[g][v][1] * x[1] + w[g][v][2] * x[2] + w[g][v][3] * x[3];
+                        acc[g] += w[g][j][0] * x[0] + w[g][j][1] * x[1] + w[g][j][2] * x[2] + w[g][j][3] * x[3];
                 }
             }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g] = wave_sum(acc[g]);
-            if (lane == bb) { gi = acc[0]; gf = acc[1]; gg = acc[2]; go = acc[3]; }
+            for (int g = 0; g < 4; ++g) {
+                const float sum = wave_sum(acc[g]);
+                if (lane == 0) s_part[ul][kq][g][bb] = sum;
+            }
         }
-        if (lane < bn) {
+        __syncthreads();
+        if (kq == 0 && lane < bn) {
             const int it = b0 + lane;
+            float gsum[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                gsum[g] = (s_part[ul][0][g][lane] + s_part[ul][1][g][lane]) + (s_part[ul][2][g][lane] + s_part[ul][3][g][lane]) +
+                          (a.b_ih[g * a.H + u] + a.b_hh[g * a.H + u]);
             const size_t idx = (size_t)it * a.H + u;
             const float c = a.c[idx];
-            const float c2 = sigmoid_acc(gf + bias[1]) * c + sigmoid_acc(gi + bias[0]) * tanhf(gg + bias[2]);
-            float h2 = sigmoid_acc(go + bias[3]) * tanhf(c2);
+            const float c2 = sigmoid_acc(gsum[1]) * c + sigmoid_acc(gsum[0]) * tanhf(gsum[2]);
+            float h2 = sigmoid_acc(gsum[3]) * tanhf(c2);
             a.c[idx] = c2;
             if (a.drop_mask) h2 = a.drop_mask[idx] ? h2 * a.drop_scale : 0.f;
             a.h_out[idx] = h2;
             if (a.h_copy) a.h_copy[(size_t)it * a.s_copy + u] = h2;
         }
+        __syncthreads();
     }
 }
 
 hipError_t t2s_launch_lstm_cell(const LstmCellArgs& a, hipStream_t stream) {
     const int K = a.n1 + a.n2 + a.H;
     const int nv4 = (K + 255) / 256;
-    dim3 grid((a.H + 3) / 4);
-#define LL(N) hipLaunchKernelGGL(lstm_cell_kernel<N>, grid, dim3(256), 0, stream, a)
-    if (nv4 <= 4) LL(4);
-    else if (nv4 <= 7) LL(7);
-    else if (nv4 <= 10) LL(10);
+    const int nvw = (nv4 + 3) / 4;
+    if (a.H % 4) return hipErrorInvalidValue;
+    dim3 grid(a.H / 4);
+#define LL(N) hipLaunchKernelGGL(lstm_cell_kernel<N>, grid, dim3(1024), 0, stream, a)
+    if (nvw <= 1) LL(1);
+    else if (nvw <= 2) LL(2);
+    else if (nvw <= 3) LL(3);
     else return hipErrorInvalidValue;
 #undef LL
     return hipGetLastError();
