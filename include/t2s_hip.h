@@ -106,9 +106,9 @@ int t2s_wg_res_skip(const void* A_hi, const void* A_lo, const float* bias, const
                     int halo, int Mpad, void* stream);
 
 /* WN.end + affine coupling on channels [c_off+n_half, c_off+2*n_half) of z; writes log_s[B][n_half][L]
- * if non-NULL (reference glow.py:175,241-246; reverse=1: glow.py:276-280) */
-int t2s_wg_end_affine(const float* skip, const float* w_end, const float* b_end, float* z, float* log_s, int B,
-                      int n_group, int c_off, int n_half, int C, int L, int Lp, int halo, int reverse, void* stream);
+ * and wn_out[B][2*n_half][L] = (b ; log_s) if non-NULL (reference glow.py:175,241-246; reverse=1: glow.py:276-280) */
+int t2s_wg_end_affine(const float* skip, const float* w_end, const float* b_end, float* z, float* log_s,
+                      float* wn_out, int B, int n_group, int c_off, int n_half, int C, int L, int Lp, int halo, int reverse, void* stream);
 
 /* Generic split-bf16 conv1d-as-GEMM with bias + activation epilogue:
  *   out[b][o][t] = act(bias[o] + sum_{tap,c} W[o][c][tap] * x[b][c][t + (tap - taps/2)*dil])
@@ -185,6 +185,81 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
 /* stop_step[b] = first step in [step0, step0+n) with sigmoid(gate) > threshold, if still -1 (tacotron.py:455) */
 int t2s_taco_stop_check(const float* mel_gate_out, int B, int n_mel, int T_cap, int step0, int n, float threshold,
                         int* stop_step, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * WaveGlow training step (reference waveglow/train.py:110-124: forward -> WaveGlowLoss -> backward -> Adam;
+ * the reference gets its backward from autograd over glow.py:207-249, these are the hand-written equivalents).
+ * "time-major planes": tm[b][t/32][row][t%32] bf16 (hi, lo) - the operands of the weight-gradient GEMMs,
+ * whose contraction index is time.
+ */
+
+/* training-mode forms of the two WN-layer entry points: also save tanh / sigmoid (T, G planes) for the
+ * backward pass, and read the residual from R planes so every layer's input stays resident */
+int t2s_wg_in_cond_gate_train(const void* A_hi, const void* A_lo, const float* bias, const void* X_hi, const void* X_lo,
+                              const void* S_hi, const void* S_lo, void* acts_hi, void* acts_lo, void* T_hi, void* T_lo,
+                              void* G_hi, void* G_lo, int B, int C, int n_cond, int taps, int dilation, int L, int Lp,
+                              int halo, int Mpad, void* stream);
+int t2s_wg_res_skip_train(const void* A_hi, const void* A_lo, const float* bias, const void* acts_hi,
+                          const void* acts_lo, const void* R_hi, const void* R_lo, void* X_hi, void* X_lo, float* skip,
+                          int B, int C, int n_res, int skip_init, int L, int Lp, int halo, int Mpad, void* stream);
+
+/* d_pre = gate'(T, G) * (W_rs^T [d_x ; d_skip]):  data gradient of res_skip_layers[i] fused with the backward of
+ * tanh*sigmoid (glow.py:33-40,164).  A = t2s_pack_transposed(W_rs); DX may be NULL (last layer: skip rows only).
+ * DP planes have 2C channels (tanh half, then sigmoid half). */
+int t2s_wg_bwd_gate_dgrad(const void* A_hi, const void* A_lo, const float* zero_bias, const void* DX_hi,
+                          const void* DX_lo, const void* DS_hi, const void* DS_lo, const void* T_hi, const void* T_lo,
+                          const void* G_hi, const void* G_lo, void* DP_hi, void* DP_lo, int B, int C, int L, int Lp,
+                          int halo, int Mpad, void* stream);
+
+/* O (+)= conv(X) with packed (transposed) weights: data gradients of in_layers[i] (dilated, taps mirrored) and
+ * cond_layers[i].  init=1 stores, init=0 accumulates into the O planes. */
+int t2s_conv_accumulate(const void* A_hi, const void* A_lo, const float* zero_bias, const void* X_hi, const void* X_lo,
+                        void* O_hi, void* O_lo, int B, int Cin, int Cout, int taps, int dilation, int init, int L, int Lp,
+                        int halo, int Mpad, void* stream);
+
+/* out[b][m][n] = sum_t A_tm[b][t][m] * X_tm[b][t][n]  (one split-K slab per batch entry b) */
+int t2s_wgrad_gemm(const void* A_hi, const void* A_lo, const void* X_hi, const void* X_lo, const float* zero_bias,
+                   float* out, int B, int M, int N, int Mpad, int Npad, int n_tchunks, void* stream);
+
+int t2s_plane_transpose(const void* src_hi, const void* src_lo, int B, int src_chunks, int n_chunks, int Lp, int shift,
+                        void* dst_hi, void* dst_lo, int Npad, int n_off, void* stream);
+int t2s_tm_ones_row(void* dst_hi, void* dst_lo, int B, int Lp, int halo, int L, int Npad, int n_row, void* stream);
+/* A[c][koff + tap'*O_pad + o] = scale[o] * v[o][c][flip ? Kt-1-tap' : tap'] -> (hi, lo) [k/32][Mpad][32] */
+int t2s_pack_transposed(const float* v, const float* scale, int O, int Cin, int Kt, int flip, int O_pad, int Mpad,
+                        int koff, void* A_hi, void* A_lo, void* stream);
+/* per-row scale g/|v| of a weight-normed conv (what the forward pack applied), for t2s_pack_transposed */
+int t2s_weightnorm_scale(const float* v, const float* g, int O, int K, float* scale, void* stream);
+/* reduce split-K slabs P[nsplit][Prows][Pcols] and apply weight_norm's backward (g NULL: plain weight) */
+int t2s_wn_backward(const float* P, int nsplit, int Prows, int Pcols, int row_off, int col_off, int tap_stride,
+                    int col_bias, const float* v, const float* g, int O, int Cin, int Kt, float* dv, float* dg,
+                    float* db, int db_accum, void* stream);
+/* affine coupling backward + un-apply (glow.py:241-246); wn_out = (b ; log_s) [B][2nh][L], d_out gets (d_b ; d_log_s) */
+int t2s_wg_affine_backward(float* z, float* dz, const float* wn_out, const float* g_log_s, float* d_out, int B,
+                           int n_group, int c_off, int n_half, int L, void* stream);
+/* out[r][j] (or [j][r]) = sum_{b,t} P[b][r][t] * Q[b][q_off+j][t], rowsum[r] = sum P; P = planes (hi/lo, or f32) */
+int t2s_small_wgrad(const void* P_hi, const void* P_lo, const float* P_f32, const float* Q, float* out, float* rowsum,
+                    int B, int chunks, int Lp, int halo, int L, int R, int J, int Jtot, int q_off, int out_transposed,
+                    void* stream);
+int t2s_rows_sum(const float* Q, int B, int Jtot, int q_off, int J, int L, float* out, void* stream);
+/* d_z[:, c_off:c_off+n_half] += W_start^T d_x */
+int t2s_wg_start_dgrad(const void* X_hi, const void* X_lo, const float* w, float* dz, int B, int n_group, int c_off,
+                       int n_half, int C, int L, int Lp, int halo, void* stream);
+/* dW = d_out . z_in^T + (*gscale_ptr * gmul) * W^-T   (glow.py:100-101) */
+int t2s_wg_convinv_wgrad(const float* dz, const float* zin, const float* Winv, const float* gscale_ptr, float gmul,
+                         int B, int n_group, int c_off, int n, int L, float* dW, void* stream);
+/* ConvTranspose1d weight / bias gradient from the conditioning-plane gradient (glow.py:215-221) */
+int t2s_wg_upsample_wgrad(const void* D_hi, const void* D_lo, const float* mel, int B, int n_mel, int frames, int ksize,
+                          int stride, int n_group, int L, int Lp, int halo, float* dW, float* db, void* stream);
+
+/* Adam over every parameter in one launch (torch.optim.Adam semantics; waveglow/train.py:79,124).  `jobs` is a
+ * DEVICE array; job i owns blocks [blk_start, blk_start + ceil(n/1024)).  gscale multiplies the gradient first. */
+typedef struct t2s_adam_job {
+    float* p; const float* g; float* m; float* v;
+    long n;
+    long blk_start;
+} t2s_adam_job;
+int t2s_adam_table(const t2s_adam_job* jobs, int n_jobs, long total_blocks, float lr, float beta1, float beta2,
+                   float eps, int step, float gscale, float weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

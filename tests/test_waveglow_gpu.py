@@ -189,14 +189,14 @@ def test_small_stages(lib):
     z_before = z.clone()
     log_s = torch.empty(B, nh, L, device=DEV)
     we_d, be_d = d(we), d(be)
-    _lib.call("t2s_wg_end_affine", _lib.ptr(skip), _lib.ptr(we_d), _lib.ptr(be_d), _lib.ptr(z), _lib.ptr(log_s), B, G,
+    _lib.call("t2s_wg_end_affine", _lib.ptr(skip), _lib.ptr(we_d), _lib.ptr(be_d), _lib.ptr(z), _lib.ptr(log_s), None, B, G,
               2, nh, C, L, Lp, halo, 0, st)
     torch.cuda.synchronize()
     want_a1 = torch.exp(o[:, nh:]) * z_before[:, 5:8].double().cpu() + o[:, :nh]
     assert _rel(log_s, o[:, nh:]) < 1e-5
     assert _rel(z[:, 5:8], want_a1) < 1e-5
     assert torch.equal(z[:, :5], z_before[:, :5])
-    _lib.call("t2s_wg_end_affine", _lib.ptr(skip), _lib.ptr(we_d), _lib.ptr(be_d), _lib.ptr(z), None, B, G, 2, nh, C,
+    _lib.call("t2s_wg_end_affine", _lib.ptr(skip), _lib.ptr(we_d), _lib.ptr(be_d), _lib.ptr(z), None, None, B, G, 2, nh, C,
               L, Lp, halo, 1, st)
     torch.cuda.synchronize()
     assert _rel(z, z_before) < 1e-5

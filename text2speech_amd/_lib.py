@@ -33,7 +33,7 @@ SIGNATURES = {
                             c_int, c_int, c_int, c_int, c_vp],
     "t2s_wg_res_skip": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int,
                         c_int, c_int, c_vp],
-    "t2s_wg_end_affine": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+    "t2s_wg_end_affine": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                           c_int, c_vp],
     "t2s_conv_bias_act": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                           c_int, c_int, c_int, c_int, c_vp],
@@ -47,6 +47,26 @@ SIGNATURES = {
     "t2s_bernoulli_mask": [c_vp, ctypes.c_size_t, ctypes.c_ulonglong, ctypes.c_ulonglong, c_vp],
     "t2s_taco_decode_steps": [c_vp, c_int, c_int, c_vp],
     "t2s_taco_stop_check": [c_vp, c_int, c_int, c_int, c_int, c_int, c_float, c_vp, c_vp],
+    "t2s_wg_in_cond_gate_train": [c_vp] * 13 + [c_int] * 9 + [c_vp],
+    "t2s_wg_res_skip_train": [c_vp] * 10 + [c_int] * 8 + [c_vp],
+    "t2s_wg_bwd_gate_dgrad": [c_vp] * 13 + [c_int] * 6 + [c_vp],
+    "t2s_conv_accumulate": [c_vp] * 7 + [c_int] * 10 + [c_vp],
+    "t2s_wgrad_gemm": [c_vp] * 6 + [c_int] * 6 + [c_vp],
+    "t2s_plane_transpose": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp],
+    "t2s_tm_ones_row": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
+    "t2s_pack_transposed": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
+    "t2s_weightnorm_scale": [c_vp, c_vp, c_int, c_int, c_vp, c_vp],
+    "t2s_wn_backward": [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp,
+                        c_vp, c_int, c_vp],
+    "t2s_wg_affine_backward": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
+    "t2s_small_wgrad": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                        c_int, c_vp],
+    "t2s_rows_sum": [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp],
+    "t2s_wg_start_dgrad": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
+    "t2s_wg_convinv_wgrad": [c_vp, c_vp, c_vp, c_vp, c_float, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp],
+    "t2s_wg_upsample_wgrad": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp,
+                              c_vp],
+    "t2s_adam_table": [c_vp, c_int, c_long, c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_vp],
 }
 _RESTYPE = {"t2s_error_string": ctypes.c_char_p, "t2s_last_hip_error": ctypes.c_char_p}
 

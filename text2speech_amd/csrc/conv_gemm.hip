@@ -67,8 +67,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     // LDS linear slot p = j*512 + tid (16 B each): row = p>>2 = j*128 + (tid>>2), slot q = tid&3.
     // The slot holds logical k-chunk q ^ s[(row>>2)&3]; (row>>2)&3 == (tid>>4)&3 for both j.
     const int thr_off = (tid >> 2) * 64 + (((tid & 3) ^ swz4((tid >> 4) & 3)) * 16);
-    const char* A_hi = (const char*)a.A_hi + (size_t)mt * T2S_TILE_M * 64 + thr_off;
-    const char* A_lo = (const char*)a.A_lo + (size_t)mt * T2S_TILE_M * 64 + thr_off;
+    const char* A_hi = (const char*)a.A_hi + (size_t)b * a.a_bstride * 2 + (size_t)mt * T2S_TILE_M * 64 + thr_off;
+    const char* A_lo = (const char*)a.A_lo + (size_t)b * a.a_bstride * 2 + (size_t)mt * T2S_TILE_M * 64 + thr_off;
     const size_t a_kstride = (size_t)a.Mpad * 64;
     const size_t x_cstride = (size_t)a.Lp * 64;            // bytes per 32-channel chunk
     const char* X_hi = (const char*)a.X_hi + ((size_t)b * a.xc * a.Lp + a.halo + t0) * 64 + thr_off;
@@ -162,17 +162,31 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
             for (int n = 0; n < 4; ++n) {
                 const int t = t0 + wc * 64 + n * 16 + tcol;
                 if (t >= a.L) continue;
-                u16x4 hi, lo;
+                u16x4 hi, lo, thi, tlo, ghi, glo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float g = fast_tanh(acc[2 * mp][n][e] + bt[e]) * fast_sigmoid(acc[2 * mp + 1][n][e] + bs[e]);
+                    const float tv = fast_tanh(acc[2 * mp][n][e] + bt[e]);
+                    const float gv = fast_sigmoid(acc[2 * mp + 1][n][e] + bs[e]);
                     u16 h, l;
-                    split_bf16(g, h, l);
+                    split_bf16(tv * gv, h, l);
                     hi[e] = h;
                     lo[e] = l;
+                    split_bf16(tv, h, l);
+                    thi[e] = h;
+                    tlo[e] = l;
+                    split_bf16(gv, h, l);
+                    ghi[e] = h;
+                    glo[e] = l;
                 }
                 *(u16x4*)(ohi + (size_t)t * 32) = hi;
                 *(u16x4*)(olo + (size_t)t * 32) = lo;
+                if (a.T_hi) {      // training: keep tanh / sigmoid for the backward pass
+                    const size_t o = (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo + t) * 32 + (ch & 31);
+                    *(u16x4*)(a.T_hi + o) = thi;
+                    *(u16x4*)(a.T_lo + o) = tlo;
+                    *(u16x4*)(a.G_hi + o) = ghi;
+                    *(u16x4*)(a.G_lo + o) = glo;
+                }
             }
         }
     } else if (EPI == EPI_RESSKIP) {
@@ -188,8 +202,12 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
                 for (int n = 0; n < 4; ++n) {
                     const int t = t0 + wc * 64 + n * 16 + tcol;
                     if (t >= a.L) continue;
-                    const u16x4 oh = *(const u16x4*)(xhi + (size_t)t * 32);
-                    const u16x4 ol = *(const u16x4*)(xlo + (size_t)t * 32);
+                    u16x4 oh = {0, 0, 0, 0}, ol = {0, 0, 0, 0};
+                    if (!a.res_init) {
+                        const size_t ro = (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo + t) * 32 + (ch & 31);
+                        oh = *(const u16x4*)((a.R_hi ? a.R_hi : a.O_hi) + ro);
+                        ol = *(const u16x4*)((a.R_lo ? a.R_lo : a.O_lo) + ro);
+                    }
                     u16x4 hi, lo;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -214,6 +232,45 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
                     if (!a.skip_init) v += *(const f32x4*)(sk + (size_t)t * 32);
                     *(f32x4*)(sk + (size_t)t * 32) = v;
                 }
+            }
+        }
+    } else if (EPI == EPI_GATE_BWD) {
+        // acc = d_acts[c][t] (rows = acts channel c).  With the saved t = tanh(.), g = sigmoid(.):
+        //   d_pre[c]     = d_acts * g * (1 - t^2)        (tanh half)
+        //   d_pre[C + c] = d_acts * t * g * (1 - g)      (sigmoid half)     -> planes with 2C channels
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int ch = mt * T2S_TILE_M + wr * 128 + m * 16 + rq;
+            if (ch >= a.C) continue;
+            const int ch2 = ch + a.C;
+            const size_t tgb = (((size_t)b * a.tc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+            const size_t o1 = (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+            const size_t o2 = (((size_t)b * a.oc + (ch2 >> 5)) * a.Lp + a.halo) * 32 + (ch2 & 31);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int t = t0 + wc * 64 + n * 16 + tcol;
+                if (t >= a.L) continue;
+                const u16x4 th = *(const u16x4*)(a.T_hi + tgb + (size_t)t * 32);
+                const u16x4 tl = *(const u16x4*)(a.T_lo + tgb + (size_t)t * 32);
+                const u16x4 gh = *(const u16x4*)(a.G_hi + tgb + (size_t)t * 32);
+                const u16x4 gl = *(const u16x4*)(a.G_lo + tgb + (size_t)t * 32);
+                u16x4 h1, l1, h2, l2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float tv = join_bf16(th[e], tl[e]), gv = join_bf16(gh[e], gl[e]);
+                    const float da = acc[m][n][e];
+                    u16 h, l;
+                    split_bf16(da * gv * (1.0f - tv * tv), h, l);
+                    h1[e] = h;
+                    l1[e] = l;
+                    split_bf16(da * tv * gv * (1.0f - gv), h, l);
+                    h2[e] = h;
+                    l2[e] = l;
+                }
+                *(u16x4*)(a.O_hi + o1 + (size_t)t * 32) = h1;
+                *(u16x4*)(a.O_lo + o1 + (size_t)t * 32) = l1;
+                *(u16x4*)(a.O_hi + o2 + (size_t)t * 32) = h2;
+                *(u16x4*)(a.O_lo + o2 + (size_t)t * 32) = l2;
             }
         }
     } else {   // EPI_BIAS_ACT: out = act(acc + bias) -> planes (and optional f32 [B][C][L] copy)
@@ -269,6 +326,7 @@ static hipError_t launch(const ConvGemmArgs& a, int epi, hipStream_t stream) {
     } while (0)
     if (epi == EPI_GATE) T2S_LAUNCH(EPI_GATE);
     else if (epi == EPI_RESSKIP) T2S_LAUNCH(EPI_RESSKIP);
+    else if (epi == EPI_GATE_BWD) T2S_LAUNCH(EPI_GATE_BWD);
     else T2S_LAUNCH(EPI_BIAS_ACT);
 #undef T2S_LAUNCH
     return hipGetLastError();

@@ -165,12 +165,12 @@ int t2s_wg_res_skip(const void* A_hi, const void* A_lo, const float* bias, const
     return T2S_OK;
 }
 
-int t2s_wg_end_affine(const float* skip, const float* w_end, const float* b_end, float* z, float* log_s, int B,
-                      int n_group, int c_off, int n_half, int C, int L, int Lp, int halo, int reverse, void* stream) {
+int t2s_wg_end_affine(const float* skip, const float* w_end, const float* b_end, float* z, float* log_s,
+                      float* wn_out, int B, int n_group, int c_off, int n_half, int C, int L, int Lp, int halo, int reverse, void* stream) {
     if (!skip || !w_end || !b_end || !z) return T2S_EINVAL;
     if (B <= 0 || L <= 0 || C <= 0 || n_half <= 0 || n_half > 8 || c_off < 0 || c_off + 2 * n_half > n_group) return T2S_EINVAL;
     if (Lp < t2s_plane_rows(L, halo)) return T2S_EINVAL;
-    T2S_CHECK_HIP(t2s_launch_end_affine(skip, w_end, b_end, z, log_s, B, n_group, c_off, n_half, C, L, Lp, halo,
+    T2S_CHECK_HIP(t2s_launch_end_affine(skip, w_end, b_end, z, log_s, wn_out, B, n_group, c_off, n_half, C, L, Lp, halo,
                                         reverse, (hipStream_t)stream));
     return T2S_OK;
 }

@@ -5,7 +5,7 @@
 
 typedef unsigned short u16;
 
-enum { EPI_GATE = 0, EPI_RESSKIP = 1, EPI_BIAS_ACT = 2 };
+enum { EPI_GATE = 0, EPI_RESSKIP = 1, EPI_BIAS_ACT = 2, EPI_GATE_BWD = 3 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
 enum { PERM_NONE = 0, PERM_GATE = 1 };
 
@@ -32,6 +32,16 @@ struct ConvGemmArgs {
     int skip_init;     // RESSKIP: 1 = store, 0 = accumulate
     int act;           // BIAS_ACT
     int f32_cl;        // BIAS_ACT: out_f32 is [B][L][C] instead of [B][C][L]
+    // training
+    u16* T_hi;         // GATE: optional saves of tanh / sigmoid values (planes, C channels); GATE_BWD: inputs
+    u16* T_lo;
+    u16* G_hi;
+    u16* G_lo;
+    int tc;            // chunks of the T/G planes
+    int res_init;      // RESSKIP: 1 = residual half stores (x = acc + bias), 0 = accumulates
+    const u16* R_hi;   // RESSKIP: residual source planes (null: read the output planes, i.e. in place)
+    const u16* R_lo;
+    long a_bstride;    // elements between the A operands of consecutive batch entries (0: shared weights)
 };
 
 hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a, int epi, hipStream_t stream);
@@ -75,5 +85,5 @@ hipError_t t2s_launch_small_logdet_inv(const float* W, int n, float scale, float
 hipError_t t2s_launch_start(const float* z, const float* w, const float* bias, int B, int n_group, int c_off,
                             int n_half, int C, int L, int Lp, int halo, u16* X_hi, u16* X_lo, hipStream_t stream);
 hipError_t t2s_launch_end_affine(const float* skip, const float* w_end, const float* b_end, float* z, float* log_s,
-                                 int B, int n_group, int c_off, int n_half, int C, int L, int Lp, int halo,
+                                 float* wn_out, int B, int n_group, int c_off, int n_half, int C, int L, int Lp, int halo,
                                  int reverse, hipStream_t stream);

@@ -351,8 +351,8 @@ hipError_t t2s_launch_start(const float* z, const float* w, const float* bias, i
 // with wavefront shuffles.
 __global__ __launch_bounds__(256) void end_affine_kernel(const float* __restrict__ skip, const float* __restrict__ w_end,
                                                          const float* __restrict__ b_end, float* z, float* log_s,
-                                                         int G, int c_off, int nh, int C, int L, int Lp, int halo,
-                                                         int reverse) {
+                                                         float* wn_out, int G, int c_off, int nh, int C, int L, int Lp,
+                                                         int halo, int reverse) {
     const int tid = threadIdx.x;
     const int l32 = tid & 31;
     const int t = blockIdx.x * 8 + (tid >> 5);
@@ -394,12 +394,16 @@ __global__ __launch_bounds__(256) void end_affine_kernel(const float* __restrict
         const float a1 = *zp;
         *zp = reverse ? (a1 - bb) / expf(ls) : expf(ls) * a1 + bb;
         if (log_s) log_s[((size_t)b * nh + l32) * L + t] = ls;
+        if (wn_out) {      // training: keep the coupling network's output (b ; log_s) for the backward pass
+            wn_out[((size_t)b * 2 * nh + l32) * L + t] = bb;
+            wn_out[((size_t)b * 2 * nh + nh + l32) * L + t] = ls;
+        }
     }
 }
 hipError_t t2s_launch_end_affine(const float* skip, const float* w_end, const float* b_end, float* z, float* log_s,
-                                 int B, int n_group, int c_off, int n_half, int C, int L, int Lp, int halo,
+                                 float* wn_out, int B, int n_group, int c_off, int n_half, int C, int L, int Lp, int halo,
                                  int reverse, hipStream_t stream) {
-    hipLaunchKernelGGL(end_affine_kernel, dim3((L + 7) / 8, B), dim3(256), 0, stream, skip, w_end, b_end, z, log_s,
+    hipLaunchKernelGGL(end_affine_kernel, dim3((L + 7) / 8, B), dim3(256), 0, stream, skip, w_end, b_end, z, log_s, wn_out,
                        n_group, c_off, n_half, C, L, Lp, halo, reverse);
     return hipGetLastError();
 }

@@ -256,13 +256,13 @@ class _Engine:
                       _lib.ptr(w["Ah"]), _lib.ptr(w["Al"]), _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), _lib.ptr(w["skip"]),
                       B, C, n_res, 1 if i == 0 else 0, L, w["Lp"], g["halo"], ly["Mpad2"], st)
 
-    def _end(self, k, z, log_s, B, L, w, c_off, n_half, reverse):
+    def _end(self, k, z, log_s, B, L, w, c_off, n_half, reverse, wn_out=None, skip=None):
         m, g = self.m, self.geom()
         wn = m.WN[k]
         w_end, b_end = _f32c(wn.end.weight), _f32c(wn.end.bias)
         self._keep_end = (w_end, b_end)
-        _lib.call("t2s_wg_end_affine", _lib.ptr(w["skip"]), _lib.ptr(w_end), _lib.ptr(b_end), _lib.ptr(z),
-                  _lib.ptr(log_s), B, m.n_group, c_off, n_half, g["C"], L, w["Lp"], g["halo"], 1 if reverse else 0,
+        _lib.call("t2s_wg_end_affine", _lib.ptr(w["skip"] if skip is None else skip), _lib.ptr(w_end), _lib.ptr(b_end),
+                  _lib.ptr(z), _lib.ptr(log_s), _lib.ptr(wn_out), B, m.n_group, c_off, n_half, g["C"], L, w["Lp"], g["halo"], 1 if reverse else 0,
                   _lib.current_stream())
 
     def _flow_geom(self, k):

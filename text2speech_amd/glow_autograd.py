@@ -1,0 +1,338 @@
+"""Training path of the MI355X WaveGlow: forward with saved activations and a hand-scheduled backward
+that issues the gfx950 kernels (reference: autograd over waveglow/glow.py:207-249, driven by
+waveglow/train.py:116-123 `outputs = model((mel, audio)); loss = criterion(outputs); loss.backward()`).
+
+``waveglow_forward_with_grad`` returns tensors hooked into autograd through one custom Function, so the
+reference's training loop (criterion -> loss.backward() -> optimizer.step()) runs unchanged; every
+parameter's ``.grad`` is produced by libt2s_hip.so, not by eager PyTorch.
+
+Memory model (sized for 288 GB HBM3E): every WN layer's input, gate output, tanh and sigmoid stay
+resident as split-bf16 planes (~140 MB per layer, 13.4 GB per step at 8 x 16000) instead of being
+recomputed.
+"""
+import torch
+
+from . import _lib
+from .glow import _f32c, _vg
+
+L_ = _lib
+
+
+def _ptr(t):
+    return _lib.ptr(t)
+
+
+class _TrainState:
+    pass
+
+
+def _bf(*shape, dev):
+    return torch.zeros(*shape, dtype=torch.bfloat16, device=dev)
+
+
+def _alloc_train(eng, B, L, dev):
+    g = eng.geom()
+    key = ("train", B, L, str(dev))
+    st = eng.ws.get(key)
+    if st is not None:
+        return st
+    m = eng.m
+    Lp = _lib.plane_rows(L, g["halo"])
+    xc, sc = g["Cpad"] // 32, g["Spad"] // 32
+    C, nl = g["C"], g["nl"]
+    st = _TrainState()
+    st.Lp = Lp
+    pl = lambda ch: (_bf(B, ch, Lp, 32, dev=dev), _bf(B, ch, Lp, 32, dev=dev))
+    st.S_planes = pl(sc)
+    st.layers = []
+    for k in range(m.n_flows):
+        fl = []
+        for i in range(nl):
+            fl.append(dict(X=pl(xc), A=pl(xc), T=pl(xc), G=pl(xc)))
+        st.layers.append(fl)
+    st.skip = [torch.zeros(B, xc, Lp, 32, dtype=torch.float32, device=dev) for _ in range(m.n_flows)]
+    st.wn_out = [None] * m.n_flows
+    # backward scratch
+    nt = Lp // 32
+    st.nt = nt
+    st.DX, st.DS = pl(xc), pl(xc)
+    st.DP = pl(2 * xc)
+    st.DSp = pl(sc)
+    st.N2 = 3 * C + g["n_cond"] + 1
+    st.N2pad = -(-st.N2 // 256) * 256
+    st.N1 = C + 1
+    st.N1pad = -(-st.N1 // 256) * 256
+    st.M2pad = _lib.padded_rows(2 * C)
+    tm = lambda rows: (_bf(B, nt, rows, 32, dev=dev), _bf(B, nt, rows, 32, dev=dev))
+    st.TM_dp = tm(st.M2pad)
+    st.TM_drs = tm(st.M2pad)
+    st.TM_x = tm(st.N2pad)
+    st.TM_act = tm(st.N1pad)
+    st.P2 = torch.empty(B, 2 * C, st.N2, dtype=torch.float32, device=dev)
+    st.P1 = torch.empty(B, 2 * C, st.N1, dtype=torch.float32, device=dev)
+    st.Mc = _lib.padded_rows(C)
+    st.Ms = _lib.padded_rows(g["n_cond"])
+    st.A_rsT = (_bf(2 * C // 32, st.Mc, 32, dev=dev), _bf(2 * C // 32, st.Mc, 32, dev=dev))
+    st.A_inT = (_bf(g["ks"] * 2 * C // 32, st.Mc, 32, dev=dev), _bf(g["ks"] * 2 * C // 32, st.Mc, 32, dev=dev))
+    st.A_cT = (_bf(2 * C // 32, st.Ms, 32, dev=dev), _bf(2 * C // 32, st.Ms, 32, dev=dev))
+    st.zero_bias = torch.zeros(max(st.M2pad, st.Ms, 1024), dtype=torch.float32, device=dev)
+    st.scale = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    eng.ws[key] = st
+    return st
+
+
+def forward_train(eng, mel, audio):
+    """WaveGlow.forward (glow.py:207-249) keeping what the backward needs."""
+    m = eng.m
+    eng._check_inputs(mel, audio)
+    dev = audio.device
+    B, T = audio.shape
+    G = m.n_group
+    L = T // G
+    g = eng.geom()
+    C, nl, ks = g["C"], g["nl"], g["ks"]
+    eng.pack_weights(dev, force=True)
+    ts = _alloc_train(eng, B, L, dev)
+    st = _lib.current_stream()
+    w = dict(Lp=ts.Lp, Sh=ts.S_planes[0], Sl=ts.S_planes[1])
+    eng._upsample(mel, B, L, w)
+    audio32 = _f32c(audio)
+    z = torch.empty(B, G, L, dtype=torch.float32, device=dev)
+    _lib.call("t2s_wg_audio_squeeze", _ptr(audio32), _ptr(z), B, T, G, L, 0, st)
+    log_s_list = []
+    log_det = torch.empty(m.n_flows, dtype=torch.float32, device=dev)
+    keep = [audio32]
+    for k in range(m.n_flows):
+        c_off, n_rem, n_half = eng._flow_geom(k)
+        fl = eng.packed["flows"][k]
+        Wk = _f32c(m.convinv[k].conv.weight)
+        keep.append(Wk)
+        _lib.call("t2s_small_logdet_inv", _ptr(Wk), n_rem, float(B * L), _lib.c_vp(log_det.data_ptr() + 4 * k), None, st)
+        _lib.call("t2s_wg_convinv", _ptr(z), _ptr(Wk), B, G, c_off, n_rem, L, st)
+        wn = m.WN[k]
+        b_start = _f32c(wn.start.bias)
+        keep.append(b_start)
+        lay = ts.layers[k]
+        _lib.call("t2s_wg_start", _ptr(z), _ptr(fl["w_start"]), _ptr(b_start), B, G, c_off, n_half, C, L, ts.Lp, g["halo"],
+                  _ptr(lay[0]["X"][0]), _ptr(lay[0]["X"][1]), st)
+        for i in range(nl):
+            ly, sv = fl["layers"][i], lay[i]
+            _lib.call("t2s_wg_in_cond_gate_train", _ptr(ly["A1h"]), _ptr(ly["A1l"]), _ptr(ly["b1"]), _ptr(sv["X"][0]),
+                      _ptr(sv["X"][1]), _ptr(ts.S_planes[0]), _ptr(ts.S_planes[1]), _ptr(sv["A"][0]), _ptr(sv["A"][1]),
+                      _ptr(sv["T"][0]), _ptr(sv["T"][1]), _ptr(sv["G"][0]), _ptr(sv["G"][1]), B, C, g["n_cond"], ks, 2 ** i,
+                      L, ts.Lp, g["halo"], g["Mpad1"], st)
+            last = i == nl - 1
+            nxt = None if last else lay[i + 1]["X"]
+            _lib.call("t2s_wg_res_skip_train", _ptr(ly["A2h"]), _ptr(ly["A2l"]), _ptr(ly["b2"]), _ptr(sv["A"][0]),
+                      _ptr(sv["A"][1]), None if last else _ptr(sv["X"][0]), None if last else _ptr(sv["X"][1]),
+                      None if last else _ptr(nxt[0]), None if last else _ptr(nxt[1]), _ptr(ts.skip[k]), B, C,
+                      0 if last else C, 1 if i == 0 else 0, L, ts.Lp, g["halo"], ly["Mpad2"], st)
+        log_s = torch.empty(B, n_half, L, dtype=torch.float32, device=dev)
+        ts.wn_out[k] = torch.empty(B, 2 * n_half, L, dtype=torch.float32, device=dev)
+        eng._end(k, z, log_s, B, L, dict(Lp=ts.Lp), c_off, n_half, reverse=False, wn_out=ts.wn_out[k], skip=ts.skip[k])
+        log_s_list.append(log_s)
+    ts.z_final = z
+    ts.mel = _f32c(mel)
+    ts.B, ts.L = B, L
+    ts.keep = keep
+    return z, log_s_list, log_det, ts
+
+
+def backward_train(eng, ts, gz, g_log_s, g_log_det):
+    """Gradients of every parameter, flows and layers walked in reverse.  Returns {id(param): grad}."""
+    m = eng.m
+    g = eng.geom()
+    C, nl, ks, n_cond, halo = g["C"], g["nl"], g["ks"], g["n_cond"], g["halo"]
+    B, L, Lp, nt = ts.B, ts.L, ts.Lp, ts.nt
+    G = m.n_group
+    dev = ts.z_final.device
+    st = _lib.current_stream()
+    grads = {}
+    zb = ts.zero_bias
+    dz = torch.zeros(B, G, L, dtype=torch.float32, device=dev) if gz is None else gz.to(torch.float32).contiguous().clone()
+    zw = ts.z_final.clone()
+    if g_log_det is not None:
+        g_log_det = g_log_det.to(torch.float32).contiguous()
+    xc, sc = g["Cpad"] // 32, g["Spad"] // 32
+    # conditioning rows + the ones row of the in/cond weight-gradient GEMM are the same for every layer
+    _lib.call("t2s_plane_transpose", _ptr(ts.S_planes[0]), _ptr(ts.S_planes[1]), B, sc, sc, Lp, 0, _ptr(ts.TM_x[0]),
+              _ptr(ts.TM_x[1]), ts.N2pad, ks * C, st)
+    _lib.call("t2s_tm_ones_row", _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), B, Lp, halo, L, ts.N2pad, ts.N2 - 1, st)
+    _lib.call("t2s_tm_ones_row", _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]), B, Lp, halo, L, ts.N1pad, C, st)
+    dsp_init = 1
+    keep = []
+
+    def new(*shape):
+        return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+    def wn_grads(conv, P, nsplit, Prows, Pcols, col_off, tap_stride, col_bias, O, Cin, Kt, with_bias=True):
+        v, gg = _vg(conv)
+        v32 = _f32c(v)
+        g32 = None if gg is None else _f32c(gg)
+        dv = new(*v.shape)
+        dg = None if gg is None else new(*gg.shape)
+        db = new(O) if with_bias else None
+        keep.extend([v32, g32])
+        _lib.call("t2s_wn_backward", _ptr(P), nsplit, Prows, Pcols, 0, col_off, tap_stride, col_bias, _ptr(v32), _ptr(g32), O,
+                  Cin, Kt, _ptr(dv), _ptr(dg), _ptr(db), 0, st)
+        if gg is None:
+            grads[id(conv.weight)] = dv
+        else:
+            grads[id(conv.weight_v)] = dv
+            grads[id(conv.weight_g)] = dg
+        if with_bias:
+            grads[id(conv.bias)] = db
+
+    def scale_of(conv):
+        v, gg = _vg(conv)
+        v32 = _f32c(v)
+        g32 = None if gg is None else _f32c(gg)
+        sc_ = new(v.size(0))
+        keep.extend([v32, g32, sc_])
+        _lib.call("t2s_weightnorm_scale", _ptr(v32), _ptr(g32), v.size(0), v[0].numel(), _ptr(sc_), st)
+        return v32, sc_
+
+    for k in reversed(range(m.n_flows)):
+        c_off, n_rem, n_half = eng._flow_geom(k)
+        wn = m.WN[k]
+        fl = eng.packed["flows"][k]
+        lay = ts.layers[k]
+        nj = 2 * n_half
+        # ---- affine coupling backward, un-apply (a1 restored in zw) ----
+        d_out = new(B, nj, L)
+        gls = None if g_log_s[k] is None else g_log_s[k].to(torch.float32).contiguous()
+        keep.append(gls)
+        _lib.call("t2s_wg_affine_backward", _ptr(zw), _ptr(dz), _ptr(ts.wn_out[k]), _ptr(gls), _ptr(d_out), B, G, c_off,
+                  n_half, L, st)
+        # ---- WN.end: weight / bias gradient, and d_skip = W_end^T d_out as planes ----
+        w_end = _f32c(wn.end.weight)
+        dW_end = new(*wn.end.weight.shape)
+        db_end = new(nj)
+        _lib.call("t2s_small_wgrad", None, None, _ptr(ts.skip[k]), _ptr(d_out), _ptr(dW_end), None, B, xc, Lp, halo, L, C, nj,
+                  nj, 0, 1, st)
+        _lib.call("t2s_rows_sum", _ptr(d_out), B, nj, 0, nj, L, _ptr(db_end), st)
+        grads[id(wn.end.weight)] = dW_end
+        grads[id(wn.end.bias)] = db_end
+        w_endT = new(C, nj)
+        _lib.call("t2s_transpose", _ptr(w_end), _ptr(w_endT), nj, C, st)
+        keep.extend([w_end, w_endT])
+        _lib.call("t2s_wg_start", _ptr(d_out), _ptr(w_endT), _ptr(zb), B, nj, 0, nj, C, L, Lp, halo, _ptr(ts.DS[0]),
+                  _ptr(ts.DS[1]), st)
+        # d_skip rows of every layer's d_rs are the same: transpose once per flow
+        for i in reversed(range(nl)):
+            last = i == nl - 1
+            sv = lay[i]
+            rows2 = C if last else 2 * C
+            Mrs = _lib.padded_rows(rows2)
+            conv_rs, conv_in, conv_c = wn.res_skip_layers[i], wn.in_layers[i], wn.cond_layers[i]
+            # 1. d_pre = gate'(T,G) * (W_rs^T [dx ; dS])
+            v_rs, s_rs = scale_of(conv_rs)
+            _lib.call("t2s_pack_transposed", _ptr(v_rs), _ptr(s_rs), rows2, C, 1, 0, rows2, ts.Mc, 0, _ptr(ts.A_rsT[0]),
+                      _ptr(ts.A_rsT[1]), st)
+            _lib.call("t2s_wg_bwd_gate_dgrad", _ptr(ts.A_rsT[0]), _ptr(ts.A_rsT[1]), _ptr(zb),
+                      None if last else _ptr(ts.DX[0]), None if last else _ptr(ts.DX[1]), _ptr(ts.DS[0]), _ptr(ts.DS[1]),
+                      _ptr(sv["T"][0]), _ptr(sv["T"][1]), _ptr(sv["G"][0]), _ptr(sv["G"][1]), _ptr(ts.DP[0]), _ptr(ts.DP[1]),
+                      B, C, L, Lp, halo, ts.Mc, st)
+            # 2. dW_rs = [dx ; dS] . acts^T  (+ bias column)
+            if not last:
+                _lib.call("t2s_plane_transpose", _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, xc, xc, Lp, 0, _ptr(ts.TM_drs[0]),
+                          _ptr(ts.TM_drs[1]), Mrs, 0, st)
+            _lib.call("t2s_plane_transpose", _ptr(ts.DS[0]), _ptr(ts.DS[1]), B, xc, xc, Lp, 0, _ptr(ts.TM_drs[0]),
+                      _ptr(ts.TM_drs[1]), Mrs, 0 if last else C, st)
+            _lib.call("t2s_plane_transpose", _ptr(sv["A"][0]), _ptr(sv["A"][1]), B, xc, xc, Lp, 0, _ptr(ts.TM_act[0]),
+                      _ptr(ts.TM_act[1]), ts.N1pad, 0, st)
+            _lib.call("t2s_wgrad_gemm", _ptr(ts.TM_drs[0]), _ptr(ts.TM_drs[1]), _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]), _ptr(zb),
+                      _ptr(ts.P1), B, rows2, ts.N1, Mrs, ts.N1pad, nt, st)
+            wn_grads(conv_rs, ts.P1, B, rows2, ts.N1, 0, 0, C, rows2, C, 1)
+            # 3. dW_in, dW_cond = d_pre . [x taps | spect | 1]^T
+            _lib.call("t2s_plane_transpose", _ptr(ts.DP[0]), _ptr(ts.DP[1]), B, 2 * xc, 2 * xc, Lp, 0, _ptr(ts.TM_dp[0]),
+                      _ptr(ts.TM_dp[1]), ts.M2pad, 0, st)
+            d = 2 ** i
+            for tap in range(ks):
+                _lib.call("t2s_plane_transpose", _ptr(sv["X"][0]), _ptr(sv["X"][1]), B, xc, xc, Lp, (tap - ks // 2) * d,
+                          _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), ts.N2pad, tap * C, st)
+            _lib.call("t2s_wgrad_gemm", _ptr(ts.TM_dp[0]), _ptr(ts.TM_dp[1]), _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), _ptr(zb),
+                      _ptr(ts.P2), B, 2 * C, ts.N2, ts.M2pad, ts.N2pad, nt, st)
+            wn_grads(conv_in, ts.P2, B, 2 * C, ts.N2, 0, C, ts.N2 - 1, 2 * C, C, ks)
+            wn_grads(conv_c, ts.P2, B, 2 * C, ts.N2, ks * C, 0, ts.N2 - 1, 2 * C, n_cond, 1)
+            # 4. dx (+)= W_in^T (*) d_pre ;  d_spect += W_cond^T d_pre
+            v_in, s_in = scale_of(conv_in)
+            _lib.call("t2s_pack_transposed", _ptr(v_in), _ptr(s_in), 2 * C, C, ks, 1, 2 * C, ts.Mc, 0, _ptr(ts.A_inT[0]),
+                      _ptr(ts.A_inT[1]), st)
+            _lib.call("t2s_conv_accumulate", _ptr(ts.A_inT[0]), _ptr(ts.A_inT[1]), _ptr(zb), _ptr(ts.DP[0]), _ptr(ts.DP[1]),
+                      _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, 2 * C, C, ks, d, 1 if last else 0, L, Lp, halo, ts.Mc, st)
+            v_c, s_c = scale_of(conv_c)
+            _lib.call("t2s_pack_transposed", _ptr(v_c), _ptr(s_c), 2 * C, n_cond, 1, 0, 2 * C, ts.Ms, 0, _ptr(ts.A_cT[0]),
+                      _ptr(ts.A_cT[1]), st)
+            _lib.call("t2s_conv_accumulate", _ptr(ts.A_cT[0]), _ptr(ts.A_cT[1]), _ptr(zb), _ptr(ts.DP[0]), _ptr(ts.DP[1]),
+                      _ptr(ts.DSp[0]), _ptr(ts.DSp[1]), B, 2 * C, n_cond, 1, 1, dsp_init, L, Lp, halo, ts.Ms, st)
+            dsp_init = 0
+        # ---- WN.start ----
+        dW_eff = new(C, n_half)
+        db_start = new(C)
+        _lib.call("t2s_small_wgrad", _ptr(ts.DX[0]), _ptr(ts.DX[1]), None, _ptr(zw), _ptr(dW_eff), _ptr(db_start), B, xc, Lp,
+                  halo, L, C, n_half, G, c_off, 0, st)
+        wn_grads(wn.start, dW_eff, 1, C, n_half, 0, 0, 0, C, n_half, 1, with_bias=False)
+        grads[id(wn.start.bias)] = db_start
+        _lib.call("t2s_wg_start_dgrad", _ptr(ts.DX[0]), _ptr(ts.DX[1]), _ptr(fl["w_start"]), _ptr(dz), B, G, c_off, n_half, C,
+                  L, Lp, halo, st)
+        # ---- invertible 1x1 conv ----
+        Wk = _f32c(m.convinv[k].conv.weight)
+        Winv = new(n_rem, n_rem)
+        WT = new(n_rem, n_rem)
+        _lib.call("t2s_small_logdet_inv", _ptr(Wk), n_rem, 1.0, None, _ptr(Winv), st)
+        _lib.call("t2s_transpose", _ptr(Wk), _ptr(WT), n_rem, n_rem, st)
+        _lib.call("t2s_wg_convinv", _ptr(zw), _ptr(Winv), B, G, c_off, n_rem, L, st)          # zw <- flow input
+        dW = new(*m.convinv[k].conv.weight.shape)
+        gp = None if g_log_det is None else _lib.c_vp(g_log_det.data_ptr() + 4 * k)
+        _lib.call("t2s_wg_convinv_wgrad", _ptr(dz), _ptr(zw), _ptr(Winv), gp, float(B * L), B, G, c_off, n_rem, L, _ptr(dW), st)
+        _lib.call("t2s_wg_convinv", _ptr(dz), _ptr(WT), B, G, c_off, n_rem, L, st)            # dz <- W^T dz
+        grads[id(m.convinv[k].conv.weight)] = dW
+        keep.extend([Wk, Winv, WT, d_out])
+    # ---- upsampler ----
+    up = m.upsample
+    dW_up = new(*up.weight.shape)
+    db_up = new(up.out_channels)
+    _lib.call("t2s_wg_upsample_wgrad", _ptr(ts.DSp[0]), _ptr(ts.DSp[1]), _ptr(ts.mel), B, up.in_channels, ts.mel.size(2),
+              up.kernel_size[0], up.stride[0], G, L, Lp, halo, _ptr(dW_up), _ptr(db_up), st)
+    grads[id(up.weight)] = dW_up
+    grads[id(up.bias)] = db_up
+    ts.keep_bwd = keep
+    return grads
+
+
+class _WaveGlowFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, mel, audio, *params):
+        eng = model._eng()
+        with torch.no_grad():
+            z, log_s_list, log_det, ts = forward_train(eng, mel, audio)
+        ctx.model = model
+        ctx.ts = ts
+        ctx.n = len(log_s_list)
+        ctx.params = params
+        return (z, *log_s_list, log_det)
+
+    @staticmethod
+    def backward(ctx, gz, *rest):
+        n = ctx.n
+        g_log_s = list(rest[:n])
+        g_log_det = rest[n]
+        eng = ctx.model._eng()
+        with torch.no_grad():
+            grads = backward_train(eng, ctx.ts, gz, g_log_s, g_log_det)
+        out = []
+        for p in ctx.params:
+            gr = grads.get(id(p))
+            out.append(None if gr is None else gr.view_as(p).to(p.dtype))
+        return (None, None, None, *out)
+
+
+def waveglow_forward_with_grad(model, mel, audio):
+    params = [p for p in model.parameters()]
+    outs = _WaveGlowFn.apply(model, mel, audio, *params)
+    n = model.n_flows
+    z = outs[0]
+    log_s_list = list(outs[1:1 + n])
+    log_det = outs[1 + n]
+    return z, log_s_list, [log_det[k] for k in range(n)]
