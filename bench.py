@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--segment", type=int, default=16000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["forward", "train"], default="forward",
+                    help="forward: the headline metric (default); train: zero_grad+forward+loss+backward+Adam, "
+                         "data-parallel over RCCL when launched with N > 1 ranks (BASELINE configs[3])")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,9 +115,30 @@ def main():
 
     eng = model._eng()
     log("rank %d: model built, starting warm-up" % rank)
-    with torch.no_grad():
+    if args.mode == "train":
+        from text2speech_amd.glow import WaveGlowLoss
+        from text2speech_amd.optim import FusedAdam
+        from text2speech_amd import distributed as D
+        model.train()
+        if dist is not None:
+            D.apply_gradient_allreduce(model)
+        opt = FusedAdam(model.parameters(), lr=1e-4)
+        crit = WaveGlowLoss(1.0)
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            loss = crit(model((mel, audio)))
+            loss.backward()
+            opt.step()
+            return loss
+    else:
+        def step():
+            with torch.no_grad():
+                model((mel, audio))
+    run_train_or_fwd = step
+    with torch.enable_grad() if args.mode == "train" else torch.no_grad():
         for _ in range(args.warmup):
-            model((mel, audio))
+            run_train_or_fwd()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -122,7 +146,7 @@ def main():
         eng.gemm_events = [] if rank == 0 else None
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            model((mel, audio))
+            run_train_or_fwd()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -154,17 +178,20 @@ def main():
                     "note": "split-bf16: 3 bf16 MFMA products per algorithmic MAC, so frac <= 1/3 by construction"}
         total_samples = args.gpus * args.batch * args.segment * args.steps
         out = {
-            "metric": "WaveGlow forward audio samples/sec (batch 8x16000 per GPU)",
+            "metric": "WaveGlow forward audio samples/sec (batch 8x16000 per GPU)" if args.mode == "forward"
+            else "WaveGlow train-step audio samples/sec (batch 8x16000 per GPU, fwd+loss+bwd+Adam, DP all-reduce)",
             "value": total_samples / dt, "unit": "audio samples/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16x3 (split-bf16 products, f32 accumulate)",
             "data": "synthetic (seeded N(0,1) mel, U(-0.5,0.5) audio; seeded random weights, WN.end ~ N(0,0.02^2))",
             "config": {"workload": "WaveGlow forward, batch %d x %d samples per GPU, 12 flows, n_group 8, "
                                    "WN 8 layers x 512 channels (reference waveglow/config.json)" % (args.batch, args.segment),
-                       "per_gpu_batch": args.batch, "segment_length": args.segment, "parallelism": "replicas, no collective"},
+                       "per_gpu_batch": args.batch, "segment_length": args.segment, "mode": args.mode,
+                       "parallelism": "replicas, no collective" if args.mode == "forward"
+                       else "dp%d, 13 bucketed RCCL all-reduces overlapped with backward" % args.gpus},
             "roofline": roof,
         }
-        if args.gpus == 1 and not args.no_cpu_baseline:
+        if args.gpus == 1 and not args.no_cpu_baseline and args.mode == "forward":
             out["cpu_baseline"] = cpu_baseline(cfg, sd)
         print(json.dumps(out), flush=True)
     if dist is not None:

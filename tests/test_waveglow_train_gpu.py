@@ -90,3 +90,35 @@ def test_adam_step_matches_torch(trained):
     torch.cuda.synchronize()
     worst = max(_rel(p.detach(), r.detach()) for p, r in zip(m.parameters(), ref))
     assert worst < 1e-6, worst
+
+
+def test_bucketed_allreduce_inside_backward_nccl_world1():
+    """The DP path end to end on one GPU: RCCL process group of size 1, weights broadcast, 13 flat gradient
+    buckets all-reduced from inside the backward; gradients must equal the single-process ones."""
+    import torch.distributed as dist
+    from text2speech_amd import distributed as D
+    from text2speech_amd.glow import WaveGlow, WaveGlowLoss
+    cfg = synth.WAVEGLOW_SMALL
+    sd = synth.waveglow_state(cfg)
+    mel, audio = synth.waveglow_inputs(1, 2048, seed=9)
+
+    def run(with_dp):
+        m = WaveGlow(**cfg)
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        if with_dp:
+            D.apply_gradient_allreduce(m)
+        WaveGlowLoss(1.0)(m((mel.to(DEV), audio.to(DEV)))).backward()
+        torch.cuda.synchronize()
+        return m, {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+
+    _, base = run(False)
+    D.init_distributed(0, 1, None, "nccl", "tcp://127.0.0.1:29517")
+    try:
+        m, got = run(True)
+        sync = m._eng().grad_sync
+        assert sync is not None and sync.n_buckets == cfg["n_flows"] + 1 and not sync.pending
+        for n in base:
+            assert torch.equal(base[n], got[n]), n
+    finally:
+        dist.destroy_process_group()

@@ -105,6 +105,7 @@ class _Engine:
         self.packed = None
         self.packed_key = None
         self.ws = {}
+        self.grad_sync = None       # distributed.GradSync: bucketed RCCL all-reduce issued from inside backward
         self.gemm_events = None     # bench.py: list of (start, end) torch.cuda.Event pairs around the gate GEMM
 
     # ------------------------------------------------------------------ geometry

@@ -165,13 +165,37 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
     def new(*shape):
         return torch.empty(*shape, dtype=torch.float32, device=dev)
 
+    # Parameter gradients of one flow live in one flat bucket, handed to RCCL as soon as the flow is done
+    # (text2speech_amd/distributed.py) while the next flow's backward kernels run.
+    sync = getattr(eng, "grad_sync", None)
+
+    class _Bucket:
+        def __init__(self, params):
+            params = list(params)
+            self.flat = torch.empty(sum(p.numel() for p in params) + 4 * len(params), dtype=torch.float32, device=dev)
+            self.off = 0
+
+        def take(self, *shape):
+            n = 1
+            for d_ in shape:
+                n *= int(d_)
+            v = self.flat[self.off:self.off + n].view(*shape)
+            self.off += -(-n // 4) * 4
+            return v
+
+        def ship(self):
+            if sync is not None:
+                sync.reduce_async(self.flat[:self.off])
+
+    bucket = None
+
     def wn_grads(conv, P, nsplit, Prows, Pcols, col_off, tap_stride, col_bias, O, Cin, Kt, with_bias=True):
         v, gg = _vg(conv)
         v32 = _f32c(v)
         g32 = None if gg is None else _f32c(gg)
-        dv = new(*v.shape)
-        dg = None if gg is None else new(*gg.shape)
-        db = new(O) if with_bias else None
+        dv = bucket.take(*v.shape)
+        dg = None if gg is None else bucket.take(*gg.shape)
+        db = bucket.take(O) if with_bias else None
         keep.extend([v32, g32])
         _lib.call("t2s_wn_backward", _ptr(P), nsplit, Prows, Pcols, 0, col_off, tap_stride, col_bias, _ptr(v32), _ptr(g32), O,
                   Cin, Kt, _ptr(dv), _ptr(dg), _ptr(db), 0, st)
@@ -198,6 +222,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         fl = eng.packed["flows"][k]
         lay = ts.layers[k]
         nj = 2 * n_half
+        bucket = _Bucket(list(wn.parameters()) + list(m.convinv[k].parameters()))
         # ---- affine coupling backward, un-apply (a1 restored in zw) ----
         d_out = new(B, nj, L)
         gls = None if g_log_s[k] is None else g_log_s[k].to(torch.float32).contiguous()
@@ -206,8 +231,8 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                   n_half, L, st)
         # ---- WN.end: weight / bias gradient, and d_skip = W_end^T d_out as planes ----
         w_end = _f32c(wn.end.weight)
-        dW_end = new(*wn.end.weight.shape)
-        db_end = new(nj)
+        dW_end = bucket.take(*wn.end.weight.shape)
+        db_end = bucket.take(nj)
         _lib.call("t2s_small_wgrad", None, None, _ptr(ts.skip[k]), _ptr(d_out), _ptr(dW_end), None, B, xc, Lp, halo, L, C, nj,
                   nj, 0, 1, st)
         _lib.call("t2s_rows_sum", _ptr(d_out), B, nj, 0, nj, L, _ptr(db_end), st)
@@ -269,7 +294,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             dsp_init = 0
         # ---- WN.start ----
         dW_eff = new(C, n_half)
-        db_start = new(C)
+        db_start = bucket.take(C)
         _lib.call("t2s_small_wgrad", _ptr(ts.DX[0]), _ptr(ts.DX[1]), None, _ptr(zw), _ptr(dW_eff), _ptr(db_start), B, xc, Lp,
                   halo, L, C, n_half, G, c_off, 0, st)
         wn_grads(wn.start, dW_eff, 1, C, n_half, 0, 0, 0, C, n_half, 1, with_bias=False)
@@ -283,20 +308,25 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         _lib.call("t2s_small_logdet_inv", _ptr(Wk), n_rem, 1.0, None, _ptr(Winv), st)
         _lib.call("t2s_transpose", _ptr(Wk), _ptr(WT), n_rem, n_rem, st)
         _lib.call("t2s_wg_convinv", _ptr(zw), _ptr(Winv), B, G, c_off, n_rem, L, st)          # zw <- flow input
-        dW = new(*m.convinv[k].conv.weight.shape)
+        dW = bucket.take(*m.convinv[k].conv.weight.shape)
         gp = None if g_log_det is None else _lib.c_vp(g_log_det.data_ptr() + 4 * k)
         _lib.call("t2s_wg_convinv_wgrad", _ptr(dz), _ptr(zw), _ptr(Winv), gp, float(B * L), B, G, c_off, n_rem, L, _ptr(dW), st)
         _lib.call("t2s_wg_convinv", _ptr(dz), _ptr(WT), B, G, c_off, n_rem, L, st)            # dz <- W^T dz
         grads[id(m.convinv[k].conv.weight)] = dW
         keep.extend([Wk, Winv, WT, d_out])
+        bucket.ship()
     # ---- upsampler ----
     up = m.upsample
-    dW_up = new(*up.weight.shape)
-    db_up = new(up.out_channels)
+    bucket = _Bucket(up.parameters())
+    dW_up = bucket.take(*up.weight.shape)
+    db_up = bucket.take(up.out_channels)
     _lib.call("t2s_wg_upsample_wgrad", _ptr(ts.DSp[0]), _ptr(ts.DSp[1]), _ptr(ts.mel), B, up.in_channels, ts.mel.size(2),
               up.kernel_size[0], up.stride[0], G, L, Lp, halo, _ptr(dW_up), _ptr(db_up), st)
     grads[id(up.weight)] = dW_up
     grads[id(up.bias)] = db_up
+    bucket.ship()
+    if sync is not None:
+        sync.finish()
     ts.keep_bwd = keep
     return grads
 
