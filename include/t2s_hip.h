@@ -66,6 +66,7 @@ typedef struct t2s_pack_job {
     float* bias_out;
     long row_start;
     long O, Cin, Kt, perm, C_gate, Mpad, koff, Cin_pad, row_off, g_is_scale;
+    float* scale_out; /* optional [O]: per-row factor g/|v| that was applied, kept for the backward pass */
 } t2s_pack_job;
 int t2s_pack_conv_weight_table(const t2s_pack_job* jobs, int n_jobs, long total_rows, void* stream);
 
@@ -236,9 +237,11 @@ int t2s_wn_backward(const float* P, int nsplit, int Prows, int Pcols, int row_of
 /* affine coupling backward + un-apply (glow.py:241-246); wn_out = (b ; log_s) [B][2nh][L], d_out gets (d_b ; d_log_s) */
 int t2s_wg_affine_backward(float* z, float* dz, const float* wn_out, const float* g_log_s, float* d_out, int B,
                            int n_group, int c_off, int n_half, int L, void* stream);
-/* out[r][j] (or [j][r]) = sum_{b,t} P[b][r][t] * Q[b][q_off+j][t], rowsum[r] = sum P; P = planes (hi/lo, or f32) */
+/* out[r][j] (or [j][r]) = sum_{b,t} P[b][r][t] * Q[b][q_off+j][t], rowsum[r] = sum P; P = planes (hi/lo, or f32).
+ * scratch: t2s_small_wgrad_scratch(B, chunks) floats of partial sums (reduced in a fixed order: deterministic). */
+long t2s_small_wgrad_scratch(int B, int chunks);
 int t2s_small_wgrad(const void* P_hi, const void* P_lo, const float* P_f32, const float* Q, float* out, float* rowsum,
-                    int B, int chunks, int Lp, int halo, int L, int R, int J, int Jtot, int q_off, int out_transposed,
+                    float* scratch, int B, int chunks, int Lp, int halo, int L, int R, int J, int Jtot, int q_off, int out_transposed,
                     void* stream);
 int t2s_rows_sum(const float* Q, int B, int Jtot, int q_off, int J, int L, float* out, void* stream);
 /* d_z[:, c_off:c_off+n_half] += W_start^T d_x */

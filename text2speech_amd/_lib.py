@@ -59,7 +59,8 @@ SIGNATURES = {
     "t2s_wn_backward": [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp,
                         c_vp, c_int, c_vp],
     "t2s_wg_affine_backward": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
-    "t2s_small_wgrad": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+    "t2s_small_wgrad_scratch": [c_int, c_int],
+    "t2s_small_wgrad": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                         c_int, c_vp],
     "t2s_rows_sum": [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp],
     "t2s_wg_start_dgrad": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
@@ -68,7 +69,8 @@ SIGNATURES = {
                               c_vp],
     "t2s_adam_table": [c_vp, c_int, c_long, c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_vp],
 }
-_RESTYPE = {"t2s_error_string": ctypes.c_char_p, "t2s_last_hip_error": ctypes.c_char_p}
+_RESTYPE = {"t2s_error_string": ctypes.c_char_p, "t2s_last_hip_error": ctypes.c_char_p,
+            "t2s_small_wgrad_scratch": ctypes.c_long}
 
 
 class T2SError(RuntimeError):

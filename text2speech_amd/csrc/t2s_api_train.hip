@@ -202,14 +202,16 @@ int t2s_wg_affine_backward(float* z, float* dz, const float* wn_out, const float
     return T2S_OK;
 }
 
+long t2s_small_wgrad_scratch(int B, int chunks) { return (long)t2s_small_wgrad_scratch_floats(B, chunks); }
+
 int t2s_small_wgrad(const void* P_hi, const void* P_lo, const float* P_f32, const float* Q, float* out, float* rowsum,
-                    int B, int chunks, int Lp, int halo, int L, int R, int J, int Jtot, int q_off, int out_transposed,
+                    float* scratch, int B, int chunks, int Lp, int halo, int L, int R, int J, int Jtot, int q_off, int out_transposed,
                     void* stream) {
-    if ((!P_f32 && (!P_hi || !P_lo)) || !Q || !out || B <= 0 || chunks <= 0 || L <= 0 || R <= 0 || R > chunks * 32 ||
+    if ((!P_f32 && (!P_hi || !P_lo)) || !Q || !out || !scratch || B <= 0 || chunks <= 0 || L <= 0 || R <= 0 || R > chunks * 32 ||
         J <= 0 || J > 16 || q_off < 0 || q_off + J > Jtot)
         return T2S_EINVAL;
     SmallWgradArgs a;
-    a.P_hi = (const u16*)P_hi; a.P_lo = (const u16*)P_lo; a.P_f32 = P_f32; a.Q = Q; a.out = out; a.rowsum = rowsum;
+    a.P_hi = (const u16*)P_hi; a.P_lo = (const u16*)P_lo; a.P_f32 = P_f32; a.Q = Q; a.out = out; a.rowsum = rowsum; a.scratch = scratch;
     a.B = B; a.chunks = chunks; a.Lp = Lp; a.halo = halo; a.L = L; a.R = R; a.J = J; a.Jtot = Jtot; a.q_off = q_off;
     a.out_transposed = out_transposed;
     T2S_CHECK_HIP(t2s_launch_small_wgrad(a, (hipStream_t)stream));

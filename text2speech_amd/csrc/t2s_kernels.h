@@ -69,6 +69,7 @@ struct PackJob {               // mirrors t2s_pack_job in include/t2s_hip.h (all
     u16* A_hi; u16* A_lo; float* bias_out;
     long row_start;            // first block index of this job (prefix sum of O)
     long O, Cin, Kt, perm, C_gate, Mpad, koff, Cin_pad, row_off, g_is_scale;
+    float* scale_out;          // optional [O]: the per-row factor applied (g/|v|), kept for the backward pass
 };
 hipError_t t2s_launch_pack_table(const PackJob* jobs, int n_jobs, long total_rows, hipStream_t stream);
 hipError_t t2s_launch_weightnorm_small(const float* v, const float* g, int O, int K, float* w, hipStream_t stream);

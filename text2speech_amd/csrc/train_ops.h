@@ -23,6 +23,7 @@ struct SmallWgradArgs {
     const float* Q;        // [B][Jtot][L]
     float* out;            // [R][J] or [J][R]
     float* rowsum;         // [R] or null
+    float* scratch;        // [B*8][chunks*32][17] partial sums
     int B, chunks, Lp, halo, L, R, J, Jtot, q_off, out_transposed;
 };
 
@@ -42,6 +43,7 @@ hipError_t t2s_launch_wn_backward(const WnBwdArgs& a, hipStream_t stream);
 hipError_t t2s_launch_affine_backward(float* z, float* dz, const float* wn_out, const float* g_ls, float* d_out, int B,
                                       int G, int c_off, int nh, int L, hipStream_t stream);
 hipError_t t2s_launch_small_wgrad(const SmallWgradArgs& a, hipStream_t stream);
+size_t t2s_small_wgrad_scratch_floats(int B, int chunks);
 hipError_t t2s_launch_rows_sum(const float* Q, int B, int Jtot, int q_off, int J, int L, float* out, hipStream_t stream);
 hipError_t t2s_launch_start_dgrad(const u16* X_hi, const u16* X_lo, const float* w, float* dz, int B, int G, int c_off,
                                   int nh, int C, int L, int Lp, int halo, hipStream_t stream);

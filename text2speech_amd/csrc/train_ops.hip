@@ -196,47 +196,60 @@ hipError_t t2s_launch_affine_backward(float* z, float* dz, const float* wn_out, 
 // P comes from planes (hi/lo bf16, or f32 planes when P_lo == NULL && P_f32 != NULL), Q is [B][Jtot][L] f32
 // at channel offset q_off.  Optionally also rowsum[r] = sum P.  One workgroup per 32-channel chunk.
 // Used for dW_end (P = skip sum, Q = d_out; transposed output), dW_start (P = dx, Q = a0).
+// grid = (chunks, B * TSPLIT): block (chunk, b, s) covers time steps t = s*8 + tl, stride 8*TSPLIT, and writes a
+// partial [17] per channel to scratch; small_wgrad_reduce_kernel sums the partials in a fixed order.
+#define SW_TSPLIT 8
 __global__ __launch_bounds__(256) void small_wgrad_kernel(const SmallWgradArgs a) {
     __shared__ float s_acc[8][32][17];
     const int tid = threadIdx.x, ci = tid & 31, tl = tid >> 5;
     const int chunk = blockIdx.x;
-    const int c = chunk * 32 + ci;
+    const int b = blockIdx.y / SW_TSPLIT, sp = blockIdx.y % SW_TSPLIT;
     float acc[17];
 #pragma unroll
     for (int j = 0; j < 17; ++j) acc[j] = 0.f;
-    for (int b = 0; b < a.B; ++b) {
-        const size_t prow = ((size_t)b * a.chunks + chunk) * a.Lp + a.halo;
-        for (int t = tl; t < a.L; t += 8) {
-            float p;
-            if (a.P_f32) p = a.P_f32[(prow + t) * 32 + ci];
-            else p = join_bf16(a.P_hi[(prow + t) * 32 + ci], a.P_lo[(prow + t) * 32 + ci]);
+    const size_t prow = ((size_t)b * a.chunks + chunk) * a.Lp + a.halo;
+    for (int t = sp * 8 + tl; t < a.L; t += 8 * SW_TSPLIT) {
+        float p;
+        if (a.P_f32) p = a.P_f32[(prow + t) * 32 + ci];
+        else p = join_bf16(a.P_hi[(prow + t) * 32 + ci], a.P_lo[(prow + t) * 32 + ci]);
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (j < a.J) acc[j] += p * a.Q[((size_t)b * a.Jtot + a.q_off + j) * a.L + t];
-            acc[16] += p;
-        }
+        for (int j = 0; j < 16; ++j)
+            if (j < a.J) acc[j] += p * a.Q[((size_t)b * a.Jtot + a.q_off + j) * a.L + t];
+        acc[16] += p;
     }
 #pragma unroll
     for (int j = 0; j < 17; ++j) s_acc[tl][ci][j] = acc[j];
     __syncthreads();
-    if (tl == 0 && c < a.R) {
-        for (int j = 0; j < a.J; ++j) {
+    if (tl == 0) {
+        float* dst = a.scratch + (((size_t)blockIdx.y * a.chunks + chunk) * 32 + ci) * 17;
+        for (int j = 0; j < 17; ++j) {
             float s = 0.f;
             for (int k = 0; k < 8; ++k) s += s_acc[k][ci][j];
-            if (a.out_transposed) a.out[(size_t)j * a.R + c] = s;      // out[J][R]
-            else a.out[(size_t)c * a.J + j] = s;                        // out[R][J]
-        }
-        if (a.rowsum) {
-            float s = 0.f;
-            for (int k = 0; k < 8; ++k) s += s_acc[k][ci][16];
-            a.rowsum[c] = s;
+            dst[j] = s;
         }
     }
 }
+__global__ void small_wgrad_reduce_kernel(const SmallWgradArgs a, int nparts) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.R) return;
+    float acc[17];
+    for (int j = 0; j < 17; ++j) acc[j] = 0.f;
+    for (int p = 0; p < nparts; ++p) {
+        const float* src = a.scratch + ((size_t)p * a.chunks * 32 + c) * 17;
+        for (int j = 0; j < 17; ++j) acc[j] += src[j];
+    }
+    for (int j = 0; j < a.J; ++j) {
+        if (a.out_transposed) a.out[(size_t)j * a.R + c] = acc[j];
+        else a.out[(size_t)c * a.J + j] = acc[j];
+    }
+    if (a.rowsum) a.rowsum[c] = acc[16];
+}
 hipError_t t2s_launch_small_wgrad(const SmallWgradArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(small_wgrad_kernel, dim3(a.chunks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(small_wgrad_kernel, dim3(a.chunks, a.B * SW_TSPLIT), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(small_wgrad_reduce_kernel, dim3((a.R + 255) / 256), dim3(256), 0, stream, a, a.B * SW_TSPLIT);
     return hipGetLastError();
 }
+size_t t2s_small_wgrad_scratch_floats(int B, int chunks) { return (size_t)B * SW_TSPLIT * chunks * 32 * 17; }
 
 // colsum[j] = sum_{b,t} Q[b][q_off + j][t]    (bias gradient of WN.end)
 __global__ __launch_bounds__(256) void rows_sum_kernel(const float* Q, int B, int Jtot, int q_off, int L, float* out) {

@@ -13,7 +13,8 @@
 static __device__ __forceinline__ void pack_row(const float* __restrict__ vrow, const float* g, int g_is_scale, int o,
                                                  int Cin, int Kt, int perm, int C_gate, int row_off, int Mpad, int koff,
                                                  int Cin_pad, u16* A_hi, u16* A_lo, const float* bias_in,
-                                                 const float* bias_in2, float* bias_out, int bias_accumulate) {
+                                                 const float* bias_in2, float* bias_out, int bias_accumulate,
+                                                 float* scale_out = nullptr) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
     const int n = Cin * Kt;
@@ -32,6 +33,7 @@ static __device__ __forceinline__ void pack_row(const float* __restrict__ vrow, 
         ss = red[0] + red[1] + red[2] + red[3];
         scale = g[o] / sqrtf(ss);
     }
+    if (scale_out && tid == 0) scale_out[o] = scale;
     int p;
     if (perm == PERM_GATE) {
         const int gate = o >= C_gate;
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restri
     const PackJob j = jobs[lo];
     const int o = (int)(blk - j.row_start);
     pack_row(j.v + (size_t)o * j.Cin * j.Kt, j.g, (int)j.g_is_scale, o, (int)j.Cin, (int)j.Kt, (int)j.perm, (int)j.C_gate,
-             (int)j.row_off, (int)j.Mpad, (int)j.koff, (int)j.Cin_pad, j.A_hi, j.A_lo, j.bias_in, j.bias_in2, j.bias_out, 0);
+             (int)j.row_off, (int)j.Mpad, (int)j.koff, (int)j.Cin_pad, j.A_hi, j.A_lo, j.bias_in, j.bias_in2, j.bias_out, 0,
+             j.scale_out);
 }
 hipError_t t2s_launch_pack_table(const PackJob* jobs, int n_jobs, long total_rows, hipStream_t stream) {
     hipLaunchKernelGGL(pack_table_kernel, dim3((unsigned)total_rows), dim3(256), 0, stream, jobs, n_jobs);

@@ -143,7 +143,10 @@ class _Engine:
                         b1=torch.zeros(g["Mpad1"], dtype=torch.float32, device=device),
                         A2h=torch.zeros(g["nk2"], Mpad2, 32, dtype=torch.bfloat16, device=device),
                         A2l=torch.zeros(g["nk2"], Mpad2, 32, dtype=torch.bfloat16, device=device),
-                        b2=torch.zeros(Mpad2, dtype=torch.float32, device=device), Mpad2=Mpad2))
+                        b2=torch.zeros(Mpad2, dtype=torch.float32, device=device), Mpad2=Mpad2,
+                        s_in=torch.empty(2 * C, dtype=torch.float32, device=device),
+                        s_cond=torch.empty(2 * C, dtype=torch.float32, device=device),
+                        s_rs=torch.empty(rows2, dtype=torch.float32, device=device)))
                 flows.append(dict(layers=layers, n_half=n_half,
                                   w_start=torch.empty(C, n_half, dtype=torch.float32, device=device),
                                   w_inv=None))
@@ -164,18 +167,19 @@ class _Engine:
                      _f32c(vr), None if gr is None else _f32c(gr), _f32c(wn.res_skip_layers[i].bias)]
                 srcs += t
                 # (v, g, bias, bias2, A_hi, A_lo, bias_out, O, Cin, Kt, perm, C_gate, Mpad, koff, Cin_pad)
-                specs.append((t[0], t[1], t[2], t[3], ly["A1h"], ly["A1l"], ly["b1"], 2 * C, C, ks, 1, C, g["Mpad1"], 0, g["Cpad"]))
+                specs.append((t[0], t[1], t[2], t[3], ly["A1h"], ly["A1l"], ly["b1"], 2 * C, C, ks, 1, C, g["Mpad1"], 0, g["Cpad"],
+                              ly["s_in"]))
                 specs.append((t[4], t[5], None, None, ly["A1h"], ly["A1l"], None, 2 * C, g["n_cond"], 1, 1, C, g["Mpad1"],
-                              ks * g["Cpad"], g["Spad"]))
+                              ks * g["Cpad"], g["Spad"], ly["s_cond"]))
                 specs.append((t[6], t[7], t[8], None, ly["A2h"], ly["A2l"], ly["b2"], t[6].size(0), C, 1, 0, 0, ly["Mpad2"], 0,
-                              g["Cpad"]))
+                              g["Cpad"], ly["s_rs"]))
         ptr_key = tuple(0 if t is None else t.data_ptr() for t in srcs)
         if self.packed.get("job_key") != ptr_key:
             rows, row_start = [], 0
             dp = lambda t: 0 if t is None else t.data_ptr()
-            for (v, gg, b1, b2, Ah, Al, bo, O, Cin, Kt, perm, Cg, Mpad, koff, Cin_pad) in specs:
+            for (v, gg, b1, b2, Ah, Al, bo, O, Cin, Kt, perm, Cg, Mpad, koff, Cin_pad, so) in specs:
                 rows.append([dp(v), dp(gg), dp(b1), dp(b2), dp(Ah), dp(Al), dp(bo), row_start,
-                             O, Cin, Kt, perm, Cg, Mpad, koff, Cin_pad, 0, 0])
+                             O, Cin, Kt, perm, Cg, Mpad, koff, Cin_pad, 0, 0, dp(so)])
                 row_start += O
             self.packed["jobs"] = torch.tensor(rows, dtype=torch.int64).to(device)
             self.packed["n_jobs"], self.packed["total_rows"] = len(rows), row_start

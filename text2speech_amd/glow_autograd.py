@@ -76,7 +76,7 @@ def _alloc_train(eng, B, L, dev):
     st.A_inT = (_bf(g["ks"] * 2 * C // 32, st.Mc, 32, dev=dev), _bf(g["ks"] * 2 * C // 32, st.Mc, 32, dev=dev))
     st.A_cT = (_bf(2 * C // 32, st.Ms, 32, dev=dev), _bf(2 * C // 32, st.Ms, 32, dev=dev))
     st.zero_bias = torch.zeros(max(st.M2pad, st.Ms, 1024), dtype=torch.float32, device=dev)
-    st.scale = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    st.sw_scratch = torch.empty(_lib.load().t2s_small_wgrad_scratch(B, xc), dtype=torch.float32, device=dev)
     eng.ws[key] = st
     return st
 
@@ -207,14 +207,11 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         if with_bias:
             grads[id(conv.bias)] = db
 
-    def scale_of(conv):
-        v, gg = _vg(conv)
-        v32 = _f32c(v)
-        g32 = None if gg is None else _f32c(gg)
-        sc_ = new(v.size(0))
-        keep.extend([v32, g32, sc_])
-        _lib.call("t2s_weightnorm_scale", _ptr(v32), _ptr(g32), v.size(0), v[0].numel(), _ptr(sc_), st)
-        return v32, sc_
+    def scale_of(conv, saved):
+        """(v, per-row scale g/|v| that this step's forward pack applied and kept)."""
+        v32 = _f32c(_vg(conv)[0])
+        keep.append(v32)
+        return v32, saved
 
     for k in reversed(range(m.n_flows)):
         c_off, n_rem, n_half = eng._flow_geom(k)
@@ -233,7 +230,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         w_end = _f32c(wn.end.weight)
         dW_end = bucket.take(*wn.end.weight.shape)
         db_end = bucket.take(nj)
-        _lib.call("t2s_small_wgrad", None, None, _ptr(ts.skip[k]), _ptr(d_out), _ptr(dW_end), None, B, xc, Lp, halo, L, C, nj,
+        _lib.call("t2s_small_wgrad", None, None, _ptr(ts.skip[k]), _ptr(d_out), _ptr(dW_end), None, _ptr(ts.sw_scratch), B, xc, Lp, halo, L, C, nj,
                   nj, 0, 1, st)
         _lib.call("t2s_rows_sum", _ptr(d_out), B, nj, 0, nj, L, _ptr(db_end), st)
         grads[id(wn.end.weight)] = dW_end
@@ -251,7 +248,8 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             Mrs = _lib.padded_rows(rows2)
             conv_rs, conv_in, conv_c = wn.res_skip_layers[i], wn.in_layers[i], wn.cond_layers[i]
             # 1. d_pre = gate'(T,G) * (W_rs^T [dx ; dS])
-            v_rs, s_rs = scale_of(conv_rs)
+            pk = fl["layers"][i]
+            v_rs, s_rs = scale_of(conv_rs, pk["s_rs"])
             _lib.call("t2s_pack_transposed", _ptr(v_rs), _ptr(s_rs), rows2, C, 1, 0, rows2, ts.Mc, 0, _ptr(ts.A_rsT[0]),
                       _ptr(ts.A_rsT[1]), st)
             _lib.call("t2s_wg_bwd_gate_dgrad", _ptr(ts.A_rsT[0]), _ptr(ts.A_rsT[1]), _ptr(zb),
@@ -281,12 +279,12 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             wn_grads(conv_in, ts.P2, B, 2 * C, ts.N2, 0, C, ts.N2 - 1, 2 * C, C, ks)
             wn_grads(conv_c, ts.P2, B, 2 * C, ts.N2, ks * C, 0, ts.N2 - 1, 2 * C, n_cond, 1)
             # 4. dx (+)= W_in^T (*) d_pre ;  d_spect += W_cond^T d_pre
-            v_in, s_in = scale_of(conv_in)
+            v_in, s_in = scale_of(conv_in, pk["s_in"])
             _lib.call("t2s_pack_transposed", _ptr(v_in), _ptr(s_in), 2 * C, C, ks, 1, 2 * C, ts.Mc, 0, _ptr(ts.A_inT[0]),
                       _ptr(ts.A_inT[1]), st)
             _lib.call("t2s_conv_accumulate", _ptr(ts.A_inT[0]), _ptr(ts.A_inT[1]), _ptr(zb), _ptr(ts.DP[0]), _ptr(ts.DP[1]),
                       _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, 2 * C, C, ks, d, 1 if last else 0, L, Lp, halo, ts.Mc, st)
-            v_c, s_c = scale_of(conv_c)
+            v_c, s_c = scale_of(conv_c, pk["s_cond"])
             _lib.call("t2s_pack_transposed", _ptr(v_c), _ptr(s_c), 2 * C, n_cond, 1, 0, 2 * C, ts.Ms, 0, _ptr(ts.A_cT[0]),
                       _ptr(ts.A_cT[1]), st)
             _lib.call("t2s_conv_accumulate", _ptr(ts.A_cT[0]), _ptr(ts.A_cT[1]), _ptr(zb), _ptr(ts.DP[0]), _ptr(ts.DP[1]),
@@ -295,7 +293,8 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         # ---- WN.start ----
         dW_eff = new(C, n_half)
         db_start = bucket.take(C)
-        _lib.call("t2s_small_wgrad", _ptr(ts.DX[0]), _ptr(ts.DX[1]), None, _ptr(zw), _ptr(dW_eff), _ptr(db_start), B, xc, Lp,
+        _lib.call("t2s_small_wgrad", _ptr(ts.DX[0]), _ptr(ts.DX[1]), None, _ptr(zw), _ptr(dW_eff), _ptr(db_start),
+                  _ptr(ts.sw_scratch), B, xc, Lp,
                   halo, L, C, n_half, G, c_off, 0, st)
         wn_grads(wn.start, dW_eff, 1, C, n_half, 0, 0, 0, C, n_half, 1, with_bias=False)
         grads[id(wn.start.bias)] = db_start
