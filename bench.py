@@ -167,13 +167,23 @@ def main():
         L = args.segment // cfg["n_group"]
         flops_per_launch = 2.0 * (2 * C) * (ks * C + n_cond) * args.batch * L
         roof = None
-        if evs:
+        if evs and args.mode == "forward":
             ms = [a.elapsed_time(b) for a, b in evs]
             avg_ms = sum(ms) / len(ms)
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            # HBM-side bytes per launch of this kernel come from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+            # --pmc WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note): profiles/r01_pmc_traffic.json
+            traffic = None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                traffic = pm["kernels"]["void conv_gemm_kernel<0>(ConvGemmArgs)"]["traffic_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"bound": "mfma", "kernel": "conv_gemm_kernel<EPI_GATE> (in_layers+cond_layers+gate)",
                     "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                    "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                    "traffic_note": "bytes/launch at batch 8x16000 from profiles/r01_pmc_traffic.json (separate --pmc passes); "
+                                    "compulsory bytes are 83 MB read + 33 MB written",
                     "avg_launch_ms": avg_ms, "launches": len(ms), "algorithmic_flops_per_launch": flops_per_launch,
                     "note": "split-bf16: 3 bf16 MFMA products per algorithmic MAC, so frac <= 1/3 by construction"}
         total_samples = args.gpus * args.batch * args.segment * args.steps
