@@ -111,6 +111,31 @@ int t2s_wg_res_skip(const void* A_hi, const void* A_lo, const float* bias, const
 int t2s_wg_end_affine(const float* skip, const float* w_end, const float* b_end, float* z, float* log_s,
                       float* wn_out, int B, int n_group, int c_off, int n_half, int C, int L, int Lp, int halo, int reverse, void* stream);
 
+/* ---- WN.end folded into the skip path (no-grad forward / infer) ----
+ * end(sum_i skip_i) = sum_i (W_end W_skip,i) acts_i + const (reference glow.py:172-175), and W_end W_skip,i is only
+ * [2*n_half x C]: the skip half of res_skip_layers and the f32 skip accumulator are never materialised. */
+typedef struct t2s_endfold_job {
+    const float *w_end, *v_skip, *scale, *b_skip;   /* [nj][C], [C][C] skip rows of weight_v, their g/|v|, their bias */
+    void* fold_A;                                   /* out: MFMA A fragments, 8192*ceil(C/128) bf16, zero-initialised */
+    float* bes;                                     /* out: [8] */
+    long nj, C;
+} t2s_endfold_job;
+/* jobs: DEVICE array, one per WN layer; run after the weight packing that produced `scale` */
+int t2s_wg_endfold_weights(const t2s_endfold_job* jobs, int n_jobs, int C, void* stream);
+/* t2s_wg_in_cond_gate plus fold_acc[slot][b][j][t] (+)= (W_end W_skip,i)[j] . acts[:, t] over the slot's 64 channels;
+ * slot count = 2*ceil(C/128); C % 16 == 0 */
+int t2s_wg_in_cond_gate_fold(const void* A_hi, const void* A_lo, const float* bias, const void* X_hi, const void* X_lo,
+                             const void* S_hi, const void* S_lo, void* acts_hi, void* acts_lo, const void* fold_A,
+                             float* fold_acc, int fold_init, int B, int C, int n_cond, int taps, int dilation, int L,
+                             int Lp, int halo, int Mpad, void* stream);
+/* residual half only: x += W_res acts + b  (rows [0, C) of the packed res_skip weights; 128-row tiles) */
+int t2s_wg_res_only(const void* A_hi, const void* A_lo, const float* bias, const void* acts_hi, const void* acts_lo,
+                    void* X_hi, void* X_lo, int B, int C, int L, int Lp, int halo, int Mpad, void* stream);
+/* WN.end output from the folded accumulators + affine coupling (forward or reverse) */
+int t2s_wg_end_fold_affine(const float* fold_acc, int nslots, const float* bes, int n_layers, const float* b_end,
+                           float* z, float* log_s, int B, int n_group, int c_off, int n_half, int L, int reverse,
+                           void* stream);
+
 /* Generic split-bf16 conv1d-as-GEMM with bias + activation epilogue:
  *   out[b][o][t] = act(bias[o] + sum_{tap,c} W[o][c][tap] * x[b][c][t + (tap - taps/2)*dil])
  * A planes packed with T2S_PERM_NONE.  Writes planes O_hi/O_lo (may be NULL) and/or out_f32 (may be NULL),

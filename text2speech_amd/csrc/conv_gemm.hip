@@ -32,8 +32,7 @@
 #include "t2s_common.h"
 #include "t2s_kernels.h"
 
-#define STAGE_BYTES 65536
-#define PLANE_BYTES 16384
+#define B_PLANE_BYTES 16384          // one B (activation) plane tile: 256 rows x 64 B
 
 static __device__ __forceinline__ int swz4(int rb) {      // {0,2,3,1}[rb]
     return (0x78 >> (rb * 2)) & 3;                        // 0b01'11'10'00
@@ -44,8 +43,12 @@ static __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int EPI>
+// MT = rows of the M (output-channel) tile: 256, or 128 for short GEMMs that would otherwise leave CUs idle.
+template <int EPI, int MT>
 __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a) {
+    constexpr int A_PLANE = MT * 64;                 // bytes of one A plane tile
+    constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE_BYTES;
+    constexpr int MW = MT / 32;                      // 16-row MFMA tiles per wave (waves are 2 (M) x 4 (N))
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -67,8 +70,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     // LDS linear slot p = j*512 + tid (16 B each): row = p>>2 = j*128 + (tid>>2), slot q = tid&3.
     // The slot holds logical k-chunk q ^ s[(row>>2)&3]; (row>>2)&3 == (tid>>4)&3 for both j.
     const int thr_off = (tid >> 2) * 64 + (((tid & 3) ^ swz4((tid >> 4) & 3)) * 16);
-    const char* A_hi = (const char*)a.A_hi + (size_t)b * a.a_bstride * 2 + (size_t)mt * T2S_TILE_M * 64 + thr_off;
-    const char* A_lo = (const char*)a.A_lo + (size_t)b * a.a_bstride * 2 + (size_t)mt * T2S_TILE_M * 64 + thr_off;
+    const char* A_hi = (const char*)a.A_hi + (size_t)b * a.a_bstride * 2 + (size_t)mt * MT * 64 + thr_off;
+    const char* A_lo = (const char*)a.A_lo + (size_t)b * a.a_bstride * 2 + (size_t)mt * MT * 64 + thr_off;
     const size_t a_kstride = (size_t)a.Mpad * 64;
     const size_t x_cstride = (size_t)a.Lp * 64;            // bytes per 32-channel chunk
     const char* X_hi = (const char*)a.X_hi + ((size_t)b * a.xc * a.Lp + a.halo + t0) * 64 + thr_off;
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     char* lds_wave = smem + wave * 1024;                   // + lane*16 is implicit in the DMA
 
     auto stage = [&](int ks, int buf) {
-        char* dst = lds_wave + buf * STAGE_BYTES;
+        char* dst = lds_wave + buf * STAGE;
         const char* ah = A_hi + (size_t)ks * a_kstride;
         const char* al = A_lo + (size_t)ks * a_kstride;
         const char *bh, *bl;
@@ -94,23 +97,23 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
             bl = S_lo + off;
         }
         glds16(ah, dst);
-        glds16(ah + 8192, dst + 8192);
-        glds16(al, dst + PLANE_BYTES);
-        glds16(al + 8192, dst + PLANE_BYTES + 8192);
-        glds16(bh, dst + 2 * PLANE_BYTES);
-        glds16(bh + 8192, dst + 2 * PLANE_BYTES + 8192);
-        glds16(bl, dst + 3 * PLANE_BYTES);
-        glds16(bl + 8192, dst + 3 * PLANE_BYTES + 8192);
+        if (MT == 256) glds16(ah + 8192, dst + 8192);
+        glds16(al, dst + A_PLANE);
+        if (MT == 256) glds16(al + 8192, dst + A_PLANE + 8192);
+        glds16(bh, dst + 2 * A_PLANE);
+        glds16(bh + 8192, dst + 2 * A_PLANE + 8192);
+        glds16(bl, dst + 2 * A_PLANE + B_PLANE_BYTES);
+        glds16(bl + 8192, dst + 2 * A_PLANE + B_PLANE_BYTES + 8192);
     };
 
     // ---- per-lane fragment read offset: row = lane&15, logical k-chunk = lane>>4 ----
     const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ swz4((lane >> 2) & 3)) * 16);
-    const int a_frag = wr * 128 * 64 + frag_off;
-    const int b_frag = 2 * PLANE_BYTES + wc * 64 * 64 + frag_off;
+    const int a_frag = wr * (MT / 2) * 64 + frag_off;
+    const int b_frag = 2 * A_PLANE + wc * 64 * 64 + frag_off;
 
-    f32x4 acc[8][4];
+    f32x4 acc[MW][4];
 #pragma unroll
-    for (int m = 0; m < 8; ++m)
+    for (int m = 0; m < MW; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -122,17 +125,17 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     for (int ks = 0; ks < nk; ++ks) {
         const int cur = ks & 1;
         if (ks + 1 < nk) stage(ks + 1, cur ^ 1);
-        const char* sb = smem + cur * STAGE_BYTES;
+        const char* sb = smem + cur * STAGE;
         bf16x8 bh[4], bl[4];
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             bh[n] = *(const bf16x8*)(sb + b_frag + n * 1024);
-            bl[n] = *(const bf16x8*)(sb + b_frag + PLANE_BYTES + n * 1024);
+            bl[n] = *(const bf16x8*)(sb + b_frag + B_PLANE_BYTES + n * 1024);
         }
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
+        for (int m = 0; m < MW; ++m) {
             const bf16x8 ah = *(const bf16x8*)(sb + a_frag + m * 1024);
-            const bf16x8 al = *(const bf16x8*)(sb + a_frag + PLANE_BYTES + m * 1024);
+            const bf16x8 al = *(const bf16x8*)(sb + a_frag + A_PLANE + m * 1024);
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
 #pragma unroll
@@ -147,52 +150,98 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     // ---- epilogue.  C/D map of mfma 16x16: col = lane&15 (time), row = 4*(lane>>4) + reg (channel) ----
     const int tcol = lane & 15;
     const int rq = (lane >> 4) * 4;
-    if (EPI == EPI_GATE) {
-        // packed rows of this wave: m even = tanh rows, m odd = sigmoid rows of the same 16 channels
+    if (EPI == EPI_GATE && MT == 256) {
+        // packed rows of this wave: m even = tanh rows, m odd = sigmoid rows of the same 16 channels.
+        // WN.end folded in (a.fold_A): the 8 x C matrix (W_end W_skip,i) times this wave's 64 gate-output channels is
+        // itself a small GEMM whose B operand is the gate output as it sits in the accumulator layout (col = time on
+        // the lane, 4 consecutive channels per 16-lane group): two 16-channel tiles form one K = 32 step, with the
+        // matching K permutation baked into fold_A by endfold_weights_kernel.  3 MFMAs per (pair, n), no shuffles.
+        f32x4 facc[4];
 #pragma unroll
-        for (int mp = 0; mp < 4; ++mp) {
-            const int prow = mt * T2S_TILE_M + wr * 128 + mp * 32 + rq;       // tanh rows prow..prow+3
-            const f32x4 bt = *(const f32x4*)(a.bias + prow);
-            const f32x4 bs = *(const f32x4*)(a.bias + prow + 16);
-            const int ch = mt * 128 + wr * 64 + mp * 16 + rq;                  // channels ch..ch+3
-            if (ch >= a.C) continue;
-            u16* ohi = a.O_hi + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
-            u16* olo = a.O_lo + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+        for (int n = 0; n < 4; ++n) facc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {
+            u16x4 hv[2][4], lv[2][4];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int mp = pair * 2 + half;
+                const int prow = mt * MT + wr * 128 + mp * 32 + rq;               // tanh rows prow..prow+3
+                const f32x4 bt = *(const f32x4*)(a.bias + prow);
+                const f32x4 bs = *(const f32x4*)(a.bias + prow + 16);
+                const int ch = mt * 128 + wr * 64 + mp * 16 + rq;                  // channels ch..ch+3
+                const bool chv = ch < a.C;
+                const size_t obase = (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int t = t0 + wc * 64 + n * 16 + tcol;
+                    u16x4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
+                    if (chv && t < a.L) {
+                        u16x4 thi, tlo, ghi, glo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float tv = fast_tanh(acc[2 * mp][n][e] + bt[e]);
+                            const float gv = fast_sigmoid(acc[2 * mp + 1][n][e] + bs[e]);
+                            u16 h, l;
+                            split_bf16(tv * gv, h, l);
+                            hi[e] = h;
+                            lo[e] = l;
+                            split_bf16(tv, h, l);
+                            thi[e] = h;
+                            tlo[e] = l;
+                            split_bf16(gv, h, l);
+                            ghi[e] = h;
+                            glo[e] = l;
+                        }
+                        const size_t o = obase + (size_t)t * 32;
+                        *(u16x4*)(a.O_hi + o) = hi;
+                        *(u16x4*)(a.O_lo + o) = lo;
+                        if (a.T_hi) {      // training: keep tanh / sigmoid for the backward pass
+                            *(u16x4*)(a.T_hi + o) = thi;
+                            *(u16x4*)(a.T_lo + o) = tlo;
+                            *(u16x4*)(a.G_hi + o) = ghi;
+                            *(u16x4*)(a.G_lo + o) = glo;
+                        }
+                    }
+                    hv[half][n] = hi;
+                    lv[half][n] = lo;
+                }
+            }
+            if (a.fold_A) {
+                const u16* fa = a.fold_A + ((size_t)((mt * 2 + wr) * 2 + pair) * 2 * 64 + lane) * 8;
+                const bf16x8 wh = *(const bf16x8*)fa;
+                const bf16x8 wl = *(const bf16x8*)(fa + 64 * 8);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+                    const u16x8 bh8 = {hv[0][n][0], hv[0][n][1], hv[0][n][2], hv[0][n][3],
+                                       hv[1][n][0], hv[1][n][1], hv[1][n][2], hv[1][n][3]};
+                    const u16x8 bl8 = {lv[0][n][0], lv[0][n][1], lv[0][n][2], lv[0][n][3],
+                                       lv[1][n][0], lv[1][n][1], lv[1][n][2], lv[1][n][3]};
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, bh8);
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, bl8);
+                    facc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, bh, facc[n], 0, 0, 0);
+                    facc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bl, facc[n], 0, 0, 0);
+                    facc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bh, facc[n], 0, 0, 0);
+                }
+            }
+        }
+        if (a.fold_A && lane < 32) {     // D rows j = 4*(lane>>4) + reg < 8, col = time
+            const int slot = mt * 2 + wr;
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const int t = t0 + wc * 64 + n * 16 + tcol;
                 if (t >= a.L) continue;
-                u16x4 hi, lo, thi, tlo, ghi, glo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float tv = fast_tanh(acc[2 * mp][n][e] + bt[e]);
-                    const float gv = fast_sigmoid(acc[2 * mp + 1][n][e] + bs[e]);
-                    u16 h, l;
-                    split_bf16(tv * gv, h, l);
-                    hi[e] = h;
-                    lo[e] = l;
-                    split_bf16(tv, h, l);
-                    thi[e] = h;
-                    tlo[e] = l;
-                    split_bf16(gv, h, l);
-                    ghi[e] = h;
-                    glo[e] = l;
-                }
-                *(u16x4*)(ohi + (size_t)t * 32) = hi;
-                *(u16x4*)(olo + (size_t)t * 32) = lo;
-                if (a.T_hi) {      // training: keep tanh / sigmoid for the backward pass
-                    const size_t o = (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo + t) * 32 + (ch & 31);
-                    *(u16x4*)(a.T_hi + o) = thi;
-                    *(u16x4*)(a.T_lo + o) = tlo;
-                    *(u16x4*)(a.G_hi + o) = ghi;
-                    *(u16x4*)(a.G_lo + o) = glo;
+                    float* dst = a.fold_acc + ((((size_t)slot * a.B + b) * 8 + rq + e) * a.L + t);
+                    *dst = a.fold_init ? facc[n][e] : *dst + facc[n][e];
                 }
             }
         }
     } else if (EPI == EPI_RESSKIP) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int prow = mt * T2S_TILE_M + wr * 128 + m * 16 + rq;
+        for (int m = 0; m < MW; ++m) {
+            const int prow = mt * MT + wr * (MT / 2) + m * 16 + rq;
             const f32x4 bv = *(const f32x4*)(a.bias + prow);
             if (prow < a.n_res) {
                 const int ch = prow;
@@ -239,8 +288,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
         //   d_pre[c]     = d_acts * g * (1 - t^2)        (tanh half)
         //   d_pre[C + c] = d_acts * t * g * (1 - g)      (sigmoid half)     -> planes with 2C channels
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int ch = mt * T2S_TILE_M + wr * 128 + m * 16 + rq;
+        for (int m = 0; m < MW; ++m) {
+            const int ch = mt * MT + wr * (MT / 2) + m * 16 + rq;
             if (ch >= a.C) continue;
             const int ch2 = ch + a.C;
             const size_t tgb = (((size_t)b * a.tc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
@@ -275,8 +324,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
         }
     } else {   // EPI_BIAS_ACT: out = act(acc + bias) -> planes (and optional f32 [B][C][L] copy)
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int ch = mt * T2S_TILE_M + wr * 128 + m * 16 + rq;
+        for (int m = 0; m < MW; ++m) {
+            const int ch = mt * MT + wr * (MT / 2) + m * 16 + rq;
             if (ch >= a.C) continue;
             const f32x4 bv = *(const f32x4*)(a.bias + ch);
             u16* ohi = a.O_hi ? a.O_hi + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31) : nullptr;
@@ -309,27 +358,29 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     }
 }
 
-static hipError_t launch(const ConvGemmArgs& a, int epi, hipStream_t stream) {
+template <int EPI, int MT>
+static hipError_t launch_one(const ConvGemmArgs& a, hipStream_t stream) {
     const int nwg = a.n_mtiles * a.n_ttiles * a.B;
-    const size_t lds = 2 * STAGE_BYTES;
-    hipError_t e;
-#define T2S_LAUNCH(E)                                                                                            \
-    do {                                                                                                         \
-        static bool attr_set = false;                                                                            \
-        if (!attr_set) {                                                                                         \
-            e = hipFuncSetAttribute((const void*)conv_gemm_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds);                                                                   \
-            if (e != hipSuccess) return e;                                                                       \
-            attr_set = true;                                                                                     \
-        }                                                                                                        \
-        hipLaunchKernelGGL(conv_gemm_kernel<E>, dim3(nwg), dim3(512), lds, stream, a);                           \
-    } while (0)
-    if (epi == EPI_GATE) T2S_LAUNCH(EPI_GATE);
-    else if (epi == EPI_RESSKIP) T2S_LAUNCH(EPI_RESSKIP);
-    else if (epi == EPI_GATE_BWD) T2S_LAUNCH(EPI_GATE_BWD);
-    else T2S_LAUNCH(EPI_BIAS_ACT);
-#undef T2S_LAUNCH
+    constexpr size_t lds = 2 * (2 * MT * 64 + 2 * B_PLANE_BYTES);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<EPI, MT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_gemm_kernel<EPI, MT>), dim3(nwg), dim3(512), lds, stream, a);
     return hipGetLastError();
 }
 
-hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a, int epi, hipStream_t stream) { return launch(a, epi, stream); }
+// a.n_mtiles must have been computed for the same tile height `mt_rows` (256 or 128)
+hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a, int epi, hipStream_t stream, int mt_rows) {
+    if (mt_rows == 128) {
+        if (epi == EPI_RESSKIP) return launch_one<EPI_RESSKIP, 128>(a, stream);
+        return hipErrorInvalidValue;
+    }
+    if (epi == EPI_GATE) return launch_one<EPI_GATE, 256>(a, stream);
+    if (epi == EPI_RESSKIP) return launch_one<EPI_RESSKIP, 256>(a, stream);
+    if (epi == EPI_GATE_BWD) return launch_one<EPI_GATE_BWD, 256>(a, stream);
+    return launch_one<EPI_BIAS_ACT, 256>(a, stream);
+}

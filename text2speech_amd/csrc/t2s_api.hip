@@ -165,6 +165,69 @@ int t2s_wg_res_skip(const void* A_hi, const void* A_lo, const float* bias, const
     return T2S_OK;
 }
 
+int t2s_wg_endfold_weights(const t2s_endfold_job* jobs, int n_jobs, int C, void* stream) {
+    if (!jobs || n_jobs <= 0 || C <= 0 || (size_t)8 * C * sizeof(float) > 60 * 1024) return T2S_EINVAL;
+    static_assert(sizeof(t2s_endfold_job) == sizeof(EndFoldJob), "t2s_endfold_job layout");
+    T2S_CHECK_HIP(t2s_launch_endfold_weights((const EndFoldJob*)jobs, n_jobs, C, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_wg_in_cond_gate_fold(const void* A_hi, const void* A_lo, const float* bias, const void* X_hi, const void* X_lo,
+                             const void* S_hi, const void* S_lo, void* acts_hi, void* acts_lo, const void* fold_A,
+                             float* fold_acc, int fold_init, int B, int C, int n_cond, int taps, int dilation, int L,
+                             int Lp, int halo, int Mpad, void* stream) {
+    if (!check_planes(A_hi, A_lo) || !check_planes(X_hi, X_lo) || !check_planes(acts_hi, acts_lo) || !bias) return T2S_EINVAL;
+    if (!fold_A || !fold_acc || !aligned16(fold_A) || C % 16) return T2S_EINVAL;
+    if (n_cond > 0 && !check_planes(S_hi, S_lo)) return T2S_EINVAL;
+    if (B <= 0 || L <= 0 || C <= 0 || C % 4 || taps <= 0 || !(taps & 1) || dilation <= 0) return T2S_EINVAL;
+    if ((taps / 2) * dilation > halo || Lp != t2s_plane_rows(L, halo)) return T2S_EINVAL;
+    if (Mpad % 256 || Mpad < cdiv(C, 128) * 256 || !aligned16(bias)) return T2S_EINVAL;
+    ConvGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A_hi = (const u16*)A_hi; a.A_lo = (const u16*)A_lo;
+    a.X_hi = (const u16*)X_hi; a.X_lo = (const u16*)X_lo;
+    a.S_hi = (const u16*)S_hi; a.S_lo = (const u16*)S_lo;
+    a.bias = bias; a.O_hi = (u16*)acts_hi; a.O_lo = (u16*)acts_lo;
+    a.fold_A = (const u16*)fold_A; a.fold_acc = fold_acc; a.fold_init = fold_init;
+    a.xc = cdiv(C, 32); a.sc = cdiv(n_cond, 32); a.oc = cdiv(C, 32);
+    a.taps = taps; a.dil = dilation;
+    a.nk_x = taps * a.xc; a.nk = a.nk_x + a.sc;
+    a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
+    a.n_mtiles = cdiv(C, 128); a.n_ttiles = cdiv(L, 256);
+    a.C = C;
+    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_GATE, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_wg_res_only(const void* A_hi, const void* A_lo, const float* bias, const void* acts_hi, const void* acts_lo,
+                    void* X_hi, void* X_lo, int B, int C, int L, int Lp, int halo, int Mpad, void* stream) {
+    if (!check_planes(A_hi, A_lo) || !check_planes(acts_hi, acts_lo) || !check_planes(X_hi, X_lo) || !bias) return T2S_EINVAL;
+    if (B <= 0 || L <= 0 || C <= 0 || C % 4 || Lp != t2s_plane_rows(L, halo) || Mpad % 256 || Mpad < C || !aligned16(bias))
+        return T2S_EINVAL;
+    ConvGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A_hi = (const u16*)A_hi; a.A_lo = (const u16*)A_lo;
+    a.X_hi = (const u16*)acts_hi; a.X_lo = (const u16*)acts_lo;
+    a.bias = bias; a.O_hi = (u16*)X_hi; a.O_lo = (u16*)X_lo;
+    a.xc = cdiv(C, 32); a.sc = 0; a.oc = cdiv(C, 32);
+    a.taps = 1; a.dil = 1; a.nk_x = a.xc; a.nk = a.xc;
+    a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
+    a.n_mtiles = cdiv(C, 128); a.n_ttiles = cdiv(L, 256);
+    a.C = 0; a.n_res = C;
+    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_RESSKIP, (hipStream_t)stream, 128));
+    return T2S_OK;
+}
+
+int t2s_wg_end_fold_affine(const float* fold_acc, int nslots, const float* bes, int n_layers, const float* b_end,
+                           float* z, float* log_s, int B, int n_group, int c_off, int n_half, int L, int reverse,
+                           void* stream) {
+    if (!fold_acc || !bes || !b_end || !z || nslots <= 0 || n_layers <= 0) return T2S_EINVAL;
+    if (B <= 0 || L <= 0 || n_half <= 0 || n_half > 4 || c_off < 0 || c_off + 2 * n_half > n_group) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_end_fold_affine(fold_acc, nslots, bes, n_layers, b_end, z, log_s, B, n_group, c_off, n_half,
+                                             L, reverse, (hipStream_t)stream));
+    return T2S_OK;
+}
+
 int t2s_wg_end_affine(const float* skip, const float* w_end, const float* b_end, float* z, float* log_s,
                       float* wn_out, int B, int n_group, int c_off, int n_half, int C, int L, int Lp, int halo, int reverse, void* stream) {
     if (!skip || !w_end || !b_end || !z) return T2S_EINVAL;

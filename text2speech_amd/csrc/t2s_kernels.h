@@ -42,9 +42,13 @@ struct ConvGemmArgs {
     const u16* R_hi;   // RESSKIP: residual source planes (null: read the output planes, i.e. in place)
     const u16* R_lo;
     long a_bstride;    // elements between the A operands of consecutive batch entries (0: shared weights)
+    // GATE with WN.end folded in: fold_acc[slot][b][j][t] (+)= sum_c fold_w[c][j] * acts[c][t]
+    const u16* fold_A;     // (W_end . W_skip_i) as MFMA A fragments [mt][wr][pair][hi,lo][lane][8] (endfold_weights_kernel)
+    float* fold_acc;       // [2*n_mtiles][B][8][L]
+    int fold_init;         // 1: store, 0: accumulate (first / later layers of a flow)
 };
 
-hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a, int epi, hipStream_t stream);
+hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a, int epi, hipStream_t stream, int mt_rows = 256);
 
 struct PackArgs {
     const float* v;        // [O][Cin][Kt]
@@ -85,6 +89,19 @@ hipError_t t2s_launch_small_logdet_inv(const float* W, int n, float scale, float
                                        hipStream_t stream);
 hipError_t t2s_launch_start(const float* z, const float* w, const float* bias, int B, int n_group, int c_off,
                             int n_half, int C, int L, int Lp, int halo, u16* X_hi, u16* X_lo, hipStream_t stream);
+struct EndFoldJob {        // one WN layer: fold_w[c][j] = sum_o W_end[j][o] * scale[o] * v_skip[o][c]
+    const float* w_end;    // [nj][C]
+    const float* v_skip;   // [C][C] skip rows of res_skip_layers[i].weight_v (or weight)
+    const float* scale;    // [C] per-row weight-norm scale of those rows
+    const float* b_skip;   // [C]
+    u16* fold_A;           // [C/128][2][2][2][64][8] bf16: MFMA A fragments (rows j, K permuted to the accumulator layout)
+    float* bes;            // [8]: W_end . b_skip
+    long nj, C;
+};
+hipError_t t2s_launch_endfold_weights(const EndFoldJob* jobs, int n_jobs, int C, hipStream_t stream);
+hipError_t t2s_launch_end_fold_affine(const float* fold_acc, int nslots, const float* bes, int n_layers,
+                                      const float* b_end, float* z, float* log_s, int B, int n_group, int c_off,
+                                      int n_half, int L, int reverse, hipStream_t stream);
 hipError_t t2s_launch_end_affine(const float* skip, const float* w_end, const float* b_end, float* z, float* log_s,
                                  float* wn_out, int B, int n_group, int c_off, int n_half, int C, int L, int Lp, int halo,
                                  int reverse, hipStream_t stream);

@@ -410,3 +410,88 @@ hipError_t t2s_launch_end_affine(const float* skip, const float* w_end, const fl
                        n_group, c_off, n_half, C, L, Lp, halo, reverse);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// WN.end folded into the skip path (forward / infer without autograd).  The skip sum only ever feeds
+// WN.end (reference glow.py:172-175):  end(sum_i skip_i) = sum_i (W_end W_skip,i) acts_i + W_end sum_i b_skip,i + b_end,
+// and W_end W_skip,i is only [2*n_half x C].  So the skip half of every res_skip GEMM (9 % of the FLOPs)
+// and the f32 skip accumulator (2 x 33 MB of traffic per layer) disappear; the gate GEMM's epilogue
+// applies the 8-row product to the gate outputs it already holds in registers.
+__global__ __launch_bounds__(256) void endfold_weights_kernel(const EndFoldJob* __restrict__ jobs, int C) {
+    extern __shared__ float s_ws[];              // [8][C]: W_end[j][o] * scale[o]
+    __shared__ float red[4];
+    const EndFoldJob j = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int nj = (int)j.nj;
+    for (int i = tid; i < 8 * C; i += 256) {
+        const int r = i / C, o = i - r * C;
+        s_ws[i] = (r < nj) ? j.w_end[(size_t)r * C + o] * (j.scale ? j.scale[o] : 1.f) : 0.f;
+    }
+    __syncthreads();
+    const int c = blockIdx.y * 256 + tid;
+    if (c < C) {
+        float acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+        for (int o = 0; o < C; ++o) {
+            const float v = j.v_skip[(size_t)o * C + c];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] += s_ws[r * C + o] * v;
+        }
+        // scatter into the A-fragment layout the gate epilogue reads: lane = q*16 + row j, element e = half*4 + reg
+        const int mt = c >> 7, wr = (c >> 6) & 1, pair = (c >> 5) & 1, half = (c >> 4) & 1, q = (c >> 2) & 3, reg = c & 3;
+        u16* base = j.fold_A + ((size_t)((mt * 2 + wr) * 2 + pair) * 2 * 64) * 8;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            u16 h, l;
+            split_bf16(acc[r], h, l);
+            const int lane = q * 16 + r;
+            base[(size_t)lane * 8 + half * 4 + reg] = h;
+            base[(size_t)(64 + lane) * 8 + half * 4 + reg] = l;
+        }
+    }
+    if (blockIdx.y == 0) {
+        for (int r = 0; r < 8; ++r) {
+            float s = 0.f;
+            if (r < nj)
+                for (int o = tid; o < C; o += 256) s += j.w_end[(size_t)r * C + o] * j.b_skip[o];
+            s = wave_sum(s);
+            __syncthreads();
+            if ((tid & 63) == 0) red[tid >> 6] = s;
+            __syncthreads();
+            if (tid == 0) j.bes[r] = red[0] + red[1] + red[2] + red[3];
+        }
+    }
+}
+hipError_t t2s_launch_endfold_weights(const EndFoldJob* jobs, int n_jobs, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(endfold_weights_kernel, dim3(n_jobs, (C + 255) / 256), dim3(256), (size_t)8 * C * sizeof(float),
+                       stream, jobs, C);
+    return hipGetLastError();
+}
+
+// out[j][t] = b_end[j] + sum_layers bes[layer][j] + sum_slots fold_acc[slot][b][j][t], then the affine coupling
+// (reference glow.py:175,241-246; reverse: glow.py:276-280)
+__global__ void end_fold_affine_kernel(const float* __restrict__ fold_acc, int nslots, const float* __restrict__ bes,
+                                       int n_layers, const float* __restrict__ b_end, float* z, float* log_s, int B, int G,
+                                       int c_off, int nh, int L, int reverse) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y, b = blockIdx.z;
+    if (t >= L) return;
+    float bb = b_end[i], ls = b_end[nh + i];
+    for (int l = 0; l < n_layers; ++l) { bb += bes[l * 8 + i]; ls += bes[l * 8 + nh + i]; }
+    for (int s = 0; s < nslots; ++s) {
+        bb += fold_acc[(((size_t)s * B + b) * 8 + i) * L + t];
+        ls += fold_acc[(((size_t)s * B + b) * 8 + nh + i) * L + t];
+    }
+    float* zp = z + ((size_t)b * G + c_off + nh + i) * L + t;
+    const float a1 = *zp;
+    *zp = reverse ? (a1 - bb) / expf(ls) : expf(ls) * a1 + bb;
+    if (log_s) log_s[((size_t)b * nh + i) * L + t] = ls;
+}
+hipError_t t2s_launch_end_fold_affine(const float* fold_acc, int nslots, const float* bes, int n_layers,
+                                      const float* b_end, float* z, float* log_s, int B, int n_group, int c_off,
+                                      int n_half, int L, int reverse, hipStream_t stream) {
+    hipLaunchKernelGGL(end_fold_affine_kernel, dim3((L + 255) / 256, n_half, B), dim3(256), 0, stream, fold_acc, nslots, bes,
+                       n_layers, b_end, z, log_s, B, n_group, c_off, n_half, L, reverse);
+    return hipGetLastError();
+}

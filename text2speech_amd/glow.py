@@ -105,6 +105,7 @@ class _Engine:
         self.packed = None
         self.packed_key = None
         self.ws = {}
+        self.use_fold = True        # no-grad forward / infer: WN.end folded into the skip path (t2s_wg_*_fold)
         self.grad_sync = None       # distributed.GradSync: bucketed RCCL all-reduce issued from inside backward
         self.gemm_events = None     # bench.py: list of (start, end) torch.cuda.Event pairs around the gate GEMM
 
@@ -146,8 +147,9 @@ class _Engine:
                         b2=torch.zeros(Mpad2, dtype=torch.float32, device=device), Mpad2=Mpad2,
                         s_in=torch.empty(2 * C, dtype=torch.float32, device=device),
                         s_cond=torch.empty(2 * C, dtype=torch.float32, device=device),
-                        s_rs=torch.empty(rows2, dtype=torch.float32, device=device)))
-                flows.append(dict(layers=layers, n_half=n_half,
+                        s_rs=torch.empty(rows2, dtype=torch.float32, device=device),
+                        fold_A=torch.zeros(-(-C // 128) * 8192, dtype=torch.bfloat16, device=device)))
+                flows.append(dict(layers=layers, n_half=n_half, bes=torch.zeros(nl, 8, dtype=torch.float32, device=device),
                                   w_start=torch.empty(C, n_half, dtype=torch.float32, device=device),
                                   w_inv=None))
             self.packed = dict(flows=flows, device=device)
@@ -186,7 +188,27 @@ class _Engine:
             self.packed["job_key"] = ptr_key
         _lib.call("t2s_pack_conv_weight_table", _lib.ptr(self.packed["jobs"]), self.packed["n_jobs"],
                   self.packed["total_rows"], st)
-        keep = srcs
+        # WN.end folded into the skip path: (W_end . W_skip_i)^T per layer, from the scales the pack just wrote
+        fsrc = []
+        for k in range(m.n_flows):
+            wn = m.WN[k]
+            fl = self.packed["flows"][k]
+            w_end = _f32c(wn.end.weight)
+            for i in range(nl):
+                vr = _f32c(_vg(wn.res_skip_layers[i])[0])
+                br = _f32c(wn.res_skip_layers[i].bias)
+                r0 = C if i < nl - 1 else 0
+                fsrc.append((w_end, vr, br, r0, fl["layers"][i], fl["bes"], i, 2 * fl["n_half"]))
+        fkey = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr()) for a, b, c, *_ in fsrc)
+        if self.packed.get("fold_key") != fkey:
+            rows = []
+            for (w_end, vr, br, r0, ly, bes, i, nj) in fsrc:
+                rows.append([w_end.data_ptr(), vr.data_ptr() + 4 * r0 * C, ly["s_rs"].data_ptr() + 4 * r0,
+                             br.data_ptr() + 4 * r0, ly["fold_A"].data_ptr(), bes.data_ptr() + 4 * 8 * i, nj, C])
+            self.packed["fold_jobs"] = torch.tensor(rows, dtype=torch.int64).to(device)
+            self.packed["fold_key"] = fkey
+        _lib.call("t2s_wg_endfold_weights", _lib.ptr(self.packed["fold_jobs"]), len(fsrc), C, st)
+        keep = srcs + [t for tup in fsrc for t in tup[:3]]
         for k in range(m.n_flows):
             wn = m.WN[k]
             fl = self.packed["flows"][k]
@@ -212,7 +234,8 @@ class _Engine:
                      Xh=torch.zeros(B, xc, Lp, 32, **bf), Xl=torch.zeros(B, xc, Lp, 32, **bf),
                      Ah=torch.zeros(B, xc, Lp, 32, **bf), Al=torch.zeros(B, xc, Lp, 32, **bf),
                      Sh=torch.zeros(B, sc, Lp, 32, **bf), Sl=torch.zeros(B, sc, Lp, 32, **bf),
-                     skip=torch.zeros(B, xc, Lp, 32, dtype=torch.float32, device=device))
+                     skip=torch.zeros(B, xc, Lp, 32, dtype=torch.float32, device=device),
+                     fold_acc=torch.zeros(2 * (-(-g["C"] // 128)), B, 8, L, dtype=torch.float32, device=device))
             self.ws = {key: w}      # keep one shape resident
         return w
 
@@ -249,23 +272,41 @@ class _Engine:
             if self.gemm_events is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            _lib.call("t2s_wg_in_cond_gate", _lib.ptr(ly["A1h"]), _lib.ptr(ly["A1l"]), _lib.ptr(ly["b1"]),
-                      _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), _lib.ptr(w["Sh"]), _lib.ptr(w["Sl"]),
-                      _lib.ptr(w["Ah"]), _lib.ptr(w["Al"]), B, C, g["n_cond"], ks, 2 ** i, L, w["Lp"], g["halo"],
-                      g["Mpad1"], st)
+            if self.use_fold:
+                _lib.call("t2s_wg_in_cond_gate_fold", _lib.ptr(ly["A1h"]), _lib.ptr(ly["A1l"]), _lib.ptr(ly["b1"]),
+                          _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), _lib.ptr(w["Sh"]), _lib.ptr(w["Sl"]),
+                          _lib.ptr(w["Ah"]), _lib.ptr(w["Al"]), _lib.ptr(ly["fold_A"]), _lib.ptr(w["fold_acc"]),
+                          1 if i == 0 else 0, B, C, g["n_cond"], ks, 2 ** i, L, w["Lp"], g["halo"], g["Mpad1"], st)
+            else:
+                _lib.call("t2s_wg_in_cond_gate", _lib.ptr(ly["A1h"]), _lib.ptr(ly["A1l"]), _lib.ptr(ly["b1"]),
+                          _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), _lib.ptr(w["Sh"]), _lib.ptr(w["Sl"]),
+                          _lib.ptr(w["Ah"]), _lib.ptr(w["Al"]), B, C, g["n_cond"], ks, 2 ** i, L, w["Lp"], g["halo"],
+                          g["Mpad1"], st)
             if self.gemm_events is not None:
                 e1.record()
                 self.gemm_events.append((e0, e1))
             n_res = C if i < nl - 1 else 0
-            _lib.call("t2s_wg_res_skip", _lib.ptr(ly["A2h"]), _lib.ptr(ly["A2l"]), _lib.ptr(ly["b2"]),
-                      _lib.ptr(w["Ah"]), _lib.ptr(w["Al"]), _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), _lib.ptr(w["skip"]),
-                      B, C, n_res, 1 if i == 0 else 0, L, w["Lp"], g["halo"], ly["Mpad2"], st)
+            if self.use_fold:
+                if n_res:       # the last layer has no residual half, and its skip half lives in the fold
+                    _lib.call("t2s_wg_res_only", _lib.ptr(ly["A2h"]), _lib.ptr(ly["A2l"]), _lib.ptr(ly["b2"]),
+                              _lib.ptr(w["Ah"]), _lib.ptr(w["Al"]), _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), B, C, L, w["Lp"],
+                              g["halo"], ly["Mpad2"], st)
+            else:
+                _lib.call("t2s_wg_res_skip", _lib.ptr(ly["A2h"]), _lib.ptr(ly["A2l"]), _lib.ptr(ly["b2"]),
+                          _lib.ptr(w["Ah"]), _lib.ptr(w["Al"]), _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), _lib.ptr(w["skip"]),
+                          B, C, n_res, 1 if i == 0 else 0, L, w["Lp"], g["halo"], ly["Mpad2"], st)
 
     def _end(self, k, z, log_s, B, L, w, c_off, n_half, reverse, wn_out=None, skip=None):
         m, g = self.m, self.geom()
         wn = m.WN[k]
         w_end, b_end = _f32c(wn.end.weight), _f32c(wn.end.bias)
         self._keep_end = (w_end, b_end)
+        if self.use_fold and wn_out is None and skip is None:
+            fl = self.packed["flows"][k]
+            _lib.call("t2s_wg_end_fold_affine", _lib.ptr(w["fold_acc"]), w["fold_acc"].size(0), _lib.ptr(fl["bes"]),
+                      g["nl"], _lib.ptr(b_end), _lib.ptr(z), _lib.ptr(log_s), B, m.n_group, c_off, n_half, L,
+                      1 if reverse else 0, _lib.current_stream())
+            return
         _lib.call("t2s_wg_end_affine", _lib.ptr(w["skip"] if skip is None else skip), _lib.ptr(w_end), _lib.ptr(b_end),
                   _lib.ptr(z), _lib.ptr(log_s), _lib.ptr(wn_out), B, m.n_group, c_off, n_half, g["C"], L, w["Lp"], g["halo"], 1 if reverse else 0,
                   _lib.current_stream())
