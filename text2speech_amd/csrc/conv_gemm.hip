@@ -32,6 +32,16 @@
 #include "t2s_common.h"
 #include "t2s_kernels.h"
 
+#include <stdlib.h>
+
+// Timing-only ablations (results are wrong): build with -DT2S_GEMM_ABLATE and set env T2S_DBG_GEMM to
+// 1 (no DMA inside the K loop), 2 (no MFMA) or 3.  Compiled out of the product build.
+#ifdef T2S_GEMM_ABLATE
+#define T2S_ABLATE(a) ((a).dbg)
+#else
+#define T2S_ABLATE(a) 0
+#endif
+
 #define B_PLANE_BYTES 16384          // one B (activation) plane tile: 256 rows x 64 B
 
 static __device__ __forceinline__ int swz4(int rb) {      // {0,2,3,1}[rb]
@@ -124,9 +134,14 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
 
     for (int ks = 0; ks < nk; ++ks) {
         const int cur = ks & 1;
-        if (ks + 1 < nk) stage(ks + 1, cur ^ 1);
+        if (ks + 1 < nk && !(T2S_ABLATE(a) & 1)) stage(ks + 1, cur ^ 1);
         const char* sb = smem + cur * STAGE;
+        // Fragment reads are ordered for the earliest possible first MFMA (it needs only a_lo(0) and b_hi(0)), and the
+        // A fragments of m-tile m+1 are fetched while m's 12 MFMAs issue: the LDS-read burst that follows every
+        // barrier overlaps matrix work instead of preceding it.
         bf16x8 bh[4], bl[4];
+        bf16x8 ah = *(const bf16x8*)(sb + a_frag);
+        bf16x8 al = *(const bf16x8*)(sb + a_frag + A_PLANE);
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             bh[n] = *(const bf16x8*)(sb + b_frag + n * 1024);
@@ -134,14 +149,23 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
         }
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
-            const bf16x8 ah = *(const bf16x8*)(sb + a_frag + m * 1024);
-            const bf16x8 al = *(const bf16x8*)(sb + a_frag + A_PLANE + m * 1024);
+            bf16x8 ah_n = ah, al_n = al;
+            if (m + 1 < MW) {
+                ah_n = *(const bf16x8*)(sb + a_frag + (m + 1) * 1024);
+                al_n = *(const bf16x8*)(sb + a_frag + A_PLANE + (m + 1) * 1024);
+            }
+            if (!(T2S_ABLATE(a) & 2)) {
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+            } else {
+                asm volatile("" :: "v"(al), "v"(ah));
+            }
+            ah = ah_n;
+            al = al_n;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -374,7 +398,10 @@ static hipError_t launch_one(const ConvGemmArgs& a, hipStream_t stream) {
 }
 
 // a.n_mtiles must have been computed for the same tile height `mt_rows` (256 or 128)
-hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a, int epi, hipStream_t stream, int mt_rows) {
+hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a_in, int epi, hipStream_t stream, int mt_rows) {
+    static const int dbg = getenv("T2S_DBG_GEMM") ? atoi(getenv("T2S_DBG_GEMM")) : 0;
+    ConvGemmArgs a = a_in;
+    a.dbg = dbg;
     if (mt_rows == 128) {
         if (epi == EPI_RESSKIP) return launch_one<EPI_RESSKIP, 128>(a, stream);
         return hipErrorInvalidValue;

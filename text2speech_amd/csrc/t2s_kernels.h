@@ -46,6 +46,7 @@ struct ConvGemmArgs {
     const u16* fold_A;     // (W_end . W_skip_i) as MFMA A fragments [mt][wr][pair][hi,lo][lane][8] (endfold_weights_kernel)
     float* fold_acc;       // [2*n_mtiles][B][8][L]
     int fold_init;         // 1: store, 0: accumulate (first / later layers of a flow)
+    int dbg;               // timing-only ablations (env T2S_DBG_GEMM): 1 = no DMA in the K loop, 2 = no MFMA; results are wrong
 };
 
 hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a, int epi, hipStream_t stream, int mt_rows = 256);
