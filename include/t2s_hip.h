@@ -189,7 +189,9 @@ typedef struct t2s_taco_decoder {
     const float *dec_w_ih, *dec_w_hh, *dec_b_ih, *dec_b_hh;   /* decoder_rnn   (tacotron.py:380) */
     const float *w_query, *w_loc_conv, *w_loc_dense, *w_v;    /* attention_layer (tacotron.py:96-143) */
     const float *w_proj, *b_proj;        /* [n_mel+1][dec+enc]: linear_projection rows, then the gate_layer row */
-    const float *w_projpre, *b_projpre;  /* [prenet][dec+enc] = W_prenet0 . W_proj[:n_mel], W_prenet0 . b_proj[:n_mel] */
+    const float *w_projpre, *b_projpre;  /* [prenet][dec+enc] = W_prenet0 . W_proj[:n_mel], W_prenet0 . b_proj[:n_mel];
+                                          * stored DIRECTLY BEHIND w_proj / b_proj (one [n_mel+1+prenet] row block) */
+    const float *w_loc_denseT;           /* [loc_filters][att_dim] (transpose of w_loc_dense) */
     const float *w_pre2;                 /* [prenet][prenet] = prenet.layers.1 */
     const float *memory, *pmem;          /* [B][T_in][enc], [B][T_in][att_dim] */
     const int *mem_lengths;              /* [B] or NULL */
@@ -199,6 +201,7 @@ typedef struct t2s_taco_decoder {
     float att_drop_scale, dec_drop_scale;
     float *att_h0, *att_h1, *att_c, *dec_h0, *dec_h1, *dec_c;   /* ping-pong h (step parity), c in place */
     float *att_w, *att_wcum, *ctx, *q, *energies, *pre1, *pre2; /* [B][T_in] x3, [B][enc], [B][att_dim], ... */
+    float *q_part;                       /* [att_rnn/4][B][att_dim] partial queries (small-batch fused attention) or NULL */
     float *mel_gate_out;                 /* [B][n_mel+1][T_cap] (autoregressive), row n_mel = gate logit */
     float *align_out;                    /* [B][T_cap][T_in] */
     float *hc_all;                       /* teacher forced: [T][B][dec+enc] */

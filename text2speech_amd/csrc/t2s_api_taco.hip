@@ -38,6 +38,7 @@ int t2s_gemv(const float* W1, int ld1, int k1, const float* W2, int ld2, int k2,
     a.bias1 = bias1; a.bias2 = bias2; a.y = y; a.sy_item = sy_item; a.sy_row = sy_row; a.rows = rows; a.items = items;
     a.act = act; a.mask = mask; a.smask_item = smask_item; a.mask_scale = mask_scale;
     if (!gemv_args_ok(a) || act < 0 || act > 2) return T2S_EINVAL;
+    a.split_row = 0; a.y2 = nullptr; a.sy2_item = a.sy2_row = 0; a.act2 = 0; a.mask2 = nullptr; a.smask2_item = 0; a.mask2_scale = 1.f;
     T2S_CHECK_HIP(t2s_launch_gemv(a, (hipStream_t)stream));
     return T2S_OK;
 }
@@ -122,14 +123,9 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         ca.n1 = P; ca.sx1 = P; ca.x2 = d->ctx; ca.n2 = E; ca.sx2 = E;
         ca.h_in = ah_in; ca.h_out = ah_out; ca.c = d->att_c; ca.B = B; ca.H = A;
         if (d->att_drop) { ca.drop_mask = d->att_drop + (size_t)s * B * A; ca.drop_scale = d->att_drop_scale; }
+        const bool fused_att = B <= 8 && T <= 512 && d->w_loc_denseT && d->att_dim <= 128;
         T2S_CHECK_HIP(t2s_launch_lstm_cell(ca, stream));
-        // 2. query = W_q h_att
-        GemvArgs qa;
-        memset(&qa, 0, sizeof(qa));
-        qa.W1 = d->w_query; qa.ld1 = A; qa.k1 = A; qa.x1 = ah_out; qa.n1 = A; qa.sx1 = A;
-        qa.y = d->q; qa.sy_item = d->att_dim; qa.sy_row = 1; qa.rows = d->att_dim; qa.items = B;
-        T2S_CHECK_HIP(t2s_launch_gemv(qa, stream));
-        // 3./4. location-sensitive energies, softmax, context, cumulative weights
+        // 2.-4. attention: query, location-sensitive energies, softmax, context, cumulative weights
         AttArgs aa;
         memset(&aa, 0, sizeof(aa));
         aa.q = d->q; aa.w_loc_conv = d->w_loc_conv; aa.w_loc_dense = d->w_loc_dense; aa.w_v = d->w_v;
@@ -138,8 +134,19 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         aa.align_out = d->align_out + (size_t)s * T; aa.s_align_b = (long)d->T_cap * T;
         if (d->teacher_forced) { aa.ctx_copy = d->hc_all + (size_t)s * B * (D + E) + D; aa.s_ctx_copy = D + E; }
         aa.B = B; aa.T = T; aa.att_dim = d->att_dim; aa.enc_dim = E; aa.loc_f = d->loc_filters; aa.loc_ks = d->loc_kernel;
-        T2S_CHECK_HIP(t2s_launch_att_energy(aa, stream));
-        T2S_CHECK_HIP(t2s_launch_att_softmax_ctx(aa, stream));
+        aa.w_query = d->w_query; aa.h_att = ah_out; aa.w_loc_denseT = d->w_loc_denseT; aa.att_rnn = A;
+        if (fused_att) {
+            // small batch: one fused launch per step (one workgroup per batch element)
+            T2S_CHECK_HIP(t2s_launch_att_fused(aa, stream));
+        } else {
+            GemvArgs qa;
+            memset(&qa, 0, sizeof(qa));
+            qa.W1 = d->w_query; qa.ld1 = A; qa.k1 = A; qa.x1 = ah_out; qa.n1 = A; qa.sx1 = A;
+            qa.y = d->q; qa.sy_item = d->att_dim; qa.sy_row = 1; qa.rows = d->att_dim; qa.items = B;
+            T2S_CHECK_HIP(t2s_launch_gemv(qa, stream));
+            T2S_CHECK_HIP(t2s_launch_att_energy(aa, stream));
+            T2S_CHECK_HIP(t2s_launch_att_softmax_ctx(aa, stream));
+        }
         // 5. decoder LSTMCell on [h_att | context]
         LstmCellArgs cd;
         memset(&cd, 0, sizeof(cd));
@@ -150,25 +157,35 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         if (d->teacher_forced) { cd.h_copy = d->hc_all + (size_t)s * B * (D + E); cd.s_copy = D + E; }
         T2S_CHECK_HIP(t2s_launch_lstm_cell(cd, stream));
         if (!d->teacher_forced) {
-            // 6. mel frame + gate logit = W_proj [h_dec | context] + b
+            // 6./7. mel frame + gate logit = W_proj [h_dec | ctx] + b, and (same launch, second row block) layer 0
+            //       of the next step's prenet through the precomposed matrix W_pre0 . W_proj (always-on dropout,
+            //       modules.py:21), so the mel frame needs no extra hop before the prenet.
+            const bool more = s + 1 < d->mask_steps;
+            const unsigned char* mk = d->prenet_masks + (size_t)(s + 1) * B * 2 * P;
             GemvArgs pa;
             memset(&pa, 0, sizeof(pa));
             pa.W1 = d->w_proj; pa.ld1 = D + E; pa.k1 = D + E;
             pa.x1 = dh_out; pa.n1 = D; pa.sx1 = D; pa.x2 = d->ctx; pa.n2 = E; pa.sx2 = E;
             pa.bias1 = d->b_proj; pa.y = d->mel_gate_out + s; pa.sy_item = (long)(d->n_mel + 1) * d->T_cap;
             pa.sy_row = d->T_cap; pa.rows = d->n_mel + 1; pa.items = B;
-            T2S_CHECK_HIP(t2s_launch_gemv(pa, stream));
-            // 7. prenet of the next step's input (always-on dropout, modules.py:21).  Layer 0 is applied to the
-            //    mel frame through the precomposed matrix W_pre0 . W_proj so it needs no extra hop.
-            if (s + 1 < d->mask_steps) {
-                const unsigned char* mk = d->prenet_masks + (size_t)(s + 1) * B * 2 * P;
-                GemvArgs p1;
-                memset(&p1, 0, sizeof(p1));
-                p1.W1 = d->w_projpre; p1.ld1 = D + E; p1.k1 = D + E;
-                p1.x1 = dh_out; p1.n1 = D; p1.sx1 = D; p1.x2 = d->ctx; p1.n2 = E; p1.sx2 = E;
-                p1.bias1 = d->b_projpre; p1.y = d->pre1; p1.sy_item = P; p1.sy_row = 1; p1.rows = P; p1.items = B;
-                p1.act = ACT_RELU; p1.mask = mk; p1.smask_item = 2 * P; p1.mask_scale = 2.0f;
-                T2S_CHECK_HIP(t2s_launch_gemv(p1, stream));
+            if (more && d->w_projpre == d->w_proj + (size_t)(d->n_mel + 1) * (D + E) && d->b_projpre == d->b_proj + d->n_mel + 1) {
+                pa.rows = d->n_mel + 1 + P; pa.split_row = d->n_mel + 1;
+                pa.y2 = d->pre1; pa.sy2_item = P; pa.sy2_row = 1; pa.act2 = ACT_RELU;
+                pa.mask2 = mk; pa.smask2_item = 2 * P; pa.mask2_scale = 2.0f;
+                T2S_CHECK_HIP(t2s_launch_gemv(pa, stream));
+            } else {
+                T2S_CHECK_HIP(t2s_launch_gemv(pa, stream));
+                if (more) {
+                    GemvArgs p1;
+                    memset(&p1, 0, sizeof(p1));
+                    p1.W1 = d->w_projpre; p1.ld1 = D + E; p1.k1 = D + E;
+                    p1.x1 = dh_out; p1.n1 = D; p1.sx1 = D; p1.x2 = d->ctx; p1.n2 = E; p1.sx2 = E;
+                    p1.bias1 = d->b_projpre; p1.y = d->pre1; p1.sy_item = P; p1.sy_row = 1; p1.rows = P; p1.items = B;
+                    p1.act = ACT_RELU; p1.mask = mk; p1.smask_item = 2 * P; p1.mask_scale = 2.0f;
+                    T2S_CHECK_HIP(t2s_launch_gemv(p1, stream));
+                }
+            }
+            if (more) {
                 GemvArgs p2;
                 memset(&p2, 0, sizeof(p2));
                 p2.W1 = d->w_pre2; p2.ld1 = P; p2.k1 = P; p2.x1 = d->pre1; p2.n1 = P; p2.sx1 = P;

@@ -15,6 +15,11 @@ struct GemvArgs {
     int rows, items;
     int act;
     const unsigned char* mask; long smask_item; float mask_scale;
+    // optional second row block (rows >= split_row, split_row > 0): its own output, activation and mask
+    int split_row;
+    float* y2; long sy2_item; long sy2_row;
+    int act2;
+    const unsigned char* mask2; long smask2_item; float mask2_scale;
 };
 
 struct LstmCellArgs {
@@ -30,6 +35,8 @@ struct LstmCellArgs {
     float* h_copy; long s_copy;           // optional second copy of h_out (stride per item)
     const unsigned char* drop_mask; float drop_scale;   // optional dropout on h_out ([B][H] of 0/1)
     int B, H;
+    // optional: per-workgroup partial attention queries q_part[wg][b][a] = sum_{u in wg} w_q[a][u] * h_out[b][u]
+    const float* w_q; float* q_part; int q_dim;
 };
 
 struct AttArgs {
@@ -47,12 +54,20 @@ struct AttArgs {
     float* ctx_copy; long s_ctx_copy;
     float* align_out; long s_align_b;
     int B, T, att_dim, enc_dim, loc_f, loc_ks;
+    // fused single-launch form (small batch): query computed in the same kernel
+    const float* w_query;      // [att_dim][att_rnn]
+    const float* h_att;        // [B][att_rnn]
+    const float* w_loc_denseT; // [F][att_dim]
+    int att_rnn;
+    const float* q_part;       // [n_part][B][att_dim] partial queries from lstm_cell_kernel (instead of w_query . h_att)
+    int n_part;
 };
 
 hipError_t t2s_launch_gemv(const GemvArgs& a, hipStream_t stream);
 hipError_t t2s_launch_lstm_cell(const LstmCellArgs& a, hipStream_t stream);
 hipError_t t2s_launch_att_energy(const AttArgs& a, hipStream_t stream);
 hipError_t t2s_launch_att_softmax_ctx(const AttArgs& a, hipStream_t stream);
+hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream);
 hipError_t t2s_launch_lstm_seq(const float* gx, const float* whhT_f, const float* whhT_r, const int* lengths, float* out,
                                int B, int T, int H, int T_out, hipStream_t stream);
 hipError_t t2s_launch_transpose(const float* in, float* out, int R, int C, hipStream_t stream);

@@ -14,6 +14,8 @@
 #include "t2s_kernels.h"
 #include "tacotron_ops.h"
 
+#include <stdlib.h>
+
 static __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------
@@ -85,10 +87,18 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const GemvArgs a) {
         acc = wave_sum(acc);
         if (lane == 0) {
             float y = acc + bias;
-            if (a.act == ACT_RELU) y = fmaxf(y, 0.f);
-            else if (a.act == ACT_TANH) y = tanhf(y);
-            if (a.mask) y *= a.mask[(size_t)it * a.smask_item + row] ? a.mask_scale : 0.f;
-            a.y[(size_t)it * a.sy_item + (size_t)row * a.sy_row] = y;
+            if (a.split_row > 0 && row >= a.split_row) {
+                const int r2 = row - a.split_row;
+                if (a.act2 == ACT_RELU) y = fmaxf(y, 0.f);
+                else if (a.act2 == ACT_TANH) y = tanhf(y);
+                if (a.mask2) y *= a.mask2[(size_t)it * a.smask2_item + r2] ? a.mask2_scale : 0.f;
+                a.y2[(size_t)it * a.sy2_item + (size_t)r2 * a.sy2_row] = y;
+            } else {
+                if (a.act == ACT_RELU) y = fmaxf(y, 0.f);
+                else if (a.act == ACT_TANH) y = tanhf(y);
+                if (a.mask) y *= a.mask[(size_t)it * a.smask_item + row] ? a.mask_scale : 0.f;
+                a.y[(size_t)it * a.sy_item + (size_t)row * a.sy_row] = y;
+            }
         }
     }
 }
@@ -304,8 +314,14 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_kernel(const AttArgs a) {
     __syncthreads();
     for (int c = tid; c < a.enc_dim; c += 256) {
         const float* mem = a.memory + (size_t)b * T * a.enc_dim + c;
-        float acc = 0.f;
-        for (int t = 0; t < T; ++t) acc += s_w[t] * mem[(size_t)t * a.enc_dim];
+        float a4[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int t = 0;
+        for (; t + 8 <= T; t += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a4[u] += s_w[t + u] * mem[(size_t)(t + u) * a.enc_dim];
+        }
+        for (; t < T; ++t) a4[0] += s_w[t] * mem[(size_t)t * a.enc_dim];
+        const float acc = ((a4[0] + a4[1]) + (a4[2] + a4[3])) + ((a4[4] + a4[5]) + (a4[6] + a4[7]));
         a.ctx[(size_t)b * a.enc_dim + c] = acc;
         if (a.ctx_copy) a.ctx_copy[(size_t)b * a.s_ctx_copy + c] = acc;
     }
@@ -318,6 +334,190 @@ hipError_t t2s_launch_att_energy(const AttArgs& a, hipStream_t stream) {
 }
 hipError_t t2s_launch_att_softmax_ctx(const AttArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(att_softmax_ctx_kernel, dim3(a.B), dim3(256), (size_t)a.T * sizeof(float), stream, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small-batch form of one attention step: query, location features, energies, softmax, context and the
+// cumulative weights in ONE launch, one 1024-thread workgroup per batch element (T <= ATT_FUSED_MAXT).
+// Cuts three dependent launches (~1.5-3 us of boundary each plus their serial prologues) out of every
+// autoregressive step; the split kernels above remain for large batches, where they fill the chip.
+#define ATT_FUSED_MAXT 512
+__global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
+    extern __shared__ float s_dyn[];                 // [T][33] location features, then [T] energies
+    __shared__ float s_q[128];
+    __shared__ float s_qp[8][128];
+    __shared__ float s_d[32 * 128];
+    __shared__ float s_cat[2][ATT_FUSED_MAXT + 64];
+    __shared__ float s_k[32 * 2 * 63];
+    __shared__ float red[16];
+    __shared__ float s_ctx[2][512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int T = a.T, AD = a.att_dim, KS = a.loc_ks, F = a.loc_f, pad = KS >> 1, A = a.att_rnn;
+    float* s_f = s_dyn;                               // [T][33]
+    float* s_e = s_dyn + (size_t)T * 33;              // [T]
+    // ---- every independent global load is issued first, so one memory latency covers them all ----
+    for (int i = tid; i < F * 2 * KS; i += 1024) s_k[i] = a.w_loc_conv[i];
+    for (int i = tid; i < 2 * (T + KS - 1); i += 1024) {
+        const int c = i / (T + KS - 1), j = i - c * (T + KS - 1);
+        const int t = j - pad;
+        const float* src = c ? a.w_cum : a.w_prev;
+        s_cat[c][j] = (t >= 0 && t < T) ? src[(size_t)b * T + t] : 0.f;
+    }
+    for (int i = tid; i < 32 * 128; i += 1024) {          // dense location weights [f][a] in LDS (registers are
+        const int f = i >> 7, ai = i & 127;                 // capped at 128 per lane by the 1024-thread workgroup)
+        s_d[i] = (f < F && ai < AD) ? a.w_loc_denseT[f * AD + ai] : 0.f;
+    }
+    const float v0 = lane < AD ? a.w_v[lane] : 0.f, v1 = lane + 64 < AD ? a.w_v[lane + 64] : 0.f;
+    // ---- query: sum of the per-workgroup partials the attention LSTM cell just wrote, or W_q h_att ----
+    if (a.q_part) {
+        const int ai = tid & 127, part = tid >> 7;            // 8 slices of the partial list per output
+        float acc = 0.f;
+        if (ai < AD) {
+            float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int w = part;
+            for (; w + 56 < a.n_part; w += 64) {           // 8 independent loads in flight
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a8[u] += a.q_part[((size_t)(w + 8 * u) * a.B + b) * AD + ai];
+            }
+            for (; w < a.n_part; w += 8) a8[0] += a.q_part[((size_t)w * a.B + b) * AD + ai];
+            acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+        }
+        s_qp[part][ai] = acc;
+        __syncthreads();
+        if (tid < AD) {
+            float q = 0.f;
+#pragma unroll
+            for (int p8 = 0; p8 < 8; ++p8) q += s_qp[p8][tid];
+            s_q[tid] = q;
+        }
+    } else {
+        f32x4 x[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int k = (v * 64 + lane) * 4;
+            x[v] = k < A ? *(const f32x4*)(a.h_att + (size_t)b * A + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int r0 = wave * 4; r0 < AD; r0 += 64) {
+            f32x4 w[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int k = (v * 64 + lane) * 4;
+                    w[i][v] = (k < A && r0 + i < AD) ? *(const f32x4*)(a.w_query + (size_t)(r0 + i) * A + k)
+                                                     : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float acc = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    acc += w[i][v][0] * x[v][0] + w[i][v][1] * x[v][1] + w[i][v][2] * x[v][2] + w[i][v][3] * x[v][3];
+                acc = wave_sum(acc);
+                if (lane == 0 && r0 + i < AD) s_q[r0 + i] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- location features f[t][:] = conv1d([w ; w_cum]) ----
+    for (int i = tid; i < T * F; i += 1024) {
+        const int t = i / F, f = i - t * F;
+        float acc = 0.f;
+        for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < KS; ++j) acc += s_k[(f * 2 + c) * KS + j] * s_cat[c][t + j];
+        s_f[t * 33 + f] = acc;
+    }
+    __syncthreads();
+    // ---- energies: attention_dim on lanes (2 per lane), one wave per time step ----
+    {
+        const float q0 = lane < AD ? s_q[lane] : 0.f, q1 = lane + 64 < AD ? s_q[lane + 64] : 0.f;
+        const int len = a.lengths ? a.lengths[b] : T;
+        for (int t = wave; t < T; t += 16) {
+            const float* pm = a.pmem + ((size_t)b * T + t) * AD;
+            const float pm0 = lane < AD ? pm[lane] : 0.f, pm1 = lane + 64 < AD ? pm[lane + 64] : 0.f;
+            float p0 = q0, p1 = q1;
+#pragma unroll
+            for (int f = 0; f < 32; ++f) {
+                const float ff = s_f[t * 33 + f];
+                p0 += s_d[f * 128 + lane] * ff;
+                p1 += s_d[f * 128 + 64 + lane] * ff;
+            }
+            float e = 0.f;
+            if (lane < AD) e += v0 * tanhf(p0 + pm0);
+            if (lane + 64 < AD) e += v1 * tanhf(p1 + pm1);
+            e = wave_sum(e);
+            if (lane == 0) s_e[t] = t < len ? e : -INFINITY;
+        }
+    }
+    __syncthreads();
+    // ---- softmax over T ----
+    float m = -INFINITY;
+    for (int t = tid; t < T; t += 1024) m = fmaxf(m, s_e[t]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = red[0];
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    __syncthreads();
+    float sum = 0.f;
+    for (int t = tid; t < T; t += 1024) {
+        const float p = expf(s_e[t] - m);
+        s_e[t] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    float tot = 0.f;
+    for (int i = 0; i < 16; ++i) tot += red[i];
+    const float inv = 1.0f / tot;
+    for (int t = tid; t < T; t += 1024) {
+        const float w = s_e[t] * inv;
+        s_e[t] = w;
+        a.w_prev[(size_t)b * T + t] = w;
+        a.w_cum[(size_t)b * T + t] += w;
+        if (a.align_out) a.align_out[(size_t)b * a.s_align_b + t] = w;
+    }
+    __syncthreads();
+    // ---- context = weights . memory : two threads per channel, each half of the time range ----
+    {
+        const int c = tid & 511, half = tid >> 9;
+        float acc = 0.f;
+        if (c < a.enc_dim) {
+            const int tb = half ? (T + 1) / 2 : 0, te = half ? T : (T + 1) / 2;
+            const float* mem = a.memory + (size_t)b * T * a.enc_dim + c;
+            float a4[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int t = tb;
+            for (; t + 8 <= te; t += 8) {         // 8 independent loads in flight per thread
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a4[u] += s_e[t + u] * mem[(size_t)(t + u) * a.enc_dim];
+            }
+            for (; t < te; ++t) a4[0] += s_e[t] * mem[(size_t)t * a.enc_dim];
+            acc = ((a4[0] + a4[1]) + (a4[2] + a4[3])) + ((a4[4] + a4[5]) + (a4[6] + a4[7]));
+        }
+        s_ctx[half][c] = acc;
+    }
+    __syncthreads();
+    if (tid < a.enc_dim && tid < 512) {
+        const float v = s_ctx[0][tid] + s_ctx[1][tid];
+        a.ctx[(size_t)b * a.enc_dim + tid] = v;
+        if (a.ctx_copy) a.ctx_copy[(size_t)b * a.s_ctx_copy + tid] = v;
+    }
+}
+hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream) {
+    if (a.T > ATT_FUSED_MAXT || a.enc_dim > 512 || a.att_dim > 128 || a.loc_f > 32 || a.loc_ks > 63 || a.att_rnn > 1024)
+        return hipErrorInvalidValue;
+    const size_t lds = ((size_t)a.T * 33 + a.T) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)att_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(att_fused_kernel, dim3(a.B), dim3(1024), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -89,11 +89,12 @@ class _DecoderStruct(ctypes.Structure):
     _I = ["B", "T_in", "n_mel", "prenet_dim", "enc_dim", "att_rnn_dim", "dec_rnn_dim", "att_dim", "loc_filters",
           "loc_kernel", "T_cap", "teacher_forced", "mask_steps"]
     _P1 = ["att_w_ih", "att_w_hh", "att_b_ih", "att_b_hh", "dec_w_ih", "dec_w_hh", "dec_b_ih", "dec_b_hh",
-           "w_query", "w_loc_conv", "w_loc_dense", "w_v", "w_proj", "b_proj", "w_projpre", "b_projpre", "w_pre2",
+           "w_query", "w_loc_conv", "w_loc_dense", "w_v", "w_proj", "b_proj", "w_projpre", "b_projpre", "w_loc_denseT",
+           "w_pre2",
            "memory", "pmem", "mem_lengths", "pre_all", "prenet_masks", "att_drop", "dec_drop"]
     _F = ["att_drop_scale", "dec_drop_scale"]
     _P2 = ["att_h0", "att_h1", "att_c", "dec_h0", "dec_h1", "dec_c", "att_w", "att_wcum", "ctx", "q", "energies",
-           "pre1", "pre2", "mel_gate_out", "align_out", "hc_all"]
+           "pre1", "pre2", "q_part", "mel_gate_out", "align_out", "hc_all"]
     _fields_ = ([(n, ctypes.c_int) for n in _I] + [(n, ctypes.c_void_p) for n in _P1] +
                 [(n, ctypes.c_float) for n in _F] + [(n, ctypes.c_void_p) for n in _P2])
 
@@ -176,22 +177,30 @@ class _TacoEngine:
                         ("w_pre2", dec.prenet.layers[1].linear_layer.weight)]:
             P[name] = _f32(t)
         n_mel = dec.n_mel_channels * dec.n_frames_per_step
-        P["w_proj"] = torch.cat([_f32(dec.linear_projection.linear_layer.weight),
-                                 _f32(dec.gate_layer.linear_layer.weight)], 0).contiguous()
-        P["b_proj"] = torch.cat([_f32(dec.linear_projection.linear_layer.bias),
-                                 _f32(dec.gate_layer.linear_layer.bias)], 0).contiguous()
-        # w_projpre = W_pre1 . W_proj[:n_mel]  (prenet layer 0 applied straight to [h_dec | ctx])
-        DE = P["w_proj"].size(1)
         Pd = dec.prenet_dim
+        DE = dec.linear_projection.linear_layer.in_features
+        # one row block [n_mel mel rows | gate row | prenet_dim precomposed prenet rows] so that the projection and
+        # the next step's prenet layer 0 are ONE launch (t2s_taco_decode_steps)
+        P["w_proj_all"] = torch.zeros(n_mel + 1 + Pd, DE, dtype=torch.float32, device=dev)
+        P["b_proj_all"] = torch.zeros(n_mel + 1 + Pd, dtype=torch.float32, device=dev)
+        P["w_proj_all"][:n_mel + 1] = torch.cat([_f32(dec.linear_projection.linear_layer.weight),
+                                               _f32(dec.gate_layer.linear_layer.weight)], 0)
+        P["b_proj_all"][:n_mel + 1] = torch.cat([_f32(dec.linear_projection.linear_layer.bias),
+                                               _f32(dec.gate_layer.linear_layer.bias)], 0)
+        P["w_proj"], P["b_proj"] = P["w_proj_all"][:n_mel + 1], P["b_proj_all"][:n_mel + 1]
+        # w_projpre = W_pre1 . W_proj[:n_mel]  (prenet layer 0 applied straight to [h_dec | ctx])
         projT = torch.empty(DE, n_mel, dtype=torch.float32, device=dev)
         _lib.call("t2s_transpose", _lib.ptr(P["w_proj"]), _lib.ptr(projT), n_mel, DE, st)
-        P["w_projpre"] = torch.empty(Pd, DE, dtype=torch.float32, device=dev)
+        P["w_projpre"] = P["w_proj_all"][n_mel + 1:]
         _lib.call("t2s_gemv", _lib.ptr(P["w_pre1"]), n_mel, n_mel, None, 0, 0, _lib.ptr(projT), n_mel, n_mel, None, 0, 0,
                   None, 0, 0, None, None, _lib.ptr(P["w_projpre"]), 1, DE, Pd, DE, 0, None, 0, 1.0, st)
-        P["b_projpre"] = torch.empty(Pd, dtype=torch.float32, device=dev)
+        P["b_projpre"] = P["b_proj_all"][n_mel + 1:]
         _lib.call("t2s_gemv", _lib.ptr(P["w_pre1"]), n_mel, n_mel, None, 0, 0, _lib.ptr(P["b_proj"]), n_mel, n_mel, None, 0,
                   0, None, 0, 0, None, None, _lib.ptr(P["b_projpre"]), Pd, 1, Pd, 1, 0, None, 0, 1.0, st)
         P["_projT"] = projT
+        F_, AD_ = P["w_loc_dense"].size(1), P["w_loc_dense"].size(0)
+        P["w_loc_denseT"] = torch.empty(F_, AD_, dtype=torch.float32, device=dev)
+        _lib.call("t2s_transpose", _lib.ptr(P["w_loc_dense"]), _lib.ptr(P["w_loc_denseT"]), AD_, F_, st)
         self.prep, self.prep_key = P, key
         return P
 
@@ -255,7 +264,7 @@ class _TacoEngine:
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         S = dict(att_h0=z(B, A), att_h1=z(B, A), att_c=z(B, A), dec_h0=z(B, D), dec_h1=z(B, D), dec_c=z(B, D),
                  att_w=z(B, T_in), att_wcum=z(B, T_in), ctx=z(B, E), q=z(B, ad), energies=z(B, T_in),
-                 pre1=z(B, Pd), pre2=z(B, Pd), align_out=z(B, T_cap, T_in))
+                 pre1=z(B, Pd), pre2=z(B, Pd), q_part=z(A // 4, B, ad), align_out=z(B, T_cap, T_in))
         pmem = torch.empty(B, T_in, ad, dtype=torch.float32, device=dev)
         self._gemv(P["w_mem"], memory, ad, B * T_in, E, pmem)
         S["pmem"], S["memory"] = pmem, memory
@@ -267,7 +276,7 @@ class _TacoEngine:
             setattr(d, k, v)
         for name in ["att_w_ih", "att_w_hh", "att_b_ih", "att_b_hh", "dec_w_ih", "dec_w_hh", "dec_b_ih", "dec_b_hh",
                      "w_query", "w_loc_conv", "w_loc_dense", "w_v", "w_proj", "b_proj", "w_projpre", "b_projpre",
-                     "w_pre2"]:
+                     "w_loc_denseT", "w_pre2"]:
             setattr(d, name, P[name].data_ptr())
         for name, t in S.items():
             setattr(d, name, t.data_ptr())
