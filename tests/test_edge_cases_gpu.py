@@ -1,0 +1,116 @@
+"""Edge cases on the GPU path against the CPU oracles: sizes that are not tile multiples, minimum sizes,
+the 256-channel WaveGlow the reference's demo checkpoint uses (inference.py:50), weight-norm removal,
+batched / tiny Tacotron inputs."""
+import pytest
+import torch
+
+from text2speech_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _wg(cfg):
+    from text2speech_amd.glow import WaveGlow
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synth.waveglow_state(cfg))
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize("B,T,frames", [(1, 2005, 9), (1, 8, 1), (5, 777, 4), (2, 2048 + 8, 9)])
+def test_waveglow_forward_odd_sizes(B, T, frames):
+    """T not a multiple of n_group (the reference's unfold floors), one grouped step, a tail of one row."""
+    from oracle import waveglow_oracle as O
+    _lib.load()
+    cfg = synth.WAVEGLOW_SMALL
+    m = _wg(cfg)
+    gen = torch.Generator().manual_seed(T)
+    mel = torch.randn(B, 80, frames, generator=gen)
+    audio = torch.rand(B, T, generator=gen) - 0.5
+    with torch.no_grad():
+        z, log_s, log_det = m((mel.to(DEV), audio.to(DEV)))
+        zo, lso, ldo = O.waveglow_forward(synth.waveglow_state(cfg), cfg, mel, audio)
+    assert tuple(z.shape) == tuple(zo.shape) == (B, 8, T // 8)
+    assert _rel(z, zo) < 1e-4
+    for a, b in zip(log_s, lso):
+        assert _rel(a, b) < 1e-3
+    for a, b in zip(log_det, ldo):
+        assert abs(float(a) - float(b)) < 1e-3 * max(1.0, abs(float(b)))
+
+
+def test_waveglow_rejects_short_mel():
+    """reference glow.py:216 asserts the upsampled spectrogram covers the audio"""
+    cfg = synth.WAVEGLOW_SMALL
+    m = _wg(cfg)
+    mel = torch.randn(1, 80, 2, device=DEV)
+    audio = torch.rand(1, 4096, device=DEV)
+    with pytest.raises(AssertionError):
+        with torch.no_grad():
+            m((mel, audio))
+
+
+def test_waveglow_256_channels_and_remove_weightnorm():
+    from oracle import waveglow_oracle as O
+    from text2speech_amd.glow import WaveGlow
+    cfg = dict(synth.WAVEGLOW_DEFAULT)
+    cfg["WN_config"] = dict(n_layers=8, n_channels=256, kernel_size=3)
+    m = _wg(cfg)
+    mel, audio = synth.waveglow_inputs(2, 4096, seed=3)
+    with torch.no_grad():
+        z, _, _ = m((mel.to(DEV), audio.to(DEV)))
+        zo, _, _ = O.waveglow_forward(synth.waveglow_state(cfg), cfg, mel, audio)
+    assert _rel(z, zo) < 1e-4
+    keys_before = set(m.state_dict().keys())
+    m2 = WaveGlow.remove_weightnorm(m)
+    assert m2 is m
+    keys_after = set(m.state_dict().keys())
+    assert "WN.0.in_layers.0.weight_g" in keys_before and "WN.0.in_layers.0.weight" in keys_after
+    assert not any(k.endswith("weight_g") for k in keys_after)
+    with torch.no_grad():
+        z2, _, _ = m((mel.to(DEV), audio.to(DEV)))
+    assert _rel(z2, z) < 1e-5          # reference: bit-identical on CPU; here both go through the same kernels
+    gen = torch.Generator().manual_seed(1)
+    mel1 = torch.randn(1, 80, 1, generator=gen)               # one frame -> 256 samples
+    a1 = m.infer(mel1.to(DEV), sigma=0.0)
+    assert tuple(a1.shape) == (1, 256)
+    ao = O.waveglow_infer(synth.waveglow_state(cfg), cfg, mel1, torch.zeros(1, 4, 32), [torch.zeros(1, 2, 32)] * 2, sigma=0.0)
+    assert _rel(a1, ao) < 1e-3
+
+
+def test_tacotron_batched_and_tiny_inputs():
+    from oracle import tacotron_oracle as TO
+    from text2speech_amd.tacotron import Tacotron
+    hp = dict(synth.TACOTRON_HPARAMS)
+    sd = synth.tacotron_state()
+    m = Tacotron(hp, 80, num_speakers=2)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    gen = torch.Generator().manual_seed(5)
+    # batched autoregressive inference (the reference only ever runs B=1; semantics per element are the same)
+    ids = torch.randint(2, 80, (3, 17), generator=gen)
+    n = 12
+    masks = (torch.rand(n, 3, 2, 256, generator=gen) < 0.5)
+    m.decoder.gate_threshold, m.decoder.max_decoder_steps = 2.0, n
+    got = m.inference(ids.to(DEV), None, prenet_masks=masks.to(torch.uint8))
+    with torch.no_grad():
+        want = TO.tacotron_inference(sd, hp, ids, n, masks.float())
+    for g, w in zip(got, want):
+        assert tuple(g.shape) == tuple(w.shape)
+        assert _rel(g, w) < 1e-3
+    # shortest possible text: 1 symbol; teacher-forced with 1 output frame, lengths equal
+    ids1 = torch.tensor([[5]])
+    mel_t = torch.randn(1, 80, 1, generator=gen)
+    mk = (torch.rand(2, 1, 2, 256, generator=gen) < 0.5)
+    out = m((ids1.to(DEV), torch.tensor([1], device=DEV), mel_t.to(DEV), 1, torch.zeros(1, device=DEV),
+             torch.tensor([1], device=DEV)), prenet_masks=mk.to(torch.uint8))
+    with torch.no_grad():
+        w = TO.tacotron_forward(sd, hp, ids1, torch.tensor([1]), mel_t, torch.tensor([1]), {"prenet": mk.float()})
+    for g, ww in zip(out, w):
+        assert tuple(g.shape) == tuple(ww.shape)
+        assert _rel(g, ww) < 1e-3
