@@ -170,14 +170,22 @@ int t2s_f32_to_planes(const float* x, int B, int C, int L, int Lp, int halo, voi
 int t2s_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, const float* conv_bias,
                 float eps, int C, float* scale, float* bias_out, void* stream);
 
+/* Training-mode BatchNorm1d on a conv output x[B][C][T]: batch mean / biased variance per channel (written to
+ * mean/var), affine, activation, optional {0,1} dropout mask * mask_scale; result as planes and/or f32 [B][C][T]
+ * (reference tacotron.py:183-184,193-194; modules.py:105-137 in .train() mode) */
+int t2s_bn_train(const float* x, const float* gamma, const float* beta, float eps, int act, const unsigned char* mask,
+                 float mask_scale, int B, int C, int T, int Lp, int halo, float* mean, float* var, void* O_hi, void* O_lo,
+                 float* out_f32, void* stream);
+
 /* Encoder BiLSTM recurrence with packed-sequence semantics (tacotron.py:199-207).  gx[B][T][8H] = W_ih x + b_ih + b_hh
  * for both directions (fwd gates then reverse gates), whhT_* = W_hh^T [H][4H]; out[B][T_out][2H]; 4H must be 1024. */
 int t2s_taco_encoder_lstm(const float* gx, const float* whhT_fwd, const float* whhT_rev, const int* lengths, float* out,
                           int B, int T, int H, int T_out, void* stream);
 
-/* Bernoulli(0.5) bytes (0/1) from a counter hash: the always-on prenet dropout (modules.py:21) when the caller
- * does not inject masks */
-int t2s_bernoulli_mask(unsigned char* mask, size_t n, unsigned long long seed, unsigned long long offset, void* stream);
+/* Bernoulli(keep_prob) bytes (0/1) from a counter hash: dropout masks (the always-on prenet dropout,
+ * modules.py:21, and the training-mode dropouts) when the caller does not inject them */
+int t2s_bernoulli_mask(unsigned char* mask, size_t n, unsigned long long seed, unsigned long long offset, float keep_prob,
+                       void* stream);
 
 /* Decoder state + weights for t2s_taco_decode_steps.  Pointers are device pointers; f32 unless noted. */
 typedef struct t2s_taco_decoder {

@@ -156,10 +156,37 @@ def test_stop_condition_and_device_masks(model):
         model.decoder.max_decoder_steps = HP["max_decoder_steps"]
 
 
-def test_training_mode_fails_loudly(model):
-    model.train()
-    try:
-        with pytest.raises(NotImplementedError):
-            model.inference((torch.arange(8) + 2)[None].to(DEV), None)
-    finally:
-        model.eval()
+def test_forward_training_mode_vs_golden(golden_dir):
+    """Tacotron.forward in .train() mode: BatchNorm batch statistics, encoder / LSTM-output / postnet dropout with the
+    reference's own captured draws (tools/gen_golden_tacotron.py::gen_forward_train)."""
+    from text2speech_amd.tacotron import Tacotron
+    g = np.load(os.path.join(golden_dir, "tacotron_fwd_train.npz"))
+    m = Tacotron(HP, 80, num_speakers=2)
+    m.load_state_dict(synth.tacotron_state(), strict=True)
+    m = m.to(DEV).train()
+    text, in_len, mel_t, out_len = ragged_batch()
+    B, T_in, T_out = 4, 40, 50
+    tm = {"enc": list(unpack(g, "enc_masks", (3, B, 512, T_in))), "att": unpack(g, "att_masks", (T_out, B, 1024)),
+          "dec": unpack(g, "dec_masks", (T_out, B, 1024)),
+          "post": list(unpack(g, "post_masks_512", (4, B, 512, T_out))) + [unpack(g, "post_masks_80", (B, 80, T_out))]}
+    pm = unpack(g, "prenet_masks", (T_out + 1, B, 2, 256))
+    rm_before = m.encoder.convolutions[0][1].running_mean.clone()
+    with torch.no_grad():
+        out = m((text.to(DEV), in_len.to(DEV), mel_t.to(DEV), int(in_len.max()), torch.zeros(B, device=DEV),
+                 out_len.to(DEV)), prenet_masks=pm, train_masks=tm)
+    for name, got in zip(("mel", "mel_post", "gate", "align"), out):
+        assert tuple(got.shape) == g[name].shape, name
+        assert _rel(got, g[name]) < 1e-3, name
+    # nn.BatchNorm1d bookkeeping happened, as in the reference's train mode
+    assert not torch.equal(rm_before, m.encoder.convolutions[0][1].running_mean)
+    assert int(m.encoder.convolutions[0][1].num_batches_tracked) == 1
+    # device-drawn dropout: runs and is finite
+    with torch.no_grad():
+        out2 = m((text.to(DEV), in_len.to(DEV), mel_t.to(DEV), int(in_len.max()), torch.zeros(B, device=DEV),
+                  out_len.to(DEV)))
+    assert bool(torch.isfinite(out2[1]).all())
+    # no backward yet: loud, not a silent fallback
+    with pytest.raises(NotImplementedError):
+        m((text.to(DEV), in_len.to(DEV), mel_t.to(DEV), int(in_len.max()), torch.zeros(B, device=DEV), out_len.to(DEV)))
+    with pytest.raises(NotImplementedError):
+        m.inference((torch.arange(8) + 2)[None].to(DEV), None)

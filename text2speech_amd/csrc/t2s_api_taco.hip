@@ -70,6 +70,17 @@ int t2s_bn_fold(const float* gamma, const float* beta, const float* mean, const 
     return T2S_OK;
 }
 
+int t2s_bn_train(const float* x, const float* gamma, const float* beta, float eps, int act, const unsigned char* mask,
+                 float mask_scale, int B, int C, int T, int Lp, int halo, float* mean, float* var, void* O_hi, void* O_lo,
+                 float* out_f32, void* stream) {
+    if (!x || !gamma || !beta || !mean || !var || B <= 0 || C <= 0 || T <= 0 || act < 0 || act > 2) return T2S_EINVAL;
+    if (!O_hi && !out_f32) return T2S_EINVAL;
+    if (O_hi && (!O_lo || Lp < t2s_plane_rows(T, halo))) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_bn_train(x, gamma, beta, eps, act, mask, mask_scale, B, C, T, Lp, halo, mean, var,
+                                      (u16*)O_hi, (u16*)O_lo, out_f32, (hipStream_t)stream));
+    return T2S_OK;
+}
+
 int t2s_taco_encoder_lstm(const float* gx, const float* whhT_fwd, const float* whhT_rev, const int* lengths, float* out,
                           int B, int T, int H, int T_out, void* stream) {
     if (!gx || !whhT_fwd || !whhT_rev || !out || B <= 0 || T <= 0 || T_out <= 0 || T_out > T || 4 * H != 1024) return T2S_EINVAL;
@@ -77,9 +88,10 @@ int t2s_taco_encoder_lstm(const float* gx, const float* whhT_fwd, const float* w
     return T2S_OK;
 }
 
-int t2s_bernoulli_mask(unsigned char* mask, size_t n, unsigned long long seed, unsigned long long offset, void* stream) {
-    if (!mask || n == 0) return T2S_EINVAL;
-    T2S_CHECK_HIP(t2s_launch_bernoulli_mask(mask, n, seed, offset, (hipStream_t)stream));
+int t2s_bernoulli_mask(unsigned char* mask, size_t n, unsigned long long seed, unsigned long long offset, float keep_prob,
+                       void* stream) {
+    if (!mask || n == 0 || !(keep_prob > 0.f && keep_prob <= 1.f)) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_bernoulli_mask(mask, n, seed, offset, keep_prob, (hipStream_t)stream));
     return T2S_OK;
 }
 

@@ -79,6 +79,10 @@ hipError_t t2s_launch_bn_fold(const float* gamma, const float* beta, const float
                               const float* conv_bias, float eps, int C, float* scale, float* bias_out,
                               hipStream_t stream);
 hipError_t t2s_launch_bernoulli_mask(unsigned char* mask, size_t n, unsigned long long seed, unsigned long long offset,
-                                     hipStream_t stream);
+                                     float keep_prob, hipStream_t stream);
 hipError_t t2s_launch_stop_check(const float* gate_out, int B, int s_gate_b, int step0, int n, float threshold,
                                  int* stop_step, hipStream_t stream);
+hipError_t t2s_launch_bn_train(const float* x, const float* gamma, const float* beta, float eps, int act,
+                               const unsigned char* mask, float mask_scale, int B, int C, int T, int Lp, int halo,
+                               float* mean, float* var, unsigned short* O_hi, unsigned short* O_lo, float* out_f32,
+                               hipStream_t stream);

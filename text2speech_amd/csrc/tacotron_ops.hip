@@ -677,16 +677,18 @@ hipError_t t2s_launch_bn_fold(const float* gamma, const float* beta, const float
 }
 
 // Bernoulli(0.5) prenet masks from a counter hash (used when the caller does not inject masks)
-__global__ void bernoulli_mask_kernel(unsigned char* mask, size_t n, unsigned long long seed, unsigned long long offset) {
+__global__ void bernoulli_mask_kernel(unsigned char* mask, size_t n, unsigned long long seed, unsigned long long offset,
+                                      unsigned int keep_thr) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     unsigned long long x = (i + offset) * 0x9E3779B97F4A7C15ull + seed;
     x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
-    mask[i] = (unsigned char)(x & 1);
+    mask[i] = (unsigned char)(((unsigned int)(x >> 40)) < keep_thr);      // 24 random bits vs keep probability
 }
 hipError_t t2s_launch_bernoulli_mask(unsigned char* mask, size_t n, unsigned long long seed, unsigned long long offset,
-                                     hipStream_t stream) {
-    hipLaunchKernelGGL(bernoulli_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mask, n, seed, offset);
+                                     float keep_prob, hipStream_t stream) {
+    const unsigned int thr = (unsigned int)(keep_prob * 16777216.0f);
+    hipLaunchKernelGGL(bernoulli_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mask, n, seed, offset, thr);
     return hipGetLastError();
 }
 
@@ -704,5 +706,74 @@ hipError_t t2s_launch_stop_check(const float* gate_out, int B, int s_gate_b, int
                                  int* stop_step, hipStream_t stream) {
     hipLaunchKernelGGL(stop_check_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, gate_out, B, s_gate_b, step0, n,
                        threshold, stop_step);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Training-mode BatchNorm1d after a conv (reference tacotron.py:183-184,193-194; modules.py:105-137):
+// batch statistics over (B, T) per channel, affine, activation, dropout mask, result written as planes.
+// x: [B][C][T] f32 (the conv output).  stats[c] = (mean, biased var).
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int B, int C, int T, float* mean,
+                                                       float* var) {
+    __shared__ double red[2][4];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float* row = x + ((size_t)b * C + c) * T;
+        for (int t = tid; t < T; t += 256) {
+            const double v = row[t];
+            s += v;
+            ss += v * v;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off, 64);
+        ss += __shfl_xor(ss, off, 64);
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = ss; }
+    __syncthreads();
+    if (tid == 0) {
+        const double n = (double)B * T;
+        const double m = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / n;
+        const double q = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / n;
+        mean[c] = (float)m;
+        var[c] = (float)(q - m * m);
+    }
+}
+// y = act((x - mean) / sqrt(var + eps) * gamma + beta) * mask * mask_scale -> planes (and optional f32 copy)
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act,
+                                const unsigned char* __restrict__ mask, float mask_scale, int C, int T, int Lp, int halo,
+                                u16* O_hi, u16* O_lo, float* out_f32) {
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int b = blockIdx.z;
+    const int nch = (C + 31) / 32;
+    if (t >= T) return;
+    for (int c = blockIdx.y * 32 + (threadIdx.x >> 6); c < blockIdx.y * 32 + 32; c += 4) {
+        float v = 0.f;
+        if (c < C) {
+            const size_t i = ((size_t)b * C + c) * T + t;
+            v = (x[i] - mean[c]) / sqrtf(var[c] + eps) * gamma[c] + beta[c];
+            if (act == ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == ACT_TANH) v = tanhf(v);
+            if (mask) v = mask[i] ? v * mask_scale : 0.f;
+            if (out_f32) out_f32[i] = v;
+        }
+        if (O_hi) {
+            u16 h, l;
+            split_bf16(v, h, l);
+            const size_t idx = (((size_t)b * nch + (c >> 5)) * Lp + halo + t) * 32 + (c & 31);
+            O_hi[idx] = h;
+            O_lo[idx] = l;
+        }
+    }
+}
+hipError_t t2s_launch_bn_train(const float* x, const float* gamma, const float* beta, float eps, int act,
+                               const unsigned char* mask, float mask_scale, int B, int C, int T, int Lp, int halo,
+                               float* mean, float* var, u16* O_hi, u16* O_lo, float* out_f32, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C), dim3(256), 0, stream, x, B, C, T, mean, var);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((T + 63) / 64, (C + 31) / 32, B), dim3(256), 0, stream, x, mean, var, gamma,
+                       beta, eps, act, mask, mask_scale, C, T, Lp, halo, O_hi, O_lo, out_f32);
     return hipGetLastError();
 }

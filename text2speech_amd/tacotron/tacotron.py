@@ -132,7 +132,9 @@ class _TacoEngine:
 
     def prepare(self, dev):
         m = self.m
-        key = tuple(p._version for p in m.parameters()) + tuple(b._version for b in m.buffers()) + (str(dev),)
+        key = tuple(p._version for p in m.parameters()) + (str(dev), m.training)
+        if not m.training:       # BatchNorm running statistics are folded into the eval-mode weights
+            key += tuple(b._version for b in m.buffers())
         if self.prep is not None and self.prep_key == key:
             return self.prep
         st = _lib.current_stream()
@@ -140,6 +142,9 @@ class _TacoEngine:
         P = {}
         P["emb"] = _f32(m.embedding.weight)
         P["enc_convs"] = [self._pack_conv_bn(seq, dev, 2) for seq in enc.convolutions]
+        if m.training:
+            P["enc_convs_plain"] = [self._pack_conv_plain(seq, dev) for seq in enc.convolutions]
+            P["post_convs_plain"] = [self._pack_conv_plain(seq, dev) for seq in m.postnet.convolutions]
         # BiLSTM: one input-projection GEMM for both directions, bias = b_ih + b_hh
         H = enc.lstm.hidden_size
         w_ih = torch.cat([_f32(enc.lstm.weight_ih_l0), _f32(enc.lstm.weight_ih_l0_reverse)], 0).contiguous()
@@ -217,8 +222,9 @@ class _TacoEngine:
                   layer["Cout"], layer.get("taps", 1), 1, act, L, Lp, halo, layer["Mpad"], _lib.current_stream())
         return Oh, Ol
 
-    def encode(self, ids, lengths):
-        """Embedding + Encoder.forward / .inference (reference tacotron.py:40,192-220)."""
+    def encode(self, ids, lengths, train_masks=None, seed=0):
+        """Embedding + Encoder.forward / .inference (reference tacotron.py:40,192-220).  In training mode the
+        convolutions use batch statistics and dropout(0.5) (masks from ``train_masks['enc']`` or drawn here)."""
         m, P = self.m, self.prep
         dev = ids.device
         st = _lib.current_stream()
@@ -231,8 +237,14 @@ class _TacoEngine:
         Xl = torch.zeros_like(Xh)
         _lib.call("t2s_embed_planes", _lib.ptr(ids64), _lib.ptr(P["emb"]), B, T, E, m.embedding.num_embeddings, Lp, halo,
                   _lib.ptr(Xh), _lib.ptr(Xl), st)
-        for layer in P["enc_convs"]:
-            Xh, Xl = self._conv(layer, Xh, Xl, B, T, Lp, halo, 1)
+        if m.training:
+            given = None if train_masks is None else train_masks.get("enc")
+            for i, (seq, layer) in enumerate(zip(m.encoder.convolutions, P["enc_convs_plain"])):
+                mk = self._drop(None if given is None else given[i], (B, layer["Cout"], T), 0.5, dev, seed + 101 + i)
+                Xh, Xl = self._conv_bn_train(seq, layer, Xh, Xl, B, T, Lp, halo, 1, mk)
+        else:
+            for layer in P["enc_convs"]:
+                Xh, Xl = self._conv(layer, Xh, Xl, B, T, Lp, halo, 1)
         H = P["H"]
         gx = torch.empty(B, T, 8 * H, dtype=torch.float32, device=dev)
         self._conv(P["lstm_in"], Xh, Xl, B, T, Lp, halo, 0, out_planes=False, out_f32=gx, f32_cl=1)
@@ -287,9 +299,11 @@ class _TacoEngine:
             S[name] = t
         return d, S
 
-    def postnet(self, mel):
-        """Postnet.forward in eval mode (reference modules.py:131-137): 5 x conv+BN, tanh on the first four."""
+    def postnet(self, mel, train_masks=None, seed=0):
+        """Postnet.forward (reference modules.py:131-137): 5 x conv+BN, tanh on the first four; in training mode
+        batch statistics and dropout(0.5) after every layer."""
         P = self.prep
+        m = self.m
         B, C, T = mel.shape
         halo = 2
         Lp = _lib.plane_rows(T, halo)
@@ -300,6 +314,15 @@ class _TacoEngine:
         _lib.call("t2s_f32_to_planes", _lib.ptr(mel), B, C, T, Lp, halo, _lib.ptr(Xh), _lib.ptr(Xl), _lib.current_stream())
         n = len(P["post_convs"])
         out = torch.empty(B, C, T, dtype=torch.float32, device=dev)
+        if m.training:
+            given = None if train_masks is None else train_masks.get("post")
+            for i, (seq, layer) in enumerate(zip(m.postnet.convolutions, P["post_convs_plain"])):
+                mk = self._drop(None if given is None else given[i], (B, layer["Cout"], T), 0.5, dev, seed + 201 + i)
+                if i < n - 1:
+                    Xh, Xl = self._conv_bn_train(seq, layer, Xh, Xl, B, T, Lp, halo, 2, mk)
+                else:
+                    self._conv_bn_train(seq, layer, Xh, Xl, B, T, Lp, halo, 0, mk, want_planes=False, out_f32=out)
+            return out
         for i, layer in enumerate(P["post_convs"]):
             if i < n - 1:
                 Xh, Xl = self._conv(layer, Xh, Xl, B, T, Lp, halo, 2)
@@ -313,8 +336,54 @@ class _TacoEngine:
             assert mk.numel() >= n * B * 2 * Pd, "prenet_masks too short"
             return mk
         mk = torch.empty(n, B, 2, Pd, dtype=torch.uint8, device=dev)
-        _lib.call("t2s_bernoulli_mask", _lib.ptr(mk), mk.numel(), int(seed), 0, _lib.current_stream())
+        _lib.call("t2s_bernoulli_mask", _lib.ptr(mk), mk.numel(), int(seed), 0, 0.5, _lib.current_stream())
         return mk
+
+    def _drop(self, given, shape, keep, dev, seed):
+        """{0,1} bytes: injected (parity tests) or drawn on the device with keep probability ``keep``."""
+        if given is not None:
+            return given.to(device=dev, dtype=torch.uint8).contiguous()
+        mk = torch.empty(*shape, dtype=torch.uint8, device=dev)
+        _lib.call("t2s_bernoulli_mask", _lib.ptr(mk), mk.numel(), int(seed), 0, float(keep), _lib.current_stream())
+        return mk
+
+    def _pack_conv_plain(self, seq, dev):
+        """ConvNorm alone (training mode: BatchNorm uses batch statistics, so nothing is folded)."""
+        conv = seq[0].conv
+        O, Cin, Kt = conv.weight.shape
+        Cpad, Mpad = -(-Cin // 32) * 32, _lib.padded_rows(O)
+        A_hi = torch.zeros(Kt * Cpad // 32, Mpad, 32, dtype=torch.bfloat16, device=dev)
+        A_lo = torch.zeros_like(A_hi)
+        bias = torch.zeros(Mpad, dtype=torch.float32, device=dev)
+        w, cb = _f32(conv.weight), (None if conv.bias is None else _f32(conv.bias))
+        _lib.call("t2s_pack_conv_weight", _lib.ptr(w), None, 0, _lib.ptr(cb), O, Cin, Kt, 0, 0, 0, Mpad, 0, Cpad,
+                  _lib.ptr(A_hi), _lib.ptr(A_lo), _lib.ptr(bias), 0, _lib.current_stream())
+        return dict(A_hi=A_hi, A_lo=A_lo, bias=bias, Mpad=Mpad, Cin=Cin, Cout=O, taps=Kt, keep=(w, cb))
+
+    def _conv_bn_train(self, seq, layer, Xh, Xl, B, T, Lp, halo, act, mask, want_planes=True, out_f32=None):
+        """conv -> BatchNorm1d with batch statistics (+ running-stat update, as nn.BatchNorm1d.train() does) ->
+        activation -> dropout mask (reference tacotron.py:193-194; modules.py:131-137)."""
+        bn = seq[1]
+        dev = Xh.device
+        C = layer["Cout"]
+        y = torch.empty(B, C, T, dtype=torch.float32, device=dev)
+        self._conv(layer, Xh, Xl, B, T, Lp, halo, 0, out_planes=False, out_f32=y)
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        var = torch.empty(C, dtype=torch.float32, device=dev)
+        Oh = Ol = None
+        if want_planes:
+            Oh = torch.zeros(B, -(-C // 32), Lp, 32, dtype=torch.bfloat16, device=dev)
+            Ol = torch.zeros_like(Oh)
+        g, be = _f32(bn.weight), _f32(bn.bias)
+        _lib.call("t2s_bn_train", _lib.ptr(y), _lib.ptr(g), _lib.ptr(be), float(bn.eps), act, _lib.ptr(mask), 2.0, B, C, T, Lp,
+                  halo, _lib.ptr(mean), _lib.ptr(var), _lib.ptr(Oh), _lib.ptr(Ol), _lib.ptr(out_f32), _lib.current_stream())
+        with torch.no_grad():          # bookkeeping of nn.BatchNorm1d in training mode ([C]-sized vectors)
+            n = B * T
+            mom = 0.1 if bn.momentum is None else bn.momentum
+            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(var * (n / max(1, n - 1)), alpha=mom)
+            bn.num_batches_tracked += 1
+        return Oh, Ol
 
     # ------------------------------------------------------------------ whole-model paths
     def inference(self, ids, prenet_masks=None, seed=0, chunk=64):
@@ -352,12 +421,12 @@ class _TacoEngine:
         mel_post = mel + self.postnet(mel)
         return [mel, mel_post, gate, align]
 
-    def forward(self, text, text_lengths, mels, output_lengths, prenet_masks=None, seed=0):
+    def forward(self, text, text_lengths, mels, output_lengths, prenet_masks=None, seed=0, train_masks=None):
         m = self.m
         dec = m.decoder
         dev = text.device
         self.prepare(dev)
-        memory, len32 = self.encode(text, text_lengths)
+        memory, len32 = self.encode(text, text_lengths, train_masks, seed)
         B, n_mel, T_out = mels.shape
         Pd, D, E = dec.prenet_dim, dec.decoder_rnn_dim, memory.size(2)
         P = self.prep
@@ -372,7 +441,16 @@ class _TacoEngine:
         mk1 = mk.view(-1)[Pd:]
         self._gemv(P["w_pre2"], p1, Pd, items, Pd, pre_all, act=1, mask=mk1, smask=2 * Pd, mask_scale=2.0)
         hc_all = torch.empty(T_out, B, D + E, dtype=torch.float32, device=dev)
-        d, S = self._decoder_struct(memory, len32, T_out, True, dict(pre_all=pre_all, hc_all=hc_all))
+        extra = dict(pre_all=pre_all, hc_all=hc_all)
+        if m.training:      # dropout on both LSTM outputs (reference tacotron.py:368-369,383-384)
+            tm = train_masks or {}
+            extra["att_drop"] = self._drop(tm.get("att"), (T_out, B, dec.attention_rnn_dim), 1 - dec.p_attention_dropout,
+                                           dev, seed + 301)
+            extra["dec_drop"] = self._drop(tm.get("dec"), (T_out, B, D), 1 - dec.p_decoder_dropout, dev, seed + 302)
+        d, S = self._decoder_struct(memory, len32, T_out, True, extra)
+        if m.training:
+            d.att_drop_scale = 1.0 / (1.0 - dec.p_attention_dropout)
+            d.dec_drop_scale = 1.0 / (1.0 - dec.p_decoder_dropout)
         _lib.call("t2s_taco_decode_steps", ctypes.byref(d), 0, T_out, _lib.current_stream())
         # hoisted projection + gate over all steps (reference tacotron.py:387-392)
         proj = torch.empty(T_out * B, n_mel + 1, dtype=torch.float32, device=dev)
@@ -380,7 +458,7 @@ class _TacoEngine:
         proj = proj.view(T_out, B, n_mel + 1)
         mel = proj[:, :, :n_mel].permute(1, 2, 0).contiguous()
         gate = proj[:, :, n_mel].permute(1, 0).contiguous()
-        mel_post = mel + self.postnet(mel)
+        mel_post = mel + self.postnet(mel, train_masks, seed)
         return [mel, mel_post, gate, S["align_out"]]
 
 
@@ -416,21 +494,27 @@ class Tacotron(nn.Module):
     def _check(self, t):
         if not t.is_cuda:
             raise _lib.T2SError("Tacotron (MI355X build) needs CUDA/HIP tensors; got %s - there is no CPU fallback" % t.device)
-        if self.training:
-            raise NotImplementedError("training-mode Tacotron forward (BatchNorm batch statistics, dropout, backward) "
-                                      "is not built yet on the MI355X path; call .eval()")
 
-    def forward(self, inputs, prenet_masks=None):
-        """Teacher-forced forward (reference tacotron.py:36-49)."""
+    def forward(self, inputs, prenet_masks=None, train_masks=None):
+        """Teacher-forced forward (reference tacotron.py:36-49).  In ``.train()`` mode BatchNorm uses batch statistics
+        and every dropout is live (``train_masks`` = {'enc': [3 x [B,C,T_in]], 'att': [T,B,H], 'dec': [T,B,H],
+        'post': [5 x [B,C,T]]} of {0,1} injects the draws; otherwise they are drawn on the device).  The backward
+        pass is not built yet: calling this with autograd enabled on trainable parameters raises."""
         text_inputs, text_lengths, mels, max_len, speaker_id, output_lengths = inputs
         self._check(text_inputs)
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("the Tacotron-2 backward pass is not built yet on the MI355X path; run the "
+                                      "training-mode forward under torch.no_grad()")
         with torch.no_grad():
-            out = self._eng().forward(text_inputs, text_lengths.data, mels, output_lengths.data, prenet_masks)
+            out = self._eng().forward(text_inputs, text_lengths.data, mels, output_lengths.data, prenet_masks,
+                                      train_masks=train_masks)
         return self.parse_output(out, output_lengths.data)
 
     def inference(self, inputs, speaker_id=None, prenet_masks=None):
         """Autoregressive decode (reference tacotron.py:51-65)."""
         self._check(inputs)
+        if self.training:
+            raise NotImplementedError("Tacotron.inference is an eval-mode path (reference inference.py:61); call .eval()")
         with torch.no_grad():
             out = self._eng().inference(inputs, prenet_masks)
         return self.parse_output(out)
