@@ -254,9 +254,11 @@ int t2s_conv_accumulate(const void* A_hi, const void* A_lo, const float* zero_bi
                         void* O_hi, void* O_lo, int B, int Cin, int Cout, int taps, int dilation, int init, int L, int Lp,
                         int halo, int Mpad, void* stream);
 
-/* out[b][m][n] = sum_t A_tm[b][t][m] * X_tm[b][t][n]  (one split-K slab per batch entry b) */
+/* out[b*ksplit + s][m][n] = sum over time chunks [k0,k1) (split s of ksplit) of A_tm[b][t][m] * X_tm[b][t][n]:
+ * B*ksplit split-K slabs; chunks outside [k0,k1) (the zero halo) are skipped */
 int t2s_wgrad_gemm(const void* A_hi, const void* A_lo, const void* X_hi, const void* X_lo, const float* zero_bias,
-                   float* out, int B, int M, int N, int Mpad, int Npad, int n_tchunks, void* stream);
+                   float* out, int B, int M, int N, int Mpad, int Npad, int n_tchunks, int k0, int k1, int ksplit,
+                   void* stream);
 
 int t2s_plane_transpose(const void* src_hi, const void* src_lo, int B, int src_chunks, int n_chunks, int Lp, int shift,
                         void* dst_hi, void* dst_lo, int Npad, int n_off, void* stream);

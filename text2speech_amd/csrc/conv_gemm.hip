@@ -73,8 +73,16 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int mt = logical % a.n_mtiles;
     const int tt_all = logical / a.n_mtiles;
-    const int b = tt_all / a.n_ttiles;
+    const int bs = tt_all / a.n_ttiles;              // batch entry (x K-split): also the output slab index
     const int t0 = (tt_all % a.n_ttiles) * T2S_TILE_N;
+    int b = bs, kbeg = 0, nk_split = a.nk;
+    if (a.ksplit > 1 || a.k0 > 0) {                  // split-K over time chunks (weight-gradient GEMMs)
+        const int sp = a.ksplit > 1 ? bs % a.ksplit : 0;
+        b = a.ksplit > 1 ? bs / a.ksplit : bs;
+        kbeg = a.k0 + sp * a.kchunk;
+        nk_split = min(a.kchunk, a.kend - kbeg);
+        if (nk_split < 0) nk_split = 0;
+    }
 
     // ---- per-thread DMA source offsets (bytes) ----
     // LDS linear slot p = j*512 + tid (16 B each): row = p>>2 = j*128 + (tid>>2), slot q = tid&3.
@@ -82,10 +90,12 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     const int thr_off = (tid >> 2) * 64 + (((tid & 3) ^ swz4((tid >> 4) & 3)) * 16);
     const char* A_hi = (const char*)a.A_hi + (size_t)b * a.a_bstride * 2 + (size_t)mt * MT * 64 + thr_off;
     const char* A_lo = (const char*)a.A_lo + (size_t)b * a.a_bstride * 2 + (size_t)mt * MT * 64 + thr_off;
+    A_hi += (size_t)kbeg * a.Mpad * 64;
+    A_lo += (size_t)kbeg * a.Mpad * 64;
     const size_t a_kstride = (size_t)a.Mpad * 64;
     const size_t x_cstride = (size_t)a.Lp * 64;            // bytes per 32-channel chunk
-    const char* X_hi = (const char*)a.X_hi + ((size_t)b * a.xc * a.Lp + a.halo + t0) * 64 + thr_off;
-    const char* X_lo = (const char*)a.X_lo + ((size_t)b * a.xc * a.Lp + a.halo + t0) * 64 + thr_off;
+    const char* X_hi = (const char*)a.X_hi + (((size_t)b * a.xc + kbeg) * a.Lp + a.halo + t0) * 64 + thr_off;
+    const char* X_lo = (const char*)a.X_lo + (((size_t)b * a.xc + kbeg) * a.Lp + a.halo + t0) * 64 + thr_off;
     const char* S_hi = (const char*)a.S_hi + ((size_t)b * a.sc * a.Lp + a.halo + t0) * 64 + thr_off;
     const char* S_lo = (const char*)a.S_lo + ((size_t)b * a.sc * a.Lp + a.halo + t0) * 64 + thr_off;
     char* lds_wave = smem + wave * 1024;                   // + lane*16 is implicit in the DMA
@@ -127,8 +137,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = a.nk;
-    stage(0, 0);
+    const int nk = nk_split;
+    if (nk > 0) stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -352,8 +362,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
             const int ch = mt * MT + wr * (MT / 2) + m * 16 + rq;
             if (ch >= a.C) continue;
             const f32x4 bv = *(const f32x4*)(a.bias + ch);
-            u16* ohi = a.O_hi ? a.O_hi + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31) : nullptr;
-            u16* olo = a.O_lo ? a.O_lo + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31) : nullptr;
+            u16* ohi = a.O_hi ? a.O_hi + (((size_t)bs * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31) : nullptr;
+            u16* olo = a.O_lo ? a.O_lo + (((size_t)bs * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31) : nullptr;
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const int t = t0 + wc * 64 + n * 16 + tcol;
@@ -365,8 +375,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
                     if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
                     else if (a.act == ACT_TANH) v = fast_tanh(v);
                     if (a.out_f32) {
-                        if (a.f32_cl) a.out_f32[((size_t)b * a.L + t) * a.C + ch + e] = v;
-                        else a.out_f32[((size_t)b * a.C + ch + e) * a.L + t] = v;
+                        if (a.f32_cl) a.out_f32[((size_t)bs * a.L + t) * a.C + ch + e] = v;
+                        else a.out_f32[((size_t)bs * a.C + ch + e) * a.L + t] = v;
                     }
                     u16 h, l;
                     split_bf16(v, h, l);

@@ -122,17 +122,22 @@ int t2s_conv_accumulate(const void* A_hi, const void* A_lo, const float* zero_bi
     a.xc = cdiv(Cin, 32); a.sc = 0; a.oc = cdiv(Cout, 32);
     a.taps = taps; a.dil = dilation; a.nk_x = taps * a.xc; a.nk = a.nk_x;
     a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
-    a.n_mtiles = cdiv(Cout, 256); a.n_ttiles = cdiv(L, 256);
+    a.n_ttiles = cdiv(L, 256);
     a.C = 0; a.n_res = Cout; a.res_init = init;      // every row takes the residual branch
-    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_RESSKIP, (hipStream_t)stream));
+    // 128-row tiles when 256-row tiles would leave most CUs without a workgroup
+    const int mt_rows = (cdiv(Cout, 256) * a.n_ttiles * B <= 128 || Cout % 256 == 0) && cdiv(Cout, 256) * a.n_ttiles * B < 200 ? 128 : 256;
+    a.n_mtiles = cdiv(Cout, mt_rows);
+    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_RESSKIP, (hipStream_t)stream, mt_rows));
     return T2S_OK;
 }
 
 int t2s_wgrad_gemm(const void* A_hi, const void* A_lo, const void* X_hi, const void* X_lo, const float* zero_bias,
-                   float* out, int B, int M, int N, int Mpad, int Npad, int n_tchunks, void* stream) {
+                   float* out, int B, int M, int N, int Mpad, int Npad, int n_tchunks, int k0, int k1, int ksplit,
+                   void* stream) {
     if (!planes_ok(A_hi, A_lo) || !planes_ok(X_hi, X_lo) || !zero_bias || !out) return T2S_EINVAL;
     if (B <= 0 || M <= 0 || N <= 0 || M % 4 || Mpad % 256 || Mpad < M || Npad != cdiv(N, 256) * 256 || n_tchunks <= 0)
         return T2S_EINVAL;
+    if (k0 < 0 || k1 > n_tchunks || k0 >= k1 || ksplit < 1 || ksplit > 16) return T2S_EINVAL;
     ConvGemmArgs a;
     memset(&a, 0, sizeof(a));
     a.A_hi = (const u16*)A_hi; a.A_lo = (const u16*)A_lo; a.a_bstride = (long)n_tchunks * Mpad * 32;
@@ -140,7 +145,8 @@ int t2s_wgrad_gemm(const void* A_hi, const void* A_lo, const void* X_hi, const v
     a.bias = zero_bias; a.out_f32 = out;
     a.xc = n_tchunks; a.sc = 0; a.oc = cdiv(M, 32);
     a.taps = 1; a.dil = 1; a.nk_x = n_tchunks; a.nk = n_tchunks;
-    a.Mpad = Mpad; a.Lp = Npad; a.halo = 0; a.L = N; a.B = B;
+    a.Mpad = Mpad; a.Lp = Npad; a.halo = 0; a.L = N; a.B = B * ksplit;
+    a.ksplit = ksplit; a.k0 = k0; a.kend = k1; a.kchunk = cdiv(k1 - k0, ksplit);
     a.n_mtiles = cdiv(M, 256); a.n_ttiles = cdiv(N, 256);
     a.C = M; a.act = ACT_NONE;
     T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_BIAS_ACT, (hipStream_t)stream));
