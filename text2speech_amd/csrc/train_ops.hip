@@ -127,8 +127,10 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const WnBwdArgs a) {
     const int n = a.Cin * a.Kt;
     const float* vrow = a.v + (size_t)o * n;
     float dot = 0.f, ss = 0.f;
-    for (int i = tid; i < n; i += 256) {
-        const int c = i / a.Kt, tap = i - c * a.Kt;
+    // (tap, c) order: consecutive threads read consecutive slab columns (the slabs are nsplit x the row length)
+    for (int j = tid; j < n; j += 256) {
+        const int tap = j / a.Cin, c = j - tap * a.Cin;
+        const int i = c * a.Kt + tap;
         float dw = 0.f;
         for (int s = 0; s < a.nsplit; ++s)
             dw += a.P[((size_t)s * a.Prows + a.row_off + o) * a.Pcols + a.col_off + tap * a.tap_stride + c];
