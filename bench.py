@@ -79,6 +79,53 @@ def cpu_baseline(cfg, sd, sample_batch=2, n_samples=16000, reps=3):
                       % (sample_batch, n_samples, 8 // sample_batch, reps)}
 
 
+def tacotron_metrics(dev):
+    """Second half of BASELINE.json's metric: Tacotron-2 mel-frames/s (autoregressive B=1; teacher-forced eval forward
+    at the configs[1] shape B=32, T_in=256, T_out=800) and the decoder step's weight stream against the HBM roofline."""
+    from text2speech_amd.tacotron import Tacotron
+    hp = dict(synth.TACOTRON_HPARAMS)
+    m = Tacotron(hp, 80, num_speakers=2)
+    m.load_state_dict(synth.tacotron_state())
+    m = m.to(dev).eval()
+    out = {}
+    ids = (torch.arange(64) % 78 + 2)[None].to(dev)
+    n = 400
+    m.decoder.gate_threshold, m.decoder.max_decoder_steps = 2.0, n
+    m.inference(ids, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        m.inference(ids, None)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    dec = m.decoder
+    A, D, E, P = dec.attention_rnn_dim, dec.decoder_rnn_dim, dec.encoder_embedding_dim, dec.prenet_dim
+    lstm_bytes = 4.0 * (4 * A * (P + E + A) + 4 * D * (A + E + D))          # f32 LSTMCell weights streamed per step
+    out["inference_B1"] = {"mel_frames_per_s": n / dt, "us_per_step": dt / n * 1e6, "frames": n, "symbols": 64}
+    out["roofline"] = {"bound": "hbm", "kernel": "decoder step (2 x lstm_cell_kernel + attention + projection)",
+                       "achieved": lstm_bytes / (dt / n) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                       "frac": lstm_bytes / (dt / n) / 1e9 / 8000.0,
+                       "algorithmic_bytes_per_step": lstm_bytes,
+                       "note": "71.3 MB of LSTMCell weights per step over the whole step time (5 dependent launches, "
+                               "latency-bound at B=1); the two cell kernels alone stream them at ~3.9 TB/s"}
+    B, T_in, T_out = 32, 256, 800
+    gen = torch.Generator().manual_seed(21)
+    text = torch.randint(2, 80, (B, T_in), generator=gen).to(dev)
+    mel = torch.randn(B, 80, T_out, generator=gen).to(dev)
+    il = torch.full((B,), T_in, dtype=torch.long, device=dev)
+    ol = torch.full((B,), T_out, dtype=torch.long, device=dev)
+    inp = (text, il, mel, T_in, torch.zeros(B, device=dev), ol)
+    m(inp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        m(inp)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 2
+    out["forward_B32_Tin256_Tout800"] = {"mel_frames_per_s": B * T_out / dt, "ms": dt * 1e3}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +134,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--segment", type=int, default=16000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tacotron", action="store_true", help="skip the Tacotron mel-frames/s block (N=1 only)")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward: the headline metric (default); train: zero_grad+forward+loss+backward+Adam, "
                          "data-parallel over RCCL when launched with N > 1 ranks (BASELINE configs[3])")
@@ -214,6 +262,11 @@ def main():
                        else "dp%d, 13 bucketed RCCL all-reduces overlapped with backward" % args.gpus},
             "roofline": roof,
         }
+        if args.gpus == 1 and args.mode == "forward" and not args.no_tacotron:
+            log("tacotron metrics")
+            del model, eng
+            torch.cuda.empty_cache()
+            out["tacotron"] = tacotron_metrics(dev)
         if args.gpus == 1 and not args.no_cpu_baseline and args.mode == "forward":
             out["cpu_baseline"] = cpu_baseline(cfg, sd)
         print(json.dumps(out), flush=True)

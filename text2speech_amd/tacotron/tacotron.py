@@ -12,6 +12,7 @@ Training-mode forward (BatchNorm batch statistics, encoder / LSTM / postnet drop
 not built yet and raises.
 """
 import ctypes
+import sys
 from math import sqrt
 
 import torch
@@ -414,7 +415,7 @@ class _TacoEngine:
                 n_done = int(sv.max().item()) + 1
                 break
         else:
-            print("Warning! Reached max decoder steps")
+            print("Warning! Reached max decoder steps", file=sys.stderr)     # reference tacotron.py:458 (stdout there)
         mel = mel_gate[:, :n_mel, :n_done].contiguous()
         gate = mel_gate[:, n_mel, :n_done].unsqueeze(-1).contiguous()          # [B, T, 1] as the reference returns
         align = S["align_out"][:, :n_done].contiguous()
