@@ -107,6 +107,13 @@ int t2s_small_logdet_inv(const float* W, int n, float scale, float* logdet_out, 
     return T2S_OK;
 }
 
+int t2s_small_logdet_inv_batch(const t2s_small_mat_job* jobs, int n_jobs, float scale, void* stream) {
+    if (!jobs || n_jobs <= 0) return T2S_EINVAL;
+    static_assert(sizeof(t2s_small_mat_job) == sizeof(SmallMatJob), "t2s_small_mat_job layout");
+    T2S_CHECK_HIP(t2s_launch_small_logdet_batch((const SmallMatJob*)jobs, n_jobs, scale, (hipStream_t)stream));
+    return T2S_OK;
+}
+
 int t2s_wg_start(const float* z, const float* w, const float* bias, int B, int n_group, int c_off, int n_half, int C,
                  int L, int Lp, int halo, void* X_hi, void* X_lo, void* stream) {
     if (!z || !w || !bias || !X_hi || !X_lo) return T2S_EINVAL;

@@ -296,6 +296,50 @@ __global__ void small_logdet_inv_kernel(const float* W, int n, float scale, floa
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j) inv_out[i * n + j] = (float)a[i][n + j];
 }
+// all flows in one launch: block k handles matrix k (device table of pointers / sizes)
+__global__ void small_logdet_batch_kernel(const SmallMatJob* jobs, float scale) {
+    __shared__ double a[16][32];
+    if (threadIdx.x != 0) return;
+    const SmallMatJob j = jobs[blockIdx.x];
+    const int n = (int)j.n;
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < n; ++c) {
+            a[i][c] = j.W[i * n + c];
+            a[i][n + c] = (i == c) ? 1.0 : 0.0;
+        }
+    double logabs = 0.0;
+    int sign = 1;
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        double best = fabs(a[c][c]);
+        for (int r = c + 1; r < n; ++r)
+            if (fabs(a[r][c]) > best) { best = fabs(a[r][c]); piv = r; }
+        if (piv != c) {
+            for (int q = 0; q < 2 * n; ++q) { double tmp = a[c][q]; a[c][q] = a[piv][q]; a[piv][q] = tmp; }
+            sign = -sign;
+        }
+        const double d = a[c][c];
+        if (d < 0) sign = -sign;
+        logabs += log(fabs(d));
+        const double inv = 1.0 / d;
+        for (int q = 0; q < 2 * n; ++q) a[c][q] *= inv;
+        for (int r = 0; r < n; ++r) {
+            if (r == c) continue;
+            const double f = a[r][c];
+            if (f == 0.0) continue;
+            for (int q = 0; q < 2 * n; ++q) a[r][q] -= f * a[c][q];
+        }
+    }
+    if (j.logdet_out) *j.logdet_out = sign > 0 ? (float)(logabs * (double)scale) : __builtin_nanf("");
+    if (j.inv_out)
+        for (int i = 0; i < n; ++i)
+            for (int c = 0; c < n; ++c) j.inv_out[i * n + c] = (float)a[i][n + c];
+}
+hipError_t t2s_launch_small_logdet_batch(const SmallMatJob* jobs, int n_jobs, float scale, hipStream_t stream) {
+    hipLaunchKernelGGL(small_logdet_batch_kernel, dim3(n_jobs), dim3(64), 0, stream, jobs, scale);
+    return hipGetLastError();
+}
+
 hipError_t t2s_launch_small_logdet_inv(const float* W, int n, float scale, float* logdet_out, float* inv_out,
                                        hipStream_t stream) {
     hipLaunchKernelGGL(small_logdet_inv_kernel, dim3(1), dim3(64), 0, stream, W, n, scale, logdet_out, inv_out);

@@ -337,13 +337,17 @@ class _Engine:
         _lib.call("t2s_wg_audio_squeeze", _lib.ptr(audio32), _lib.ptr(z), B, T, G, L, 0, st)
         log_s_list, log_det_list = [], []
         log_det = torch.empty(m.n_flows, dtype=torch.float32, device=dev)
-        keep = []
+        Ws = [_f32c(m.convinv[k].conv.weight) for k in range(m.n_flows)]
+        keep = list(Ws)
+        # B*L*logdet(W_k) of all flows in one launch (reference glow.py:100)
+        jkey = tuple(w_.data_ptr() for w_ in Ws) + (log_det.data_ptr(),)
+        jobs = torch.tensor([[Ws[k].data_ptr(), log_det.data_ptr() + 4 * k, 0, self._flow_geom(k)[1]]
+                             for k in range(m.n_flows)], dtype=torch.int64).to(dev)
+        keep.append(jobs)
+        _lib.call("t2s_small_logdet_inv_batch", _lib.ptr(jobs), m.n_flows, float(B * L), st)
         for k in range(m.n_flows):
             c_off, n_rem, n_half = self._flow_geom(k)
-            Wk = _f32c(m.convinv[k].conv.weight)
-            keep.append(Wk)
-            _lib.call("t2s_small_logdet_inv", _lib.ptr(Wk), n_rem, float(B * L), _lib.c_vp(log_det.data_ptr() + 4 * k),
-                      None, st)
+            Wk = Ws[k]
             _lib.call("t2s_wg_convinv", _lib.ptr(z), _lib.ptr(Wk), B, G, c_off, n_rem, L, st)
             self._wn(k, z, B, L, w, c_off, n_half)
             log_s = torch.empty(B, n_half, L, dtype=torch.float32, device=dev)
