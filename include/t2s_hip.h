@@ -217,6 +217,11 @@ typedef struct t2s_taco_decoder {
     float *mel_gate_out;                 /* [B][n_mel+1][T_cap] (autoregressive), row n_mel = gate logit */
     float *align_out;                    /* [B][T_cap][T_in] */
     float *hc_all;                       /* teacher forced: [T][B][dec+enc] */
+    /* training saves (teacher forced; all NULL otherwise): per step t */
+    float *att_gates_all, *att_c_all;    /* [T][B][4H], [T][B][H] attention-LSTM gates (post-activation i,f,g,o) / cell state */
+    float *dec_gates_all, *dec_c_all;    /* same for the decoder LSTM */
+    float *att_h_all;                    /* [T][B][H] attention-LSTM output after dropout */
+    float *q_all, *wcum_all;             /* [T][B][att_dim] queries, [T][B][T_in] cumulative weights after the step */
 } t2s_taco_decoder;
 
 /* Enqueue decoder steps [step0, step0+n_steps) (Decoder.decode, tacotron.py:355-393, plus in autoregressive mode

@@ -136,6 +136,8 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         ca.h_in = ah_in; ca.h_out = ah_out; ca.c = d->att_c; ca.B = B; ca.H = A;
         if (d->att_drop) { ca.drop_mask = d->att_drop + (size_t)s * B * A; ca.drop_scale = d->att_drop_scale; }
         const bool fused_att = B <= 8 && T <= 512 && d->w_loc_denseT && d->att_dim <= 128;
+        if (d->att_gates_all) { ca.gates_out = d->att_gates_all + (size_t)s * B * 4 * A; ca.c_out = d->att_c_all + (size_t)s * B * A; }
+        if (d->att_h_all) { ca.h_copy = d->att_h_all + (size_t)s * B * A; ca.s_copy = A; }
         T2S_CHECK_HIP(t2s_launch_lstm_cell(ca, stream));
         // 2.-4. attention: query, location-sensitive energies, softmax, context, cumulative weights
         AttArgs aa;
@@ -147,6 +149,8 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         if (d->teacher_forced) { aa.ctx_copy = d->hc_all + (size_t)s * B * (D + E) + D; aa.s_ctx_copy = D + E; }
         aa.B = B; aa.T = T; aa.att_dim = d->att_dim; aa.enc_dim = E; aa.loc_f = d->loc_filters; aa.loc_ks = d->loc_kernel;
         aa.w_query = d->w_query; aa.h_att = ah_out; aa.w_loc_denseT = d->w_loc_denseT; aa.att_rnn = A;
+        if (d->q_all) aa.q_save = d->q_all + (size_t)s * B * d->att_dim;
+        if (d->wcum_all) aa.wcum_save = d->wcum_all + (size_t)s * B * T;
         if (fused_att) {
             // small batch: one fused launch per step (one workgroup per batch element)
             T2S_CHECK_HIP(t2s_launch_att_fused(aa, stream));
@@ -154,7 +158,9 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
             GemvArgs qa;
             memset(&qa, 0, sizeof(qa));
             qa.W1 = d->w_query; qa.ld1 = A; qa.k1 = A; qa.x1 = ah_out; qa.n1 = A; qa.sx1 = A;
-            qa.y = d->q; qa.sy_item = d->att_dim; qa.sy_row = 1; qa.rows = d->att_dim; qa.items = B;
+            qa.y = d->q_all ? d->q_all + (size_t)s * B * d->att_dim : d->q; qa.sy_item = d->att_dim; qa.sy_row = 1;
+            qa.rows = d->att_dim; qa.items = B;
+            aa.q = qa.y;
             T2S_CHECK_HIP(t2s_launch_gemv(qa, stream));
             T2S_CHECK_HIP(t2s_launch_att_energy(aa, stream));
             T2S_CHECK_HIP(t2s_launch_att_softmax_ctx(aa, stream));
@@ -167,6 +173,7 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         cd.h_in = dh_in; cd.h_out = dh_out; cd.c = d->dec_c; cd.B = B; cd.H = D;
         if (d->dec_drop) { cd.drop_mask = d->dec_drop + (size_t)s * B * D; cd.drop_scale = d->dec_drop_scale; }
         if (d->teacher_forced) { cd.h_copy = d->hc_all + (size_t)s * B * (D + E); cd.s_copy = D + E; }
+        if (d->dec_gates_all) { cd.gates_out = d->dec_gates_all + (size_t)s * B * 4 * D; cd.c_out = d->dec_c_all + (size_t)s * B * D; }
         T2S_CHECK_HIP(t2s_launch_lstm_cell(cd, stream));
         if (!d->teacher_forced) {
             // 6./7. mel frame + gate logit = W_proj [h_dec | ctx] + b, and (same launch, second row block) layer 0

@@ -35,6 +35,8 @@ struct LstmCellArgs {
     float* h_copy; long s_copy;           // optional second copy of h_out (stride per item)
     const unsigned char* drop_mask; float drop_scale;   // optional dropout on h_out ([B][H] of 0/1)
     int B, H;
+    float* gates_out;    // optional [B][4H]: post-activation i,f,g,o (training: kept for the backward pass)
+    float* c_out;        // optional [B][H]: new cell state copy
     // optional: per-workgroup partial attention queries q_part[wg][b][a] = sum_{u in wg} w_q[a][u] * h_out[b][u]
     const float* w_q; float* q_part; int q_dim;
 };
@@ -61,6 +63,8 @@ struct AttArgs {
     int att_rnn;
     const float* q_part;       // [n_part][B][att_dim] partial queries from lstm_cell_kernel (instead of w_query . h_att)
     int n_part;
+    float* q_save;             // optional [B][att_dim]: query of this step (training)
+    float* wcum_save;          // optional [B][T]: cumulative weights after this step (training)
 };
 
 hipError_t t2s_launch_gemv(const GemvArgs& a, hipStream_t stream);

@@ -124,17 +124,19 @@ hipError_t t2s_launch_gemv(const GemvArgs& a, hipStream_t stream) {
 // One wave per hidden unit u keeps rows {u, H+u, 2H+u, 3H+u} of [W_ih | W_hh] in registers and loops
 // over the batch; lane (b mod 64) then does the pointwise update for item b.  h is ping-ponged by the
 // caller (h_in read by every workgroup, h_out written by the owner), c is updated in place.
-// Work split: a workgroup owns 4 hidden units; each unit's K range is split over 4 waves (16 waves per
-// workgroup, so every CU has 16 waves streaming weights instead of 4 - the cell is latency-bound at B=1).
+// Work split: a workgroup owns 2 hidden units; each unit's K range is split over 4 waves (8 waves per workgroup,
+// two workgroups per CU: 16 waves per CU streaming weights - the cell is latency-bound at B=1 - while the
+// 512-thread block keeps a 256-VGPR budget, so nothing spills).
 // Wave (unit, kq) keeps float4 slots v = kq, kq+4, ... of its four gate rows in registers; partial sums
 // meet in LDS and thread (unit, item) applies the cell update.
-template <int NVW>
-__global__ __launch_bounds__(1024) void lstm_cell_kernel(const LstmCellArgs a) {
-    __shared__ float s_part[4][4][4][64];            // [unit][kq][gate][item]
+// UNITS = hidden units per workgroup (4 -> 1024 threads, 2 -> 512 threads); SAVE = keep gates / cell state (training)
+template <int NVW, int UNITS, bool SAVE>
+__global__ __launch_bounds__(UNITS * 256) void lstm_cell_kernel(const LstmCellArgs a) {
+    __shared__ float s_part[UNITS][4][4][64];        // [unit][kq][gate][item]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int ul = wave >> 2, kq = wave & 3;
-    const int u = blockIdx.x * 4 + ul;               // H % 4 == 0 is checked by the caller
+    const int u = blockIdx.x * UNITS + ul;           // H % UNITS == 0 is checked by the caller
     const int K1 = a.n1 + a.n2, K = K1 + a.H;
     f32x4 w[4][NVW];
     const float* xp[NVW];
@@ -187,9 +189,15 @@ __global__ __launch_bounds__(1024) void lstm_cell_kernel(const LstmCellArgs a) {
                           (a.b_ih[g * a.H + u] + a.b_hh[g * a.H + u]);
             const size_t idx = (size_t)it * a.H + u;
             const float c = a.c[idx];
-            const float c2 = sigmoid_acc(gsum[1]) * c + sigmoid_acc(gsum[0]) * tanhf(gsum[2]);
-            float h2 = sigmoid_acc(gsum[3]) * tanhf(c2);
+            const float gi_ = sigmoid_acc(gsum[0]), gf_ = sigmoid_acc(gsum[1]), gg_ = tanhf(gsum[2]), go_ = sigmoid_acc(gsum[3]);
+            const float c2 = gf_ * c + gi_ * gg_;
+            float h2 = go_ * tanhf(c2);
             a.c[idx] = c2;
+            if (SAVE && a.gates_out) {
+                float* go = a.gates_out + (size_t)it * 4 * a.H + u;
+                go[0] = gi_; go[a.H] = gf_; go[2 * a.H] = gg_; go[3 * a.H] = go_;
+                a.c_out[idx] = c2;
+            }
             if (a.drop_mask) h2 = a.drop_mask[idx] ? h2 * a.drop_scale : 0.f;
             a.h_out[idx] = h2;
             if (a.h_copy) a.h_copy[(size_t)it * a.s_copy + u] = h2;
@@ -203,8 +211,13 @@ hipError_t t2s_launch_lstm_cell(const LstmCellArgs& a, hipStream_t stream) {
     const int nv4 = (K + 255) / 256;
     const int nvw = (nv4 + 3) / 4;
     if (a.H % 4) return hipErrorInvalidValue;
-    dim3 grid(a.H / 4);
-#define LL(N) hipLaunchKernelGGL(lstm_cell_kernel<N>, grid, dim3(1024), 0, stream, a)
+    // eval / inference: 4 units per 1024-thread workgroup (128-VGPR cap, fits without the save code);
+    // training saves: 2 units per 512-thread workgroup (256-VGPR budget)
+#define LL(N)                                                                                                     \
+    do {                                                                                                          \
+        if (a.gates_out) hipLaunchKernelGGL((lstm_cell_kernel<N, 2, true>), dim3(a.H / 2), dim3(512), 0, stream, a); \
+        else hipLaunchKernelGGL((lstm_cell_kernel<N, 4, false>), dim3(a.H / 4), dim3(1024), 0, stream, a);          \
+    } while (0)
     if (nvw <= 1) LL(1);
     else if (nvw <= 2) LL(2);
     else if (nvw <= 3) LL(3);
@@ -308,7 +321,9 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_kernel(const AttArgs a) {
         const float w = s_w[t] * inv;
         s_w[t] = w;
         a.w_prev[(size_t)b * T + t] = w;
-        a.w_cum[(size_t)b * T + t] += w;
+        const float wc = a.w_cum[(size_t)b * T + t] + w;
+        a.w_cum[(size_t)b * T + t] = wc;
+        if (a.wcum_save) a.wcum_save[(size_t)b * T + t] = wc;
         if (a.align_out) a.align_out[(size_t)b * a.s_align_b + t] = w;
     }
     __syncthreads();
@@ -421,6 +436,7 @@ __global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
         }
     }
     __syncthreads();
+    if (a.q_save && tid < AD) a.q_save[(size_t)b * AD + tid] = s_q[tid];
     // ---- location features f[t][:] = conv1d([w ; w_cum]) ----
     for (int i = tid; i < T * F; i += 1024) {
         const int t = i / F, f = i - t * F;
@@ -478,7 +494,9 @@ __global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
         const float w = s_e[t] * inv;
         s_e[t] = w;
         a.w_prev[(size_t)b * T + t] = w;
-        a.w_cum[(size_t)b * T + t] += w;
+        const float wc = a.w_cum[(size_t)b * T + t] + w;
+        a.w_cum[(size_t)b * T + t] = wc;
+        if (a.wcum_save) a.wcum_save[(size_t)b * T + t] = wc;
         if (a.align_out) a.align_out[(size_t)b * a.s_align_b + t] = w;
     }
     __syncthreads();

@@ -95,7 +95,8 @@ class _DecoderStruct(ctypes.Structure):
            "memory", "pmem", "mem_lengths", "pre_all", "prenet_masks", "att_drop", "dec_drop"]
     _F = ["att_drop_scale", "dec_drop_scale"]
     _P2 = ["att_h0", "att_h1", "att_c", "dec_h0", "dec_h1", "dec_c", "att_w", "att_wcum", "ctx", "q", "energies",
-           "pre1", "pre2", "q_part", "mel_gate_out", "align_out", "hc_all"]
+           "pre1", "pre2", "q_part", "mel_gate_out", "align_out", "hc_all", "att_gates_all", "att_c_all",
+           "dec_gates_all", "dec_c_all", "att_h_all", "q_all", "wcum_all"]
     _fields_ = ([(n, ctypes.c_int) for n in _I] + [(n, ctypes.c_void_p) for n in _P1] +
                 [(n, ctypes.c_float) for n in _F] + [(n, ctypes.c_void_p) for n in _P2])
 
