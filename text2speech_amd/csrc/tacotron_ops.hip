@@ -189,13 +189,13 @@ __global__ __launch_bounds__(UNITS * 256) void lstm_cell_kernel(const LstmCellAr
                           (a.b_ih[g * a.H + u] + a.b_hh[g * a.H + u]);
             const size_t idx = (size_t)it * a.H + u;
             const float c = a.c[idx];
-            const float gi_ = sigmoid_acc(gsum[0]), gf_ = sigmoid_acc(gsum[1]), gg_ = tanhf(gsum[2]), go_ = sigmoid_acc(gsum[3]);
-            const float c2 = gf_ * c + gi_ * gg_;
-            float h2 = go_ * tanhf(c2);
+            const float c2 = sigmoid_acc(gsum[1]) * c + sigmoid_acc(gsum[0]) * tanhf(gsum[2]);
+            float h2 = sigmoid_acc(gsum[3]) * tanhf(c2);
             a.c[idx] = c2;
-            if (SAVE && a.gates_out) {
+            if constexpr (SAVE) {      // training: post-activation gates and the new cell state, for the backward pass
                 float* go = a.gates_out + (size_t)it * 4 * a.H + u;
-                go[0] = gi_; go[a.H] = gf_; go[2 * a.H] = gg_; go[3 * a.H] = go_;
+                go[0] = sigmoid_acc(gsum[0]); go[a.H] = sigmoid_acc(gsum[1]); go[2 * a.H] = tanhf(gsum[2]);
+                go[3 * a.H] = sigmoid_acc(gsum[3]);
                 a.c_out[idx] = c2;
             }
             if (a.drop_mask) h2 = a.drop_mask[idx] ? h2 * a.drop_scale : 0.f;
