@@ -311,6 +311,49 @@ typedef struct t2s_adam_job {
 int t2s_adam_table(const t2s_adam_job* jobs, int n_jobs, long total_blocks, float lr, float beta1, float beta2,
                    float eps, int step, float gscale, float weight_decay, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Tacotron-2 training step, backward (reference: autograd over tacotron/tacotron.py:36-49,355-429 and
+ * tacotron/modules.py:19-22,94-137; loop train.py:219-225).  Weight gradients of every Linear / LSTM matrix contract
+ * over (step, batch) items and reuse t2s_wgrad_gemm on time-major planes built by t2s_rows_to_tm.
+ */
+/* x[item - shift][c] (f32 rows, stride ld) -> time-major planes tm[item/32][n_off + c][item%32]; items_pad % 32 == 0 */
+int t2s_rows_to_tm(const float* x, long ld, int items, int items_pad, int shift, int C, void* dst_hi, void* dst_lo,
+                   int Npad, int n_off, void* stream);
+/* LSTMCell backward, pointwise part: dh = (dh1+dh2+dh3)*dropout -> dgates[B][4H] (i,f,g,o), dc_carry updated in place */
+int t2s_lstm_cell_bwd(const float* dh1, long s1, const float* dh2, long s2, const float* dh3, long s3,
+                      const unsigned char* drop_mask, float drop_scale, const float* gates, const float* c_new,
+                      const float* c_prev, float* dc_carry, float* dgates, int B, int H, void* stream);
+/* dz = (y > 0) ? scale*dy : 0  (backward of relu followed by dropout-with-scale, e.g. the prenet) */
+int t2s_relu_drop_bwd(const float* dy, const float* y, float scale, size_t n, float* dz, void* stream);
+
+typedef struct t2s_att_bwd {
+    const float *dctx1; long sc1; const float *dctx2; long sc2; const float *dctx3; long sc3;
+    const float *w_cur; long s_wcur;
+    const float *w_prev, *wc_prev; long s_wprev, s_wcprev;
+    const float *q, *pmem, *memory; const int *lengths;
+    const float *w_loc_conv, *w_loc_dense, *w_v;
+    float *dw_carry, *dwc_carry, *d_q, *d_pmem, *d_memory, *dD_part, *dK_part, *dv_part;
+    int B, T, att_dim, enc_dim, loc_f, loc_ks;
+} t2s_att_bwd;
+/* one decoder step of the location-sensitive attention, backward (tacotron.py:124-166,379); T <= 256 */
+int t2s_taco_att_bwd(const t2s_att_bwd* a, void* stream);
+
+typedef struct t2s_bn_bwd_args {
+    const float *x, *mean, *var, *gamma, *beta; float eps;
+    const float *dout_f32; const void *dout_hi, *dout_lo;
+    const unsigned char *mask; float mask_scale; int act;
+    float *dgamma, *dbeta; void *dx_hi, *dx_lo;
+    int B, C, T, Lp, halo;
+} t2s_bn_bwd_args;
+/* training-mode BatchNorm1d backward fused with the backward of activation + dropout; dx as planes */
+int t2s_bn_bwd(const t2s_bn_bwd_args* a, void* stream);
+/* out[j] = sum_i in[i][j] ; out = a + b (+ c) */
+int t2s_sum_axis0(const float* in, int n0, int n, float* out, void* stream);
+int t2s_add3(const float* a, const float* b, const float* c, size_t n, float* out, void* stream);
+/* planes -> f32 [B][C][L] (accumulate=1: +=) */
+int t2s_planes_to_f32(const void* X_hi, const void* X_lo, int B, int C, int L, int Lp, int halo, float* out,
+                      int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

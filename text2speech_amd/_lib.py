@@ -54,6 +54,15 @@ SIGNATURES = {
     "t2s_bernoulli_mask": [c_vp, ctypes.c_size_t, ctypes.c_ulonglong, ctypes.c_ulonglong, c_float, c_vp],
     "t2s_taco_decode_steps": [c_vp, c_int, c_int, c_vp],
     "t2s_taco_stop_check": [c_vp, c_int, c_int, c_int, c_int, c_int, c_float, c_vp, c_vp],
+    "t2s_rows_to_tm": [c_vp, c_long, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp],
+    "t2s_lstm_cell_bwd": [c_vp, c_long, c_vp, c_long, c_vp, c_long, c_vp, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
+                          c_vp],
+    "t2s_relu_drop_bwd": [c_vp, c_vp, c_float, ctypes.c_size_t, c_vp, c_vp],
+    "t2s_taco_att_bwd": [c_vp, c_vp],
+    "t2s_bn_bwd": [c_vp, c_vp],
+    "t2s_sum_axis0": [c_vp, c_int, c_int, c_vp, c_vp],
+    "t2s_add3": [c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp],
+    "t2s_planes_to_f32": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp],
     "t2s_wg_in_cond_gate_train": [c_vp] * 13 + [c_int] * 9 + [c_vp],
     "t2s_wg_res_skip_train": [c_vp] * 10 + [c_int] * 8 + [c_vp],
     "t2s_wg_bwd_gate_dgrad": [c_vp] * 13 + [c_int] * 6 + [c_vp],

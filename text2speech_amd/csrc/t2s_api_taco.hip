@@ -18,7 +18,7 @@ static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static int gemv_args_ok(const GemvArgs& a) {
     if (!a.W1 || !a.x1 || !a.y || a.rows <= 0 || a.items <= 0) return 0;
     const int K = a.n1 + a.n2 + a.n3;
-    if (K != a.k1 + a.k2 || K > 2560) return 0;
+    if (K != a.k1 + a.k2 || K > 4096) return 0;
     if ((a.n1 | a.n2 | a.n3 | a.k1 | a.k2 | a.ld1 | a.ld2) & 3) return 0;
     if ((a.sx1 | a.sx2 | a.sx3) & 3) return 0;
     if (!al16(a.W1) || !al16(a.x1) || (a.W2 && !al16(a.W2)) || (a.x2 && !al16(a.x2)) || (a.x3 && !al16(a.x3))) return 0;

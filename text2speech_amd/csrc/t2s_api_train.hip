@@ -156,7 +156,7 @@ int t2s_wgrad_gemm(const void* A_hi, const void* A_lo, const void* X_hi, const v
 int t2s_plane_transpose(const void* src_hi, const void* src_lo, int B, int src_chunks, int n_chunks, int Lp, int shift,
                         void* dst_hi, void* dst_lo, int Npad, int n_off, void* stream) {
     if (!planes_ok(src_hi, src_lo) || !planes_ok(dst_hi, dst_lo) || B <= 0 || n_chunks <= 0 || n_chunks > src_chunks ||
-        Lp % 32 || n_off % 32 || n_off + n_chunks * 32 > Npad)
+        Lp <= 0 || n_off % 32 || n_off + n_chunks * 32 > Npad)
         return T2S_EINVAL;
     T2S_CHECK_HIP(t2s_launch_plane_transpose((const u16*)src_hi, (const u16*)src_lo, B, src_chunks, n_chunks, Lp, shift,
                                              (u16*)dst_hi, (u16*)dst_lo, Npad, n_off, (hipStream_t)stream));
@@ -164,7 +164,7 @@ int t2s_plane_transpose(const void* src_hi, const void* src_lo, int B, int src_c
 }
 
 int t2s_tm_ones_row(void* dst_hi, void* dst_lo, int B, int Lp, int halo, int L, int Npad, int n_row, void* stream) {
-    if (!dst_hi || !dst_lo || B <= 0 || Lp % 32 || n_row < 0 || n_row >= Npad) return T2S_EINVAL;
+    if (!dst_hi || !dst_lo || B <= 0 || Lp <= 0 || n_row < 0 || n_row >= Npad) return T2S_EINVAL;
     T2S_CHECK_HIP(t2s_launch_tm_ones_row((u16*)dst_hi, (u16*)dst_lo, B, Lp, halo, L, Npad, n_row, (hipStream_t)stream));
     return T2S_OK;
 }

@@ -1,0 +1,59 @@
+// Internal argument blocks of the Tacotron-2 backward kernels (taco_bwd_ops.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short u16;
+
+struct LstmBwdArgs {
+    const float* dh1; long s1;   // up to three gradient sources for h (per-item strides), any may be null
+    const float* dh2; long s2;
+    const float* dh3; long s3;
+    const unsigned char* drop_mask; float drop_scale;   // [B][H] or null
+    const float* gates;          // [B][4H] post-activation i,f,g,o
+    const float* c_new;          // [B][H]
+    const float* c_prev;         // [B][H] or null (zeros)
+    float* dc_carry;             // [B][H] in/out
+    float* dgates;               // [B][4H] out
+    int B, H;
+};
+
+struct AttBwdArgs {
+    const float* dctx1; long sc1; const float* dctx2; long sc2; const float* dctx3; long sc3;   // gradient sources of ctx_t
+    const float* w_cur; long s_wcur;      // w_t [B][.] (row stride)
+    const float* w_prev; const float* wc_prev; long s_wprev; long s_wcprev;   // w_{t-1}, wc_{t-1} (null: zeros), row strides
+    const float* q;              // [B][att_dim] query of this step
+    const float* pmem;           // [B][T][att_dim]
+    const float* memory;         // [B][T][enc]
+    const int* lengths;
+    const float* w_loc_conv; const float* w_loc_dense; const float* w_v;
+    float* dw_carry;             // [B][T] in: dL/dw_t from step t+1's features; out: same for step t-1
+    float* dwc_carry;            // [B][T] in: dL/dwc_t; out: dL/dwc_{t-1}
+    float* d_q;                  // [B][att_dim] out
+    float* d_pmem;               // [B][T][att_dim] +=
+    float* d_memory;             // [B][T][enc] +=
+    float* dD_part; float* dK_part; float* dv_part;   // per-batch-element partial parameter gradients, +=
+    int B, T, att_dim, enc_dim, loc_f, loc_ks;
+};
+
+struct BnBwdArgs {
+    const float* x;              // conv output [B][C][T] (pre-BN)
+    const float* mean; const float* var; const float* gamma; const float* beta; float eps;
+    const float* dout_f32;       // [B][C][T] or null
+    const u16* dout_hi; const u16* dout_lo;   // planes or null
+    const unsigned char* mask; float mask_scale; int act;
+    float* dgamma; float* dbeta; // [C]
+    u16* dx_hi; u16* dx_lo;      // planes out
+    int B, C, T, Lp, halo;
+};
+
+hipError_t t2s_launch_rows_to_tm(const float* x, long ld, int items, int items_pad, int shift, int C, u16* dst_hi,
+                                 u16* dst_lo, int Npad, int n_off, hipStream_t stream);
+hipError_t t2s_launch_lstm_cell_bwd(const LstmBwdArgs& a, hipStream_t stream);
+hipError_t t2s_launch_relu_drop_bwd(const float* dy, const float* y, float scale, size_t n, float* dz, hipStream_t stream);
+hipError_t t2s_launch_att_bwd(const AttBwdArgs& a, hipStream_t stream);
+hipError_t t2s_launch_bn_bwd(const BnBwdArgs& a, hipStream_t stream);
+hipError_t t2s_launch_planes_to_f32(const u16* X_hi, const u16* X_lo, int B, int C, int L, int Lp, int halo, float* out,
+                                    int accumulate, hipStream_t stream);
+hipError_t t2s_launch_sum_axis0(const float* in, int n0, int n, float* out, hipStream_t stream);
+hipError_t t2s_launch_add3(const float* a, const float* b, const float* c, size_t n, float* out, hipStream_t stream);

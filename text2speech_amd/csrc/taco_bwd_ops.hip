@@ -1,0 +1,365 @@
+// Backward kernels of the Tacotron-2 training step (reference: autograd over tacotron/tacotron.py:36-49,
+// 355-429 and tacotron/modules.py:19-22,94-137, driven by train.py:219-225).
+//
+// Weight gradients of every Linear / LSTM matrix are GEMMs that contract over (step, batch) "items": the f32 row
+// tensors [items][C] are turned into time-major (hi, lo) planes by rows_to_tm_kernel and fed to the same split-K
+// conv_gemm weight-gradient path the WaveGlow backward uses.  What is genuinely sequential - the per-step chain
+// through the two LSTM cells and the location-sensitive attention - is the kernels below, one launch per stage.
+#include "t2s_common.h"
+#include "t2s_kernels.h"
+#include "taco_bwd_ops.h"
+
+static __device__ __forceinline__ float sum3(const float* a, long sa, const float* b, long sb, const float* c, long sc,
+                                              int item, int j) {
+    float v = 0.f;
+    if (a) v += a[(size_t)item * sa + j];
+    if (b) v += b[(size_t)item * sb + j];
+    if (c) v += c[(size_t)item * sc + j];
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32 rows x[item - shift][c0 + c] (row stride ld)  ->  time-major planes tm[item/32][n_off + c][item%32]
+__global__ __launch_bounds__(256) void rows_to_tm_kernel(const float* __restrict__ x, long ld, int items, int shift, int C,
+                                                         u16* dst_hi, u16* dst_lo, int Npad, int n_off) {
+    __shared__ float tile[32][33];
+    const int ic = blockIdx.x, cc = blockIdx.y, tid = threadIdx.x;
+    {
+        const int r = tid >> 3, q = tid & 7;
+        const int item = ic * 32 + r - shift;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = cc * 32 + q * 4 + e;
+            tile[r][q * 4 + e] = (item >= 0 && item < items && c < C) ? x[(size_t)item * ld + c] : 0.f;
+        }
+    }
+    __syncthreads();
+    {
+        const int ci = tid >> 3, tq = tid & 7;
+        if (cc * 32 + ci < C) {
+            u16x4 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u16 h, l;
+                split_bf16(tile[tq * 4 + e][ci], h, l);
+                vh[e] = h;
+                vl[e] = l;
+            }
+            const size_t idx = (((size_t)ic) * Npad + n_off + cc * 32 + ci) * 32 + tq * 4;
+            *(u16x4*)(dst_hi + idx) = vh;
+            *(u16x4*)(dst_lo + idx) = vl;
+        }
+    }
+}
+hipError_t t2s_launch_rows_to_tm(const float* x, long ld, int items, int items_pad, int shift, int C, u16* dst_hi,
+                                 u16* dst_lo, int Npad, int n_off, hipStream_t stream) {
+    hipLaunchKernelGGL(rows_to_tm_kernel, dim3(items_pad / 32, (C + 31) / 32), dim3(256), 0, stream, x, ld, items, shift, C,
+                       dst_hi, dst_lo, Npad, n_off);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// LSTMCell backward, pointwise part (torch gate order i,f,g,o):
+//   dh = (dh1 + dh2 + dh3) * dropout ;  do = dh tanh(c') ;  dc = dc_carry + dh o (1 - tanh(c')^2)
+//   dgates = (dc g i(1-i), dc c f(1-f), dc i (1-g^2), do o(1-o)) ;  dc_carry <- dc f
+__global__ void lstm_cell_bwd_kernel(const LstmBwdArgs a) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (u >= a.H) return;
+    float dh = sum3(a.dh1, a.s1, a.dh2, a.s2, a.dh3, a.s3, b, u);
+    const size_t idx = (size_t)b * a.H + u;
+    if (a.drop_mask) dh = a.drop_mask[idx] ? dh * a.drop_scale : 0.f;
+    const float* g4 = a.gates + (size_t)b * 4 * a.H + u;
+    const float gi = g4[0], gf = g4[a.H], gg = g4[2 * a.H], go = g4[3 * a.H];
+    const float tc = tanhf(a.c_new[idx]);
+    const float cp = a.c_prev ? a.c_prev[idx] : 0.f;
+    const float dc = a.dc_carry[idx] + dh * go * (1.f - tc * tc);
+    float* dg = a.dgates + (size_t)b * 4 * a.H + u;
+    dg[0] = dc * gg * gi * (1.f - gi);
+    dg[a.H] = dc * cp * gf * (1.f - gf);
+    dg[2 * a.H] = dc * gi * (1.f - gg * gg);
+    dg[3 * a.H] = dh * tc * go * (1.f - go);
+    a.dc_carry[idx] = dc * gf;
+}
+hipError_t t2s_launch_lstm_cell_bwd(const LstmBwdArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((a.H + 255) / 256, a.B), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// dz = (y > 0) ? scale * dy : 0   (backward of y = relu(z) * mask * scale; y > 0 iff z > 0 and mask == 1)
+__global__ void relu_drop_bwd_kernel(const float* dy, const float* y, float scale, size_t n, float* dz) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dz[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
+}
+hipError_t t2s_launch_relu_drop_bwd(const float* dy, const float* y, float scale, size_t n, float* dz, hipStream_t stream) {
+    hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dy, y, scale, n, dz);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// One step of the location-sensitive attention, backward (reference tacotron.py:124-166,379), one 512-thread
+// workgroup per batch element, T <= ATTB_MAXT.  Forward (recomputed here from the saved query / weights):
+//   f = conv1d([w_prev ; wc_prev], K) ; p = q + D f + pm ; e = v . tanh(p) ; w = softmax(e) ; ctx = w . mem ; wc = wc_prev + w
+#define ATTB_MAXT 256
+__global__ __launch_bounds__(512) void att_bwd_kernel(const AttBwdArgs a) {
+    __shared__ float s_cat[2][ATTB_MAXT + 64];
+    __shared__ float s_k[32 * 2 * 63];
+    __shared__ float s_f[ATTB_MAXT][33];
+    __shared__ float s_df[ATTB_MAXT][33];
+    __shared__ float s_d[32 * 128];          // D^T [f][a]
+    __shared__ float s_dw[ATTB_MAXT];
+    __shared__ float s_w[ATTB_MAXT];
+    __shared__ float s_dctx[512];
+    __shared__ float s_dp[8][128];
+    __shared__ float s_acc[128 * 32];        // cross-wave sum of dD, then reused
+    __shared__ float s_vec[2][128];          // dq, dv
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int T = a.T, AD = a.att_dim, KS = a.loc_ks, F = a.loc_f, pad = KS >> 1, E = a.enc_dim;
+    const int len = a.lengths ? a.lengths[b] : T;
+    // ---- loads ----
+    for (int c = tid; c < E; c += 512) s_dctx[c] = sum3(a.dctx1, a.sc1, a.dctx2, a.sc2, a.dctx3, a.sc3, b, c);
+    for (int i = tid; i < F * 2 * KS; i += 512) s_k[i] = a.w_loc_conv[i];
+    for (int i = tid; i < 2 * (T + KS - 1); i += 512) {
+        const int c = i / (T + KS - 1), j = i - c * (T + KS - 1);
+        const int t = j - pad;
+        const float* src = c ? a.wc_prev : a.w_prev;
+        s_cat[c][j] = (src && t >= 0 && t < T) ? src[(size_t)b * (c ? a.s_wcprev : a.s_wprev) + t] : 0.f;
+    }
+    for (int i = tid; i < 32 * 128; i += 512) {
+        const int f = i >> 7, ai = i & 127;
+        s_d[i] = (f < F && ai < AD) ? a.w_loc_dense[ai * F + f] : 0.f;
+        s_acc[i] = 0.f;
+    }
+    for (int t = tid; t < T; t += 512) s_w[t] = a.w_cur[(size_t)b * a.s_wcur + t];
+    if (tid < 128) { s_vec[0][tid] = 0.f; s_vec[1][tid] = 0.f; }
+    __syncthreads();
+    // ---- location features ----
+    for (int i = tid; i < T * F; i += 512) {
+        const int t = i / F, f = i - t * F;
+        float acc = 0.f;
+        for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < KS; ++j) acc += s_k[(f * 2 + c) * KS + j] * s_cat[c][t + j];
+        s_f[t][f] = acc;
+    }
+    // ---- d_w = mem . d_ctx + carries ; d_mem += w (x) d_ctx ----
+    for (int t = wave; t < T; t += 8) {
+        float acc = 0.f;
+        const size_t mo = ((size_t)b * T + t) * E;
+        const float wt = s_w[t];
+        for (int c = lane; c < E; c += 64) {
+            acc += a.memory[mo + c] * s_dctx[c];
+            a.d_memory[mo + c] += wt * s_dctx[c];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) s_dw[t] = acc + a.dw_carry[(size_t)b * T + t] + a.dwc_carry[(size_t)b * T + t];
+    }
+    __syncthreads();
+    // ---- softmax backward: d_e = w (d_w - sum w d_w) ----
+    float part = 0.f;
+    for (int t = tid; t < T; t += 512) part += s_w[t] * s_dw[t];
+    part = wave_sum(part);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    float sdot = 0.f;
+    for (int i = 0; i < 8; ++i) sdot += red[i];
+    __syncthreads();
+    for (int t = tid; t < T; t += 512) s_dw[t] = (t < len) ? s_w[t] * (s_dw[t] - sdot) : 0.f;      // now d_e
+    __syncthreads();
+    // ---- energies backward: attention_dim on lanes (2 per lane), one wave per time step ----
+    {
+        const float q0 = lane < AD ? a.q[(size_t)b * AD + lane] : 0.f, q1 = lane + 64 < AD ? a.q[(size_t)b * AD + lane + 64] : 0.f;
+        const float v0 = lane < AD ? a.w_v[lane] : 0.f, v1 = lane + 64 < AD ? a.w_v[lane + 64] : 0.f;
+        float dq0 = 0.f, dq1 = 0.f, dv0 = 0.f, dv1 = 0.f;
+        float dD0[32], dD1[32];
+#pragma unroll
+        for (int f = 0; f < 32; ++f) { dD0[f] = 0.f; dD1[f] = 0.f; }
+        for (int t = wave; t < T; t += 8) {
+            const size_t po = ((size_t)b * T + t) * AD;
+            float p0 = q0 + (lane < AD ? a.pmem[po + lane] : 0.f), p1 = q1 + (lane + 64 < AD ? a.pmem[po + lane + 64] : 0.f);
+#pragma unroll
+            for (int f = 0; f < 32; ++f) {
+                const float ff = s_f[t][f];
+                p0 += s_d[f * 128 + lane] * ff;
+                p1 += s_d[f * 128 + 64 + lane] * ff;
+            }
+            const float th0 = tanhf(p0), th1 = tanhf(p1);
+            const float de = s_dw[t];
+            const float dp0 = lane < AD ? de * v0 * (1.f - th0 * th0) : 0.f;
+            const float dp1 = lane + 64 < AD ? de * v1 * (1.f - th1 * th1) : 0.f;
+            dq0 += dp0; dq1 += dp1;
+            dv0 += de * th0; dv1 += de * th1;
+            if (lane < AD) a.d_pmem[po + lane] += dp0;
+            if (lane + 64 < AD) a.d_pmem[po + lane + 64] += dp1;
+#pragma unroll
+            for (int f = 0; f < 32; ++f) {
+                const float ff = s_f[t][f];
+                dD0[f] += dp0 * ff;
+                dD1[f] += dp1 * ff;
+            }
+            s_dp[wave][lane] = dp0;
+            s_dp[wave][lane + 64] = dp1;
+            // d_f[t][f] = sum_a D[a][f] d_pre[a]   (lanes 0..31 = f); same-wave LDS exchange
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 32) {
+                float acc = 0.f;
+                for (int ai = 0; ai < 128; ++ai) acc += s_d[lane * 128 + ai] * s_dp[wave][ai];
+                s_df[t][lane] = acc;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // deterministic cross-wave sums: waves add in turn
+        for (int w = 0; w < 8; ++w) {
+            if (wave == w) {
+                s_vec[0][lane] += dq0; s_vec[0][lane + 64] += dq1;
+                s_vec[1][lane] += dv0; s_vec[1][lane + 64] += dv1;
+#pragma unroll
+                for (int f = 0; f < 32; ++f) {
+                    s_acc[lane * 32 + f] += dD0[f];
+                    s_acc[(lane + 64) * 32 + f] += dD1[f];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < AD) {
+        a.d_q[(size_t)b * AD + tid] = s_vec[0][tid];
+        a.dv_part[(size_t)b * AD + tid] += s_vec[1][tid];
+    }
+    for (int i = tid; i < AD * F; i += 512) a.dD_part[(size_t)b * AD * F + i] += s_acc[(i / F) * 32 + (i % F)];
+    // ---- location conv backward: carries for step t-1 and the kernel gradient ----
+    for (int i = tid; i < 2 * T; i += 512) {
+        const int c = i / T, tp = i - c * T;           // gradient w.r.t. cat[c][tp]
+        float acc = 0.f;
+        for (int f = 0; f < F; ++f)
+            for (int j = 0; j < KS; ++j) {
+                const int t = tp - j + pad;           // cat index tp feeds output t with tap j: tp = t + j - pad
+                if (t >= 0 && t < T) acc += s_k[(f * 2 + c) * KS + j] * s_df[t][f];
+            }
+        if (c == 0) a.dw_carry[(size_t)b * T + tp] = acc;
+        else a.dwc_carry[(size_t)b * T + tp] += acc;
+    }
+    for (int i = tid; i < F * 2 * KS; i += 512) {
+        const int f = i / (2 * KS), r = i - f * 2 * KS, c = r / KS, j = r - c * KS;
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) acc += s_df[t][f] * s_cat[c][t + j];
+        a.dK_part[(size_t)b * F * 2 * KS + i] += acc;
+    }
+}
+hipError_t t2s_launch_att_bwd(const AttBwdArgs& a, hipStream_t stream) {
+    if (a.T > ATTB_MAXT || a.enc_dim > 512 || a.att_dim > 128 || a.loc_f > 32 || a.loc_ks > 63) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(att_bwd_kernel, dim3(a.B), dim3(512), 0, stream, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Training-mode BatchNorm backward fused with the backward of activation + dropout.  With y = act(bn(x)) * mask * s:
+//   dy' = d_out * mask * s * act'(.) ;  sums: S1 = sum dy', S2 = sum dy' xhat  over (B, T) per channel
+//   dx = gamma inv_std / N (N dy' - S1 - xhat S2) ;  dgamma = S2 ; dbeta = S1
+// d_out comes as f32 [B][C][T] or as planes (hi, lo); dx is written as planes (the dgrad / wgrad GEMM operand).
+static __device__ __forceinline__ float bn_dyp(const BnBwdArgs& a, int b, int c, int t, float xhat) {
+    const size_t i = ((size_t)b * a.C + c) * a.T + t;
+    float d;
+    if (a.dout_f32) d = a.dout_f32[i];
+    else {
+        const size_t pi = (((size_t)b * ((a.C + 31) / 32) + (c >> 5)) * a.Lp + a.halo + t) * 32 + (c & 31);
+        d = join_bf16(a.dout_hi[pi], a.dout_lo[pi]);
+    }
+    if (a.mask) d = a.mask[i] ? d * a.mask_scale : 0.f;
+    if (a.act != ACT_NONE) {
+        const float ybn = xhat * a.gamma[c] + a.beta[c];
+        if (a.act == ACT_RELU) d = ybn > 0.f ? d : 0.f;
+        else { const float th = tanhf(ybn); d *= 1.f - th * th; }
+    }
+    return d;
+}
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
+    __shared__ double red[2][4];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const float mu = a.mean[c], istd = 1.0f / sqrtf(a.var[c] + a.eps);
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < a.B; ++b)
+        for (int t = tid; t < a.T; t += 256) {
+            const float xhat = (a.x[((size_t)b * a.C + c) * a.T + t] - mu) * istd;
+            const float d = bn_dyp(a, b, c, t, xhat);
+            s1 += d;
+            s2 += d * xhat;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        a.dbeta[c] = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        a.dgamma[c] = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+__global__ void bn_bwd_apply_kernel(const BnBwdArgs a) {
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int b = blockIdx.z;
+    const int nch = (a.C + 31) / 32;
+    if (t >= a.T) return;
+    const float n = (float)a.B * a.T;
+    for (int c = blockIdx.y * 32 + (threadIdx.x >> 6); c < blockIdx.y * 32 + 32; c += 4) {
+        float dx = 0.f;
+        if (c < a.C) {
+            const float istd = 1.0f / sqrtf(a.var[c] + a.eps);
+            const float xhat = (a.x[((size_t)b * a.C + c) * a.T + t] - a.mean[c]) * istd;
+            const float d = bn_dyp(a, b, c, t, xhat);
+            dx = a.gamma[c] * istd / n * (n * d - a.dbeta[c] - xhat * a.dgamma[c]);
+        }
+        u16 h, l;
+        split_bf16(dx, h, l);
+        const size_t idx = (((size_t)b * nch + (c >> 5)) * a.Lp + a.halo + t) * 32 + (c & 31);
+        a.dx_hi[idx] = h;
+        a.dx_lo[idx] = l;
+    }
+}
+hipError_t t2s_launch_bn_bwd(const BnBwdArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(a.C), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((a.T + 63) / 64, (a.C + 31) / 32, a.B), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+// planes (hi, lo) -> f32 [B][C][L]
+__global__ void planes_to_f32_kernel(const u16* X_hi, const u16* X_lo, int C, int L, int Lp, int halo, float* out, int accumulate) {
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int b = blockIdx.z;
+    const int nch = (C + 31) / 32;
+    if (t >= L) return;
+    for (int c = blockIdx.y * 32 + (threadIdx.x >> 6); c < blockIdx.y * 32 + 32 && c < C; c += 4) {
+        const size_t idx = (((size_t)b * nch + (c >> 5)) * Lp + halo + t) * 32 + (c & 31);
+        const float v = join_bf16(X_hi[idx], X_lo[idx]);
+        float* o = out + ((size_t)b * C + c) * L + t;
+        *o = accumulate ? *o + v : v;
+    }
+}
+hipError_t t2s_launch_planes_to_f32(const u16* X_hi, const u16* X_lo, int B, int C, int L, int Lp, int halo, float* out,
+                                    int accumulate, hipStream_t stream) {
+    hipLaunchKernelGGL(planes_to_f32_kernel, dim3((L + 63) / 64, (C + 31) / 32, B), dim3(256), 0, stream, X_hi, X_lo, C, L,
+                       Lp, halo, out, accumulate);
+    return hipGetLastError();
+}
+
+// out[j] = sum_i in[i][j]   (per-batch-element partial parameter gradients -> the gradient)
+__global__ void sum_axis0_kernel(const float* in, int n0, int n, float* out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float s = 0.f;
+    for (int i = 0; i < n0; ++i) s += in[(size_t)i * n + j];
+    out[j] = s;
+}
+hipError_t t2s_launch_sum_axis0(const float* in, int n0, int n, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(sum_axis0_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, in, n0, n, out);
+    return hipGetLastError();
+}
+// out = a + b (+ c)
+__global__ void add3_kernel(const float* a, const float* b, const float* c, size_t n, float* out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i] + (c ? c[i] : 0.f);
+}
+hipError_t t2s_launch_add3(const float* a, const float* b, const float* c, size_t n, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(add3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, b, c, n, out);
+    return hipGetLastError();
+}

@@ -113,6 +113,7 @@ hipError_t t2s_launch_gemv(const GemvArgs& a, hipStream_t stream) {
     else if (nv4 <= 4) GL(4);
     else if (nv4 <= 7) GL(7);
     else if (nv4 <= 10) GL(10);
+    else if (nv4 <= 16) GL(16);
     else return hipErrorInvalidValue;
 #undef GL
     return hipGetLastError();

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void plane_transpose_kernel(const u16* __restr
 }
 hipError_t t2s_launch_plane_transpose(const u16* src_hi, const u16* src_lo, int B, int src_chunks, int n_chunks, int Lp,
                                       int shift, u16* dst_hi, u16* dst_lo, int Npad, int n_off, hipStream_t stream) {
-    const int n_tchunks = Lp / 32;
+    const int n_tchunks = (Lp + 31) / 32;      // rows beyond Lp read as zero
     hipLaunchKernelGGL(plane_transpose_kernel, dim3(n_tchunks, n_chunks, B), dim3(256), 0, stream, src_hi, src_lo,
                        src_chunks, Lp, shift, dst_hi, dst_lo, Npad, n_off, n_tchunks);
     return hipGetLastError();
@@ -54,7 +54,7 @@ __global__ void tm_ones_row_kernel(u16* dst_hi, u16* dst_lo, int Lp, int halo, i
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (t >= Lp) return;
-    const size_t idx = (((size_t)b * (Lp / 32) + (t >> 5)) * Npad + n_row) * 32 + (t & 31);
+    const size_t idx = (((size_t)b * ((Lp + 31) / 32) + (t >> 5)) * Npad + n_row) * 32 + (t & 31);
     dst_hi[idx] = (t >= halo && t < halo + L) ? (u16)0x3F80 : (u16)0;
     dst_lo[idx] = 0;
 }

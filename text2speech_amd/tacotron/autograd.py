@@ -1,0 +1,351 @@
+"""Training path of the MI355X Tacotron-2: teacher-forced forward with saved per-step state and a hand-scheduled
+backward that issues HIP kernels only (reference: autograd over tacotron/tacotron.py:36-49,355-429 and
+tacotron/modules.py:19-22,94-137, driven by train.py:219-225 `y_pred = model(x); loss = criterion(y_pred, y);
+loss.backward()`).
+
+Structure of the backward (all through the C ABI of libt2s_hip.so):
+  postnet  : BatchNorm(batch statistics)+tanh+dropout backward (t2s_bn_bwd), conv data gradients as convolutions
+             with transposed / mirrored weights (t2s_conv_accumulate), conv weight gradients as time-contracting GEMMs
+             (t2s_plane_transpose + t2s_wgrad_gemm)
+  decoder  : projection, then T_out steps in reverse: LSTM-cell pointwise backward (t2s_lstm_cell_bwd), W^T dgates
+             (t2s_gemv on transposed weights), attention backward (t2s_taco_att_bwd); weight gradients of both LSTM cells,
+             the query / memory / prenet / projection Linears as ONE split-K GEMM each over all (step, batch) items
+             (t2s_rows_to_tm + t2s_wgrad_gemm)
+  encoder  : BiLSTM BPTT, convolutions, embedding
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+from .tacotron import _f32
+
+vp, i32, f32c, lng = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long
+
+
+class _AttBwd(ctypes.Structure):
+    """Mirror of t2s_att_bwd."""
+    _fields_ = ([("dctx1", vp), ("sc1", lng), ("dctx2", vp), ("sc2", lng), ("dctx3", vp), ("sc3", lng),
+                 ("w_cur", vp), ("s_wcur", lng), ("w_prev", vp), ("wc_prev", vp), ("s_wprev", lng), ("s_wcprev", lng),
+                 ("q", vp), ("pmem", vp), ("memory", vp), ("lengths", vp), ("w_loc_conv", vp), ("w_loc_dense", vp),
+                 ("w_v", vp), ("dw_carry", vp), ("dwc_carry", vp), ("d_q", vp), ("d_pmem", vp), ("d_memory", vp),
+                 ("dD_part", vp), ("dK_part", vp), ("dv_part", vp)] +
+                [(n, i32) for n in ("B", "T", "att_dim", "enc_dim", "loc_f", "loc_ks")])
+
+
+class _BnBwd(ctypes.Structure):
+    """Mirror of t2s_bn_bwd_args."""
+    _fields_ = [("x", vp), ("mean", vp), ("var", vp), ("gamma", vp), ("beta", vp), ("eps", f32c), ("dout_f32", vp),
+                ("dout_hi", vp), ("dout_lo", vp), ("mask", vp), ("mask_scale", f32c), ("act", i32), ("dgamma", vp),
+                ("dbeta", vp), ("dx_hi", vp), ("dx_lo", vp), ("B", i32), ("C", i32), ("T", i32), ("Lp", i32), ("halo", i32)]
+
+
+def _p(t, off_elems=0):
+    """raw address of a tensor (+ element offset), None -> NULL"""
+    if t is None:
+        return None
+    return vp(t.data_ptr() + off_elems * t.element_size())
+
+
+def _ru(a, b):
+    return -(-a // b) * b
+
+
+class _Bwd:
+    def __init__(self, eng, sv):
+        self.eng, self.sv = eng, sv
+        self.m = eng.m
+        self.dev = sv["memory"].device
+        self.st = _lib.current_stream()
+        self.grads = {}
+        self.keep = []
+        self.zero_bias = torch.zeros(8192, dtype=torch.float32, device=self.dev)
+
+    def new(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.dev)
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+
+    def bf(self, *shape):
+        return torch.zeros(*shape, dtype=torch.bfloat16, device=self.dev)
+
+    # ------------------------------------------------------------------ generic pieces
+    def gemv(self, W, ld, K, x_ptr, sx, y_ptr, sy_item, rows, items):
+        _lib.call("t2s_gemv", _p(W), ld, K, None, 0, 0, x_ptr, K, sx, None, 0, 0, None, 0, 0, None, None, y_ptr, sy_item, 1,
+                  rows, items, 0, None, 0, 1.0, self.st)
+
+    def transpose(self, w2d):
+        R, C = w2d.shape
+        out = self.new(C, R)
+        _lib.call("t2s_transpose", _p(w2d), _p(out), R, C, self.st)
+        self.keep.append(w2d)
+        return out
+
+    def items_wgrad(self, items, a_srcs, x_srcs, M, N_cols):
+        """sum over items of A[item][m] * [X | 1][item][n] via the split-K GEMM.  a_srcs / x_srcs: lists of
+        (ptr, ld, C, row_off, shift).  Returns (P [nsplit][M4][N], nsplit, M4, N); column N-1 is the ones column."""
+        items_pad = _ru(items, 32)
+        nch = items_pad // 32
+        M4 = _ru(M, 4)
+        Mpad = _lib.padded_rows(M4)
+        N = N_cols + 1
+        Npad = _ru(N, 256)
+        A = (self.bf(nch, Mpad, 32), self.bf(nch, Mpad, 32))
+        X = (self.bf(nch, Npad, 32), self.bf(nch, Npad, 32))
+        for (ptr, ld, C, off, shift) in a_srcs:
+            _lib.call("t2s_rows_to_tm", ptr, ld, items, items_pad, shift, C, _p(A[0]), _p(A[1]), Mpad, off, self.st)
+        for (ptr, ld, C, off, shift) in x_srcs:
+            _lib.call("t2s_rows_to_tm", ptr, ld, items, items_pad, shift, C, _p(X[0]), _p(X[1]), Npad, off, self.st)
+        _lib.call("t2s_tm_ones_row", _p(X[0]), _p(X[1]), 1, items_pad, 0, items, Npad, N_cols, self.st)
+        ks = max(1, min(16, nch))
+        P = self.new(ks, M4, N)
+        _lib.call("t2s_wgrad_gemm", _p(A[0]), _p(A[1]), _p(X[0]), _p(X[1]), _p(self.zero_bias), _p(P), 1, M4, N, Mpad, Npad,
+                  nch, 0, nch, ks, self.st)
+        self.keep += [A, X]
+        return P, ks, M4, N
+
+    def slab_to_grad(self, P, ks, M4, N, param, O, Cin, col_off, bias_param=None, Kt=1, tap_stride=0):
+        w = _f32(param)
+        dW = self.new(*param.shape)
+        db = None if bias_param is None else self.new(O)
+        _lib.call("t2s_wn_backward", _p(P), ks, M4, N, 0, col_off, tap_stride, N - 1, _p(w), None, O, Cin, Kt, _p(dW), None,
+                  _p(db), 0, self.st)
+        self.grads[id(param)] = dW
+        if bias_param is not None:
+            self.grads[id(bias_param)] = db
+        self.keep.append(w)
+
+    # ------------------------------------------------------------------ conv + BatchNorm stack (postnet / encoder)
+    def conv_bn_stack_backward(self, saves, dout_f32):
+        """Backward of [conv -> BN(batch stats) -> act -> dropout] x n.  dout_f32: [B][C_last][T] gradient of the stack's
+        output.  Returns the gradient w.r.t. the stack's input as planes (hi, lo) with its channel count."""
+        d_planes = None
+        for i in reversed(range(len(saves))):
+            s = saves[i]
+            conv, bn, layer = s["seq"][0].conv, s["seq"][1], s["layer"]
+            B, T, Lp, halo = s["B"], s["T"], s["Lp"], s["halo"]
+            Cout, Cin, Kt = layer["Cout"], layer["Cin"], layer["taps"]
+            occ = -(-Cout // 32)
+            dconv = (self.bf(B, occ, Lp, 32), self.bf(B, occ, Lp, 32))
+            dgamma, dbeta = self.new(Cout), self.new(Cout)
+            g32, b32 = _f32(bn.weight), _f32(bn.bias)
+            a = _BnBwd(x=s["y"].data_ptr(), mean=s["mean"].data_ptr(), var=s["var"].data_ptr(), gamma=g32.data_ptr(),
+                       beta=b32.data_ptr(), eps=float(bn.eps),
+                       dout_f32=None if d_planes is not None else dout_f32.data_ptr(),
+                       dout_hi=None if d_planes is None else d_planes[0].data_ptr(),
+                       dout_lo=None if d_planes is None else d_planes[1].data_ptr(),
+                       mask=None if s["mask"] is None else s["mask"].data_ptr(), mask_scale=2.0, act=s["act"],
+                       dgamma=dgamma.data_ptr(), dbeta=dbeta.data_ptr(), dx_hi=dconv[0].data_ptr(), dx_lo=dconv[1].data_ptr(),
+                       B=B, C=Cout, T=T, Lp=Lp, halo=halo)
+            _lib.call("t2s_bn_bwd", ctypes.byref(a), self.st)
+            self.grads[id(bn.weight)], self.grads[id(bn.bias)] = dgamma, dbeta
+            self.keep += [g32, b32, dconv]
+            # conv weight gradient: contraction over time per batch element (split-K slabs), bias from the ones row
+            nt = -(-Lp // 32)
+            Cin_pad = _ru(Cin, 32)
+            Mpad = _lib.padded_rows(Cout)
+            Ncols = Kt * Cin_pad
+            N = Ncols + 1
+            Npad = _ru(N, 256)
+            A = (self.bf(B, nt, Mpad, 32), self.bf(B, nt, Mpad, 32))
+            X = (self.bf(B, nt, Npad, 32), self.bf(B, nt, Npad, 32))
+            _lib.call("t2s_plane_transpose", _p(dconv[0]), _p(dconv[1]), B, occ, occ, Lp, 0, _p(A[0]), _p(A[1]), Mpad, 0, self.st)
+            icc = Cin_pad // 32
+            for tap in range(Kt):
+                _lib.call("t2s_plane_transpose", _p(s["Xh"]), _p(s["Xl"]), B, icc, icc, Lp, tap - Kt // 2, _p(X[0]), _p(X[1]),
+                          Npad, tap * Cin_pad, self.st)
+            _lib.call("t2s_tm_ones_row", _p(X[0]), _p(X[1]), B, Lp, halo, T, Npad, Ncols, self.st)
+            M4 = _ru(Cout, 4)
+            P = self.new(B, M4, N)
+            _lib.call("t2s_wgrad_gemm", _p(A[0]), _p(A[1]), _p(X[0]), _p(X[1]), _p(self.zero_bias), _p(P), B, M4, N, Mpad,
+                      Npad, nt, 0, nt, 1, self.st)
+            self.slab_to_grad(P, B, M4, N, conv.weight, Cout, Cin, 0, conv.bias, Kt=Kt, tap_stride=Cin_pad)
+            self.keep += [A, X, P]
+            # data gradient: convolution of dconv with the transposed, tap-mirrored weight
+            w32 = _f32(conv.weight)
+            Opad = _ru(Cout, 32)
+            Mi = _lib.padded_rows(Cin)
+            At = (self.bf(Kt * Opad // 32, Mi, 32), self.bf(Kt * Opad // 32, Mi, 32))
+            _lib.call("t2s_pack_transposed", _p(w32), None, Cout, Cin, Kt, 1, Opad, Mi, 0, _p(At[0]), _p(At[1]), self.st)
+            d_in = (self.bf(B, icc, Lp, 32), self.bf(B, icc, Lp, 32))
+            _lib.call("t2s_conv_accumulate", _p(At[0]), _p(At[1]), _p(self.zero_bias), _p(dconv[0]), _p(dconv[1]), _p(d_in[0]),
+                      _p(d_in[1]), B, Cout, _ru(Cin, 4), Kt, 1, 1, T, Lp, halo, Mi, self.st)
+            self.keep += [w32, At, d_in]
+            d_planes = d_in
+        return d_planes
+
+    # ------------------------------------------------------------------ the whole thing
+    def run(self, g_mel, g_mel_post, g_gate):
+        sv, m, dev, st = self.sv, self.m, self.dev, self.st
+        dec = m.decoder
+        P = self.eng.prep
+        B, T, n_mel = sv["B"], sv["T_out"], sv["n_mel"]
+        A, D, Pd = dec.attention_rnn_dim, dec.decoder_rnn_dim, dec.prenet_dim
+        S = sv["S"]
+        memory = sv["memory"]
+        T_in, E = memory.size(1), memory.size(2)
+        al = dec.attention_layer
+        ad = al.query_layer.linear_layer.out_features
+        F_, KS = al.location_layer.location_conv.conv.out_channels, al.location_layer.location_conv.conv.kernel_size[0]
+        z = lambda t_: self.zeros(*t_.shape) if t_ is None else t_.to(torch.float32).contiguous()
+        g_mel = self.zeros(B, n_mel, T) if g_mel is None else g_mel.to(torch.float32).contiguous()
+        g_mel_post = self.zeros(B, n_mel, T) if g_mel_post is None else g_mel_post.to(torch.float32).contiguous()
+        g_gate = self.zeros(B, T) if g_gate is None else g_gate.to(torch.float32).contiguous()
+        # ---- postnet: mel_post = mel + postnet(mel) ----
+        d_in = self.conv_bn_stack_backward(sv["post_convs"], g_mel_post)
+        d_mel = self.new(B, n_mel, T)
+        _lib.call("t2s_add3", _p(g_mel), _p(g_mel_post), None, d_mel.numel(), _p(d_mel), st)
+        s0 = sv["post_convs"][0]
+        _lib.call("t2s_planes_to_f32", _p(d_in[0]), _p(d_in[1]), B, n_mel, T, s0["Lp"], s0["halo"], _p(d_mel), 1, st)
+        # ---- projection + gate (hoisted over all steps): proj[t,b,:] = W_proj [h_dec | ctx] + b ----
+        items = T * B
+        NP = _ru(n_mel + 1, 4)
+        d_proj = self.zeros(T, B, NP)
+        d_proj[:, :, :n_mel] = d_mel.permute(2, 0, 1)
+        d_proj[:, :, n_mel] = g_gate.permute(1, 0)
+        d_proj = d_proj.view(items, NP)
+        DE = D + E
+        w_proj = self.zeros(NP, DE)
+        w_proj[:n_mel + 1] = P["w_proj"]
+        w_projT = self.transpose(w_proj)                                     # [DE][NP]
+        d_hc = self.new(items, DE)
+        self.gemv(w_projT, NP, NP, _p(d_proj), NP, _p(d_hc), DE, DE, items)
+        hc_all = sv["hc_all"]
+        Pp, ks, M4, N = self.items_wgrad(items, [(_p(d_proj), NP, n_mel + 1, 0, 0)], [(_p(hc_all), DE, DE, 0, 0)], n_mel + 1, DE)
+        lp, gl = dec.linear_projection.linear_layer, dec.gate_layer.linear_layer
+        # rows [0, n_mel) -> linear_projection, row n_mel -> gate_layer
+        dWp, dbp = self.new(n_mel + 1, DE), self.new(n_mel + 1)
+        _lib.call("t2s_wn_backward", _p(Pp), ks, M4, N, 0, 0, 0, N - 1, _p(w_proj), None, n_mel + 1, DE, 1, _p(dWp), None, _p(dbp),
+                  0, st)
+        self.grads[id(lp.weight)], self.grads[id(lp.bias)] = dWp[:n_mel].contiguous(), dbp[:n_mel].contiguous()
+        self.grads[id(gl.weight)], self.grads[id(gl.bias)] = dWp[n_mel:].contiguous(), dbp[n_mel:].contiguous()
+        # ---- decoder BPTT ----
+        W_dT = self.transpose(torch.cat([P["dec_w_ih"], P["dec_w_hh"]], 1).contiguous())      # [A+E+D][4D]
+        W_aT = self.transpose(torch.cat([P["att_w_ih"], P["att_w_hh"]], 1).contiguous())      # [Pd+E+A][4A]
+        W_qT = self.transpose(P["w_query"])                                                    # [A][ad]
+        KD, KA = A + E + D, Pd + E + A
+        out_d = self.zeros(T, B, KD)
+        out_a = self.zeros(T, B, KA)
+        dg_d, dg_a = self.zeros(T, B, 4 * D), self.zeros(T, B, 4 * A)
+        dq_all = self.zeros(T, B, ad)
+        dah_q = self.new(B, A)
+        dc_d, dc_a = self.zeros(B, D), self.zeros(B, A)
+        dw_c, dwc_c = self.zeros(B, T_in), self.zeros(B, T_in)
+        d_pmem, d_memory = self.zeros(B, T_in, ad), self.zeros(B, T_in, E)
+        dD_p, dK_p, dv_p = self.zeros(B, ad * F_), self.zeros(B, F_ * 2 * KS), self.zeros(B, ad)
+        align = S["align_out"]                     # [B][T_cap][T_in]
+        T_cap = align.size(1)
+        att_drop, dec_drop = S.get("att_drop"), S.get("dec_drop")
+        a_scale = 1.0 / (1.0 - dec.p_attention_dropout)
+        d_scale = 1.0 / (1.0 - dec.p_decoder_dropout)
+        len32 = sv["len32"]
+        w_v = P["w_v"].reshape(-1).contiguous()
+        for t in reversed(range(T)):
+            nxt = t + 1 < T
+            # decoder LSTMCell
+            _lib.call("t2s_lstm_cell_bwd", _p(d_hc, t * B * DE), DE, _p(out_d, (t + 1) * B * KD + A + E) if nxt else None, KD,
+                      None, 0, _p(dec_drop, t * B * D) if dec_drop is not None else None, d_scale,
+                      _p(S["dec_gates_all"], t * B * 4 * D), _p(S["dec_c_all"], t * B * D),
+                      _p(S["dec_c_all"], (t - 1) * B * D) if t > 0 else None, _p(dc_d), _p(dg_d, t * B * 4 * D), B, D, st)
+            self.gemv(W_dT, 4 * D, 4 * D, _p(dg_d, t * B * 4 * D), 4 * D, _p(out_d, t * B * KD), KD, KD, B)
+            # attention
+            ab = _AttBwd(dctx1=_p(out_d, t * B * KD + A), sc1=KD, dctx2=_p(d_hc, t * B * DE + D), sc2=DE,
+                         dctx3=_p(out_a, (t + 1) * B * KA + Pd) if nxt else None, sc3=KA,
+                         w_cur=_p(align, t * T_in), s_wcur=T_cap * T_in,
+                         w_prev=_p(align, (t - 1) * T_in) if t > 0 else None,
+                         wc_prev=_p(S["wcum_all"], (t - 1) * B * T_in) if t > 0 else None, s_wprev=T_cap * T_in, s_wcprev=T_in,
+                         q=_p(S["q_all"], t * B * ad), pmem=_p(S["pmem"]), memory=_p(memory), lengths=_p(len32),
+                         w_loc_conv=_p(P["w_loc_conv"]), w_loc_dense=_p(P["w_loc_dense"]), w_v=_p(w_v),
+                         dw_carry=_p(dw_c), dwc_carry=_p(dwc_c), d_q=_p(dq_all, t * B * ad), d_pmem=_p(d_pmem),
+                         d_memory=_p(d_memory), dD_part=_p(dD_p), dK_part=_p(dK_p), dv_part=_p(dv_p),
+                         B=B, T=T_in, att_dim=ad, enc_dim=E, loc_f=F_, loc_ks=KS)
+            _lib.call("t2s_taco_att_bwd", ctypes.byref(ab), st)
+            self.gemv(W_qT, ad, ad, _p(dq_all, t * B * ad), ad, _p(dah_q), A, A, B)
+            # attention LSTMCell
+            _lib.call("t2s_lstm_cell_bwd", _p(out_d, t * B * KD), KD, _p(dah_q), A,
+                      _p(out_a, (t + 1) * B * KA + Pd + E) if nxt else None, KA,
+                      _p(att_drop, t * B * A) if att_drop is not None else None, a_scale,
+                      _p(S["att_gates_all"], t * B * 4 * A), _p(S["att_c_all"], t * B * A),
+                      _p(S["att_c_all"], (t - 1) * B * A) if t > 0 else None, _p(dc_a), _p(dg_a, t * B * 4 * A), B, A, st)
+            self.gemv(W_aT, 4 * A, 4 * A, _p(dg_a, t * B * 4 * A), 4 * A, _p(out_a, t * B * KA), KA, KA, B)
+        # ---- weight gradients over all (step, batch) items ----
+        ar = dec.attention_rnn
+        Pa, ks, M4, N = self.items_wgrad(items, [(_p(dg_a), 4 * A, 4 * A, 0, 0)],
+                                         [(_p(sv["pre_all"]), Pd, Pd, 0, 0), (_p(hc_all, D), DE, E, Pd, B),
+                                          (_p(S["att_h_all"]), A, A, Pd + E, B)], 4 * A, KA)
+        self.slab_to_grad(Pa, ks, M4, N, ar.weight_ih, 4 * A, Pd + E, 0, ar.bias_ih)
+        self.slab_to_grad(Pa, ks, M4, N, ar.weight_hh, 4 * A, A, Pd + E, ar.bias_hh)
+        dr = dec.decoder_rnn
+        Pdd, ks, M4, N = self.items_wgrad(items, [(_p(dg_d), 4 * D, 4 * D, 0, 0)],
+                                          [(_p(S["att_h_all"]), A, A, 0, 0), (_p(hc_all, D), DE, E, A, 0),
+                                           (_p(hc_all), DE, D, A + E, B)], 4 * D, KD)
+        self.slab_to_grad(Pdd, ks, M4, N, dr.weight_ih, 4 * D, A + E, 0, dr.bias_ih)
+        self.slab_to_grad(Pdd, ks, M4, N, dr.weight_hh, 4 * D, D, A + E, dr.bias_hh)
+        Pq, ks, M4, N = self.items_wgrad(items, [(_p(dq_all), ad, ad, 0, 0)], [(_p(S["att_h_all"]), A, A, 0, 0)], ad, A)
+        self.slab_to_grad(Pq, ks, M4, N, al.query_layer.linear_layer.weight, ad, A, 0)
+        # memory layer: pmem = W_mem memory
+        items_m = B * T_in
+        Pm, ks, M4, N = self.items_wgrad(items_m, [(_p(d_pmem), ad, ad, 0, 0)], [(_p(memory), E, E, 0, 0)], ad, E)
+        self.slab_to_grad(Pm, ks, M4, N, al.memory_layer.linear_layer.weight, ad, E, 0)
+        W_mT = self.transpose(P["w_mem"])                                    # [E][ad]
+        d_mem2 = self.new(B, T_in, E)
+        self.gemv(W_mT, ad, ad, _p(d_pmem), ad, _p(d_mem2), E, E, items_m)
+        d_mem_tot = self.new(B, T_in, E)
+        _lib.call("t2s_add3", _p(d_memory), _p(d_mem2), None, d_mem_tot.numel(), _p(d_mem_tot), st)
+        # attention parameters accumulated per batch element
+        loc = al.location_layer
+        for part, param, n in ((dD_p, loc.location_dense.linear_layer.weight, ad * F_),
+                               (dK_p, loc.location_conv.conv.weight, F_ * 2 * KS), (dv_p, al.v.linear_layer.weight, ad)):
+            g = self.new(*param.shape)
+            _lib.call("t2s_sum_axis0", _p(part), B, n, _p(g), st)
+            self.grads[id(param)] = g
+        # prenet (hoisted): pre_all = drop(relu(W2 drop(relu(W1 frames))))
+        d_pre = out_a[:, :, :Pd].contiguous().view(items, Pd)
+        dz2 = self.new(items, Pd)
+        _lib.call("t2s_relu_drop_bwd", _p(d_pre), _p(sv["pre_all"]), 2.0, dz2.numel(), _p(dz2), st)
+        l0, l1 = dec.prenet.layers[0].linear_layer, dec.prenet.layers[1].linear_layer
+        P2, ks, M4, N = self.items_wgrad(items, [(_p(dz2), Pd, Pd, 0, 0)], [(_p(sv["p1"]), Pd, Pd, 0, 0)], Pd, Pd)
+        self.slab_to_grad(P2, ks, M4, N, l1.weight, Pd, Pd, 0)
+        W2T = self.transpose(P["w_pre2"])
+        d_p1 = self.new(items, Pd)
+        self.gemv(W2T, Pd, Pd, _p(dz2), Pd, _p(d_p1), Pd, Pd, items)
+        dz1 = self.new(items, Pd)
+        _lib.call("t2s_relu_drop_bwd", _p(d_p1), _p(sv["p1"]), 2.0, dz1.numel(), _p(dz1), st)
+        P1, ks, M4, N = self.items_wgrad(items, [(_p(dz1), Pd, Pd, 0, 0)], [(_p(sv["frames"]), n_mel, n_mel, 0, 0)], Pd, n_mel)
+        self.slab_to_grad(P1, ks, M4, N, l0.weight, Pd, n_mel, 0)
+        self.d_memory = d_mem_tot
+        self.keep += [d_proj, w_proj, d_hc, out_d, out_a, dg_d, dg_a, dq_all, d_pmem, d_memory, dz2, dz1, d_p1, d_pre, w_v]
+        return self.grads
+
+
+class _TacotronFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, text, text_lengths, mels, output_lengths, prenet_masks, train_masks, *params):
+        eng = model._eng()
+        sv = {}
+        with torch.no_grad():
+            out = eng.forward(text, text_lengths, mels, output_lengths, prenet_masks, train_masks=train_masks, save=sv)
+        ctx.model, ctx.sv, ctx.params = model, sv, params
+        ctx.mark_non_differentiable(out[3])
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, g_mel, g_mel_post, g_gate, g_align):
+        eng = ctx.model._eng()
+        with torch.no_grad():
+            bw = _Bwd(eng, ctx.sv)
+            grads = bw.run(g_mel, g_mel_post, g_gate)
+            from .autograd_encoder import encoder_backward
+            encoder_backward(bw, bw.d_memory)
+        outs = []
+        for p in ctx.params:
+            g = grads.get(id(p))
+            outs.append(None if g is None else g.reshape(p.shape).to(p.dtype))
+        ctx.model.__dict__["_last_bwd"] = bw          # keeps scratch alive until the next step's backward
+        return (None, None, None, None, None, None, None, *outs)
+
+
+def tacotron_forward_with_grad(model, text, text_lengths, mels, output_lengths, prenet_masks, train_masks):
+    params = list(model.parameters())
+    return list(_TacotronFn.apply(model, text, text_lengths, mels, output_lengths, prenet_masks, train_masks, *params))

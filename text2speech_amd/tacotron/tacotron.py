@@ -224,7 +224,7 @@ class _TacoEngine:
                   layer["Cout"], layer.get("taps", 1), 1, act, L, Lp, halo, layer["Mpad"], _lib.current_stream())
         return Oh, Ol
 
-    def encode(self, ids, lengths, train_masks=None, seed=0):
+    def encode(self, ids, lengths, train_masks=None, seed=0, save=None):
         """Embedding + Encoder.forward / .inference (reference tacotron.py:40,192-220).  In training mode the
         convolutions use batch statistics and dropout(0.5) (masks from ``train_masks['enc']`` or drawn here)."""
         m, P = self.m, self.prep
@@ -243,7 +243,8 @@ class _TacoEngine:
             given = None if train_masks is None else train_masks.get("enc")
             for i, (seq, layer) in enumerate(zip(m.encoder.convolutions, P["enc_convs_plain"])):
                 mk = self._drop(None if given is None else given[i], (B, layer["Cout"], T), 0.5, dev, seed + 101 + i)
-                Xh, Xl = self._conv_bn_train(seq, layer, Xh, Xl, B, T, Lp, halo, 1, mk)
+                Xh, Xl = self._conv_bn_train(seq, layer, Xh, Xl, B, T, Lp, halo, 1, mk,
+                                             save=None if save is None else save.setdefault("enc_convs", []))
         else:
             for layer in P["enc_convs"]:
                 Xh, Xl = self._conv(layer, Xh, Xl, B, T, Lp, halo, 1)
@@ -258,6 +259,8 @@ class _TacoEngine:
         memory = torch.empty(B, T_out, 2 * H, dtype=torch.float32, device=dev)
         _lib.call("t2s_taco_encoder_lstm", _lib.ptr(gx), _lib.ptr(P["whhT"][0][0]), _lib.ptr(P["whhT"][1][0]),
                   _lib.ptr(len32), _lib.ptr(memory), B, T, H, T_out, st)
+        if save is not None:
+            save.update(enc_ids=ids64, enc_gx=gx, enc_Xh=Xh, enc_Xl=Xl, enc_T=T, enc_Lp=Lp, enc_len32=len32, memory=memory)
         return memory, len32
 
     def _gemv(self, W, x, rows, items, K, y, act=0, mask=None, smask=0, mask_scale=1.0, bias=None, sy_item=None,
@@ -301,7 +304,7 @@ class _TacoEngine:
             S[name] = t
         return d, S
 
-    def postnet(self, mel, train_masks=None, seed=0):
+    def postnet(self, mel, train_masks=None, seed=0, save=None):
         """Postnet.forward (reference modules.py:131-137): 5 x conv+BN, tanh on the first four; in training mode
         batch statistics and dropout(0.5) after every layer."""
         P = self.prep
@@ -320,10 +323,11 @@ class _TacoEngine:
             given = None if train_masks is None else train_masks.get("post")
             for i, (seq, layer) in enumerate(zip(m.postnet.convolutions, P["post_convs_plain"])):
                 mk = self._drop(None if given is None else given[i], (B, layer["Cout"], T), 0.5, dev, seed + 201 + i)
+                sv = None if save is None else save.setdefault("post_convs", [])
                 if i < n - 1:
-                    Xh, Xl = self._conv_bn_train(seq, layer, Xh, Xl, B, T, Lp, halo, 2, mk)
+                    Xh, Xl = self._conv_bn_train(seq, layer, Xh, Xl, B, T, Lp, halo, 2, mk, save=sv)
                 else:
-                    self._conv_bn_train(seq, layer, Xh, Xl, B, T, Lp, halo, 0, mk, want_planes=False, out_f32=out)
+                    self._conv_bn_train(seq, layer, Xh, Xl, B, T, Lp, halo, 0, mk, want_planes=False, out_f32=out, save=sv)
             return out
         for i, layer in enumerate(P["post_convs"]):
             if i < n - 1:
@@ -362,7 +366,7 @@ class _TacoEngine:
                   _lib.ptr(A_hi), _lib.ptr(A_lo), _lib.ptr(bias), 0, _lib.current_stream())
         return dict(A_hi=A_hi, A_lo=A_lo, bias=bias, Mpad=Mpad, Cin=Cin, Cout=O, taps=Kt, keep=(w, cb))
 
-    def _conv_bn_train(self, seq, layer, Xh, Xl, B, T, Lp, halo, act, mask, want_planes=True, out_f32=None):
+    def _conv_bn_train(self, seq, layer, Xh, Xl, B, T, Lp, halo, act, mask, want_planes=True, out_f32=None, save=None):
         """conv -> BatchNorm1d with batch statistics (+ running-stat update, as nn.BatchNorm1d.train() does) ->
         activation -> dropout mask (reference tacotron.py:193-194; modules.py:131-137)."""
         bn = seq[1]
@@ -385,6 +389,9 @@ class _TacoEngine:
             bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
             bn.running_var.mul_(1 - mom).add_(var * (n / max(1, n - 1)), alpha=mom)
             bn.num_batches_tracked += 1
+        if save is not None:
+            save.append(dict(seq=seq, layer=layer, Xh=Xh, Xl=Xl, y=y, mean=mean, var=var, mask=mask, act=act, B=B, T=T, Lp=Lp,
+                             halo=halo))
         return Oh, Ol
 
     # ------------------------------------------------------------------ whole-model paths
@@ -423,12 +430,12 @@ class _TacoEngine:
         mel_post = mel + self.postnet(mel)
         return [mel, mel_post, gate, align]
 
-    def forward(self, text, text_lengths, mels, output_lengths, prenet_masks=None, seed=0, train_masks=None):
+    def forward(self, text, text_lengths, mels, output_lengths, prenet_masks=None, seed=0, train_masks=None, save=None):
         m = self.m
         dec = m.decoder
         dev = text.device
         self.prepare(dev)
-        memory, len32 = self.encode(text, text_lengths, train_masks, seed)
+        memory, len32 = self.encode(text, text_lengths, train_masks, seed, save=save)
         B, n_mel, T_out = mels.shape
         Pd, D, E = dec.prenet_dim, dec.decoder_rnn_dim, memory.size(2)
         P = self.prep
@@ -449,6 +456,13 @@ class _TacoEngine:
             extra["att_drop"] = self._drop(tm.get("att"), (T_out, B, dec.attention_rnn_dim), 1 - dec.p_attention_dropout,
                                            dev, seed + 301)
             extra["dec_drop"] = self._drop(tm.get("dec"), (T_out, B, D), 1 - dec.p_decoder_dropout, dev, seed + 302)
+        if save is not None:        # per-step state the decoder backward needs (teacher-forced, training)
+            A_, T_in_ = dec.attention_rnn_dim, memory.size(1)
+            ad_ = dec.attention_layer.query_layer.linear_layer.out_features
+            zf = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=dev)
+            extra.update(att_gates_all=zf(T_out, B, 4 * A_), att_c_all=zf(T_out, B, A_), dec_gates_all=zf(T_out, B, 4 * D),
+                         dec_c_all=zf(T_out, B, D), att_h_all=zf(T_out, B, A_), q_all=zf(T_out, B, ad_),
+                         wcum_all=zf(T_out, B, T_in_))
         d, S = self._decoder_struct(memory, len32, T_out, True, extra)
         if m.training:
             d.att_drop_scale = 1.0 / (1.0 - dec.p_attention_dropout)
@@ -460,7 +474,10 @@ class _TacoEngine:
         proj = proj.view(T_out, B, n_mel + 1)
         mel = proj[:, :, :n_mel].permute(1, 2, 0).contiguous()
         gate = proj[:, :, n_mel].permute(1, 0).contiguous()
-        mel_post = mel + self.postnet(mel, train_masks, seed)
+        mel_post = mel + self.postnet(mel, train_masks, seed, save=save)
+        if save is not None:
+            save.update(S=S, frames=frames, p1=p1, pre_all=pre_all, hc_all=hc_all, prenet_masks=mk, len32=len32, B=B, T_out=T_out,
+                        n_mel=n_mel)
         return [mel, mel_post, gate, S["align_out"]]
 
 
@@ -505,8 +522,10 @@ class Tacotron(nn.Module):
         text_inputs, text_lengths, mels, max_len, speaker_id, output_lengths = inputs
         self._check(text_inputs)
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("the Tacotron-2 backward pass is not built yet on the MI355X path; run the "
-                                      "training-mode forward under torch.no_grad()")
+            from .autograd import tacotron_forward_with_grad
+            out = tacotron_forward_with_grad(self, text_inputs, text_lengths.data, mels, output_lengths.data, prenet_masks,
+                                             train_masks)
+            return self.parse_output(out, output_lengths.data)
         with torch.no_grad():
             out = self._eng().forward(text_inputs, text_lengths.data, mels, output_lengths.data, prenet_masks,
                                       train_masks=train_masks)
@@ -528,9 +547,10 @@ class Tacotron(nn.Module):
             T = outputs[0].size(2)
             if mask.size(1) < T:
                 mask = torch.cat([mask, mask.new_ones(mask.size(0), T - mask.size(1))], 1)
-            outputs[0].masked_fill_(mask.unsqueeze(1), 0.0)
-            outputs[1].masked_fill_(mask.unsqueeze(1), 0.0)
-            outputs[2].masked_fill_(mask, 1e3)
+            # .data, as the reference does (tacotron.py:73-75): the fill bypasses autograd
+            outputs[0].data.masked_fill_(mask.unsqueeze(1), 0.0)
+            outputs[1].data.masked_fill_(mask.unsqueeze(1), 0.0)
+            outputs[2].data.masked_fill_(mask, 1e3)
         return outputs
 
     def parse_batch(self, batch):
