@@ -184,7 +184,17 @@ int t2s_bn_train(const float* x, const float* gamma, const float* beta, float ep
 /* Encoder BiLSTM recurrence with packed-sequence semantics (tacotron.py:199-207).  gx[B][T][8H] = W_ih x + b_ih + b_hh
  * for both directions (fwd gates then reverse gates), whhT_* = W_hh^T [H][4H]; out[B][T_out][2H]; 4H must be 1024. */
 int t2s_taco_encoder_lstm(const float* gx, const float* whhT_fwd, const float* whhT_rev, const int* lengths, float* out,
-                          int B, int T, int H, int T_out, void* stream);
+                          int B, int T, int H, int T_out, float* gates_save /* [B][T][2][4H] or NULL */,
+                          float* c_save /* [B][T][2][H] or NULL */, void* stream);
+/* BPTT of that recurrence: d_out[B][T_out][2H] -> dgx[B][T][8H] (zero beyond each length), hprev[B][T][2H] (the h each
+ * step consumed; the X operand of the W_hh weight-gradient GEMM); whh_* are the natural [4H][H] matrices */
+int t2s_taco_encoder_lstm_bwd(const float* d_out, const float* out, const float* gates_save, const float* c_save,
+                              const float* whh_fwd, const float* whh_rev, const int* lengths, float* dgx, float* hprev,
+                              int B, int T, int H, int T_out, void* stream);
+/* f32 channel-last rows x[b][t][c] -> planes ; embedding gradient d_emb[v][e] = sum over (b,t) with ids == v of planes */
+int t2s_rows_to_planes(const float* x, int B, int T, int C, int Lp, int halo, void* X_hi, void* X_lo, void* stream);
+int t2s_embedding_grad(const long* ids, const void* D_hi, const void* D_lo, int B, int T, int E, int V, int Lp, int halo,
+                       float* d_emb, void* stream);
 
 /* Bernoulli(keep_prob) bytes (0/1) from a counter hash: dropout masks (the always-on prenet dropout,
  * modules.py:21, and the training-mode dropouts) when the caller does not inject them */

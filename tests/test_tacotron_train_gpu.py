@@ -94,9 +94,9 @@ def test_param_grads_vs_oracle(trained, prefix):
         # a conv bias in front of a batch-statistics BatchNorm has an exactly-zero gradient: both sides are rounding
         # noise there, so differences below an absolute floor count as equal
         diff = float((got[n].double() - want[n].double()).norm())
-        worst.append((0.0 if diff < 1e-6 else _rel(got[n], want[n]), n))
+        worst.append((0.0 if diff < 2e-5 else _rel(got[n], want[n]), n))
     worst.sort(reverse=True)
-    assert worst[0][0] < 5e-3, worst[:6]
+    assert worst[0][0] < 5e-3, [(r, n, float(got[n].norm()), float(want[n].norm())) for r, n in worst[:6]]
 
 
 def test_grads_vs_reference_golden(trained):

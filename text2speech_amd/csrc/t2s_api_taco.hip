@@ -82,9 +82,10 @@ int t2s_bn_train(const float* x, const float* gamma, const float* beta, float ep
 }
 
 int t2s_taco_encoder_lstm(const float* gx, const float* whhT_fwd, const float* whhT_rev, const int* lengths, float* out,
-                          int B, int T, int H, int T_out, void* stream) {
+                          int B, int T, int H, int T_out, float* gates_save, float* c_save, void* stream) {
     if (!gx || !whhT_fwd || !whhT_rev || !out || B <= 0 || T <= 0 || T_out <= 0 || T_out > T || 4 * H != 1024) return T2S_EINVAL;
-    T2S_CHECK_HIP(t2s_launch_lstm_seq(gx, whhT_fwd, whhT_rev, lengths, out, B, T, H, T_out, (hipStream_t)stream));
+    if ((gates_save == nullptr) != (c_save == nullptr)) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_lstm_seq(gx, whhT_fwd, whhT_rev, lengths, out, B, T, H, T_out, gates_save, c_save, (hipStream_t)stream));
     return T2S_OK;
 }
 

@@ -65,6 +65,29 @@ int t2s_bn_bwd(const t2s_bn_bwd_args* p, void* stream) {
     return T2S_OK;
 }
 
+int t2s_taco_encoder_lstm_bwd(const float* d_out, const float* out, const float* gates_save, const float* c_save,
+                              const float* whh_fwd, const float* whh_rev, const int* lengths, float* dgx, float* hprev,
+                              int B, int T, int H, int T_out, void* stream) {
+    if (!d_out || !out || !gates_save || !c_save || !whh_fwd || !whh_rev || !dgx || !hprev || B <= 0 || T <= 0 || H != 256 ||
+        T_out <= 0 || T_out > T)
+        return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_lstm_seq_bwd(d_out, out, gates_save, c_save, whh_fwd, whh_rev, lengths, dgx, hprev, B, T, H,
+                                          T_out, (hipStream_t)stream));
+    return T2S_OK;
+}
+int t2s_rows_to_planes(const float* x, int B, int T, int C, int Lp, int halo, void* X_hi, void* X_lo, void* stream) {
+    if (!x || !X_hi || !X_lo || B <= 0 || T <= 0 || C <= 0 || Lp < t2s_plane_rows(T, halo)) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_rows_to_planes(x, B, T, C, Lp, halo, (u16*)X_hi, (u16*)X_lo, (hipStream_t)stream));
+    return T2S_OK;
+}
+int t2s_embedding_grad(const long* ids, const void* D_hi, const void* D_lo, int B, int T, int E, int V, int Lp, int halo,
+                       float* d_emb, void* stream) {
+    if (!ids || !D_hi || !D_lo || !d_emb || B <= 0 || T <= 0 || E <= 0 || V <= 0) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_embedding_grad(ids, (const u16*)D_hi, (const u16*)D_lo, B, T, E, V, Lp, halo, d_emb,
+                                            (hipStream_t)stream));
+    return T2S_OK;
+}
+
 int t2s_sum_axis0(const float* in, int n0, int n, float* out, void* stream) {
     if (!in || !out || n0 <= 0 || n <= 0) return T2S_EINVAL;
     T2S_CHECK_HIP(t2s_launch_sum_axis0(in, n0, n, out, (hipStream_t)stream));

@@ -57,3 +57,10 @@ hipError_t t2s_launch_planes_to_f32(const u16* X_hi, const u16* X_lo, int B, int
                                     int accumulate, hipStream_t stream);
 hipError_t t2s_launch_sum_axis0(const float* in, int n0, int n, float* out, hipStream_t stream);
 hipError_t t2s_launch_add3(const float* a, const float* b, const float* c, size_t n, float* out, hipStream_t stream);
+hipError_t t2s_launch_lstm_seq_bwd(const float* d_out, const float* out, const float* gates, const float* csave,
+                                   const float* whh_f, const float* whh_r, const int* lengths, float* dgx, float* hprev,
+                                   int B, int T, int H, int T_out, hipStream_t stream);
+hipError_t t2s_launch_rows_to_planes(const float* x, int B, int T, int C, int Lp, int halo, u16* X_hi, u16* X_lo,
+                                     hipStream_t stream);
+hipError_t t2s_launch_embedding_grad(const long* ids, const u16* D_hi, const u16* D_lo, int B, int T, int E, int V, int Lp,
+                                     int halo, float* d_emb, hipStream_t stream);

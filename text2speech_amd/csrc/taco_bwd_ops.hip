@@ -363,3 +363,110 @@ hipError_t t2s_launch_add3(const float* a, const float* b, const float* c, size_
     hipLaunchKernelGGL(add3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, b, c, n, out);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Encoder BiLSTM BPTT (reference tacotron.py:199-207), one 1024-thread workgroup per (batch element, direction),
+// steps walked in the reverse of the forward order; W_hh ([4H][H], natural layout: coalesced over k) is streamed
+// once per step, the recurrent gradient lives in LDS.
+__global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ out,
+                                                            const float* __restrict__ gates, const float* __restrict__ csave,
+                                                            const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                                            const int* __restrict__ lengths, float* dgx, float* hprev, int T,
+                                                            int H, int T_out) {
+    __shared__ float s_dg[1024];
+    __shared__ float s_dh[256];
+    __shared__ float s_part[4][256];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x, dir = blockIdx.y;
+    const float* W = dir ? whh_r : whh_f;
+    const int len = lengths ? lengths[b] : T;
+    float dc = 0.f;
+    if (tid < H) s_dh[tid] = 0.f;
+    __syncthreads();
+    for (int s = 0; s < len; ++s) {
+        const int t = dir ? s : len - 1 - s;                 // reverse of the forward order
+        const int tp = dir ? t + 1 : t - 1;                  // the step the forward pass visited just before t
+        const bool has_prev = dir ? (t < len - 1) : (t > 0);
+        if (tid < H) {
+            const int u = tid;
+            const float dh = d_out[((size_t)b * T_out + t) * 2 * H + dir * H + u] + s_dh[u];
+            const size_t gb = (((size_t)b * T + t) * 2 + dir) * 4 * H + u;
+            const float gi = gates[gb], gf = gates[gb + H], gg = gates[gb + 2 * H], go = gates[gb + 3 * H];
+            const float cn = csave[(((size_t)b * T + t) * 2 + dir) * H + u];
+            const float cp = has_prev ? csave[(((size_t)b * T + tp) * 2 + dir) * H + u] : 0.f;
+            const float tc = tanhf(cn);
+            const float dct = dc + dh * go * (1.f - tc * tc);
+            const float d0 = dct * gg * gi * (1.f - gi), d1 = dct * cp * gf * (1.f - gf), d2 = dct * gi * (1.f - gg * gg),
+                        d3 = dh * tc * go * (1.f - go);
+            dc = dct * gf;
+            s_dg[u] = d0; s_dg[H + u] = d1; s_dg[2 * H + u] = d2; s_dg[3 * H + u] = d3;
+            float* o = dgx + ((size_t)b * T + t) * 8 * H + dir * 4 * H + u;
+            o[0] = d0; o[H] = d1; o[2 * H] = d2; o[3 * H] = d3;
+            hprev[((size_t)b * T + t) * 2 * H + dir * H + u] = has_prev ? out[((size_t)b * T_out + tp) * 2 * H + dir * H + u] : 0.f;
+        }
+        __syncthreads();
+        {
+            const int jq = tid >> 8, k = tid & 255;
+            float acc = 0.f;
+            if (k < H) {
+#pragma unroll 8
+                for (int j = jq * H; j < (jq + 1) * H; ++j) acc += W[(size_t)j * H + k] * s_dg[j];
+            }
+            s_part[jq][k] = acc;
+        }
+        __syncthreads();
+        if (tid < H) s_dh[tid] = (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
+        __syncthreads();
+    }
+}
+hipError_t t2s_launch_lstm_seq_bwd(const float* d_out, const float* out, const float* gates, const float* csave,
+                                   const float* whh_f, const float* whh_r, const int* lengths, float* dgx, float* hprev,
+                                   int B, int T, int H, int T_out, hipStream_t stream) {
+    if (H != 256) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(B, 2), dim3(1024), 0, stream, d_out, out, gates, csave, whh_f, whh_r, lengths,
+                       dgx, hprev, T, H, T_out);
+    return hipGetLastError();
+}
+
+// f32 channel-last rows x[b][t][c] -> planes
+__global__ void rows_to_planes_kernel(const float* x, int T, int C, int Lp, int halo, u16* X_hi, u16* X_lo) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int nch = (C + 31) / 32;
+    for (int c = threadIdx.x; c < nch * 32; c += blockDim.x) {
+        const float v = c < C ? x[((size_t)b * T + t) * C + c] : 0.f;
+        u16 h, l;
+        split_bf16(v, h, l);
+        const size_t idx = (((size_t)b * nch + (c >> 5)) * Lp + halo + t) * 32 + (c & 31);
+        X_hi[idx] = h;
+        X_lo[idx] = l;
+    }
+}
+hipError_t t2s_launch_rows_to_planes(const float* x, int B, int T, int C, int Lp, int halo, u16* X_hi, u16* X_lo,
+                                     hipStream_t stream) {
+    hipLaunchKernelGGL(rows_to_planes_kernel, dim3(T, B), dim3(256), 0, stream, x, T, C, Lp, halo, X_hi, X_lo);
+    return hipGetLastError();
+}
+
+// d_emb[v][e] = sum over (b, t) with ids[b][t] == v of d_x[b][e][t]   (d_x as planes); one workgroup per symbol:
+// deterministic, no atomics (the vocabulary is 80 symbols)
+__global__ __launch_bounds__(256) void embedding_grad_kernel(const long* __restrict__ ids, const u16* __restrict__ D_hi,
+                                                             const u16* __restrict__ D_lo, int B, int T, int E, int Lp,
+                                                             int halo, float* d_emb) {
+    const int v = blockIdx.x;
+    const int nch = (E + 31) / 32;
+    for (int e = threadIdx.x; e < E; e += 256) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < T; ++t)
+                if (ids[(size_t)b * T + t] == v) {
+                    const size_t idx = (((size_t)b * nch + (e >> 5)) * Lp + halo + t) * 32 + (e & 31);
+                    acc += join_bf16(D_hi[idx], D_lo[idx]);
+                }
+        d_emb[(size_t)v * E + e] = acc;
+    }
+}
+hipError_t t2s_launch_embedding_grad(const long* ids, const u16* D_hi, const u16* D_lo, int B, int T, int E, int V, int Lp,
+                                     int halo, float* d_emb, hipStream_t stream) {
+    hipLaunchKernelGGL(embedding_grad_kernel, dim3(V), dim3(256), 0, stream, ids, D_hi, D_lo, B, T, E, Lp, halo, d_emb);
+    return hipGetLastError();
+}

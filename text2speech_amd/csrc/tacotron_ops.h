@@ -73,7 +73,7 @@ hipError_t t2s_launch_att_energy(const AttArgs& a, hipStream_t stream);
 hipError_t t2s_launch_att_softmax_ctx(const AttArgs& a, hipStream_t stream);
 hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream);
 hipError_t t2s_launch_lstm_seq(const float* gx, const float* whhT_f, const float* whhT_r, const int* lengths, float* out,
-                               int B, int T, int H, int T_out, hipStream_t stream);
+                               int B, int T, int H, int T_out, float* gates_save, float* c_save, hipStream_t stream);
 hipError_t t2s_launch_transpose(const float* in, float* out, int R, int C, hipStream_t stream);
 hipError_t t2s_launch_embed_planes(const long* ids, const float* emb, int B, int T, int E, int V, int Lp, int halo,
                                    unsigned short* X_hi, unsigned short* X_lo, hipStream_t stream);

@@ -548,7 +548,8 @@ hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream) {
 template <int BT>
 __global__ __launch_bounds__(1024) void lstm_seq_kernel(const float* __restrict__ gx, const float* __restrict__ whhT_f,
                                                         const float* __restrict__ whhT_r, const int* __restrict__ lengths,
-                                                        float* out, int B, int T, int H, int T_out) {
+                                                        float* out, int B, int T, int H, int T_out, float* gates_save,
+                                                        float* c_save) {
     __shared__ float s_h[BT][256];
     __shared__ float s_g[BT][1024];
     const int j = threadIdx.x;              // gate row, 4H == blockDim.x
@@ -594,6 +595,14 @@ __global__ __launch_bounds__(1024) void lstm_seq_kernel(const float* __restrict_
                     const float h = sigmoid_acc(go) * tanhf(c[i]);
                     s_h[i][j] = h;
                     const int t = dir ? len[i] - 1 - s : s;
+                    if (gates_save) {      // training: post-activation gates and cell state per step, for the BPTT kernel
+                        const size_t gb = (((size_t)(b0 + i) * T + t) * 2 + dir) * 4 * H + j;
+                        gates_save[gb] = sigmoid_acc(gi);
+                        gates_save[gb + H] = sigmoid_acc(gf);
+                        gates_save[gb + 2 * H] = tanhf(gg);
+                        gates_save[gb + 3 * H] = sigmoid_acc(go);
+                        c_save[(((size_t)(b0 + i) * T + t) * 2 + dir) * H + j] = c[i];
+                    }
                     out[((size_t)(b0 + i) * T_out + t) * (2 * H) + dir * H + j] = h;
                 }
             }
@@ -609,10 +618,10 @@ __global__ __launch_bounds__(1024) void lstm_seq_kernel(const float* __restrict_
 }
 
 hipError_t t2s_launch_lstm_seq(const float* gx, const float* whhT_f, const float* whhT_r, const int* lengths, float* out,
-                               int B, int T, int H, int T_out, hipStream_t stream) {
+                               int B, int T, int H, int T_out, float* gates_save, float* c_save, hipStream_t stream) {
     if (4 * H != 1024) return hipErrorInvalidValue;
-    if (B >= 8) hipLaunchKernelGGL(lstm_seq_kernel<4>, dim3((B + 3) / 4, 2), dim3(1024), 0, stream, gx, whhT_f, whhT_r, lengths, out, B, T, H, T_out);
-    else hipLaunchKernelGGL(lstm_seq_kernel<1>, dim3(B, 2), dim3(1024), 0, stream, gx, whhT_f, whhT_r, lengths, out, B, T, H, T_out);
+    if (B >= 8) hipLaunchKernelGGL(lstm_seq_kernel<4>, dim3((B + 3) / 4, 2), dim3(1024), 0, stream, gx, whhT_f, whhT_r, lengths, out, B, T, H, T_out, gates_save, c_save);
+    else hipLaunchKernelGGL(lstm_seq_kernel<1>, dim3(B, 2), dim3(1024), 0, stream, gx, whhT_f, whhT_r, lengths, out, B, T, H, T_out, gates_save, c_save);
     return hipGetLastError();
 }
 

@@ -105,11 +105,11 @@ class _Bwd:
         self.keep += [A, X]
         return P, ks, M4, N
 
-    def slab_to_grad(self, P, ks, M4, N, param, O, Cin, col_off, bias_param=None, Kt=1, tap_stride=0):
+    def slab_to_grad(self, P, ks, M4, N, param, O, Cin, col_off, bias_param=None, Kt=1, tap_stride=0, row_off=0):
         w = _f32(param)
         dW = self.new(*param.shape)
         db = None if bias_param is None else self.new(O)
-        _lib.call("t2s_wn_backward", _p(P), ks, M4, N, 0, col_off, tap_stride, N - 1, _p(w), None, O, Cin, Kt, _p(dW), None,
+        _lib.call("t2s_wn_backward", _p(P), ks, M4, N, row_off, col_off, tap_stride, N - 1, _p(w), None, O, Cin, Kt, _p(dW), None,
                   _p(db), 0, self.st)
         self.grads[id(param)] = dW
         if bias_param is not None:
@@ -117,10 +117,10 @@ class _Bwd:
         self.keep.append(w)
 
     # ------------------------------------------------------------------ conv + BatchNorm stack (postnet / encoder)
-    def conv_bn_stack_backward(self, saves, dout_f32):
-        """Backward of [conv -> BN(batch stats) -> act -> dropout] x n.  dout_f32: [B][C_last][T] gradient of the stack's
-        output.  Returns the gradient w.r.t. the stack's input as planes (hi, lo) with its channel count."""
-        d_planes = None
+    def conv_bn_stack_backward(self, saves, dout_f32=None, dout_planes=None):
+        """Backward of [conv -> BN(batch stats) -> act -> dropout] x n.  The gradient of the stack's output comes as f32
+        [B][C_last][T] or as planes.  Returns the gradient w.r.t. the stack's input as planes (hi, lo)."""
+        d_planes = dout_planes
         for i in reversed(range(len(saves))):
             s = saves[i]
             conv, bn, layer = s["seq"][0].conv, s["seq"][1], s["layer"]

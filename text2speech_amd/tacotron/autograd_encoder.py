@@ -1,6 +1,70 @@
-"""Encoder part of the Tacotron-2 backward (BiLSTM BPTT, conv+BatchNorm stack, embedding)."""
+"""Encoder part of the Tacotron-2 backward (reference tacotron.py:192-209 under autograd): BiLSTM BPTT, the input
+projection's weight / data gradients through the GEMM paths, the conv + BatchNorm stack, and the embedding."""
+import torch
+
+from .. import _lib
+from .tacotron import _f32
 
 
 def encoder_backward(bw, d_memory):
-    """d_memory: [B][T_in][enc_dim] gradient w.r.t. the encoder output.  (stage 3: filled in below)"""
-    return
+    """d_memory: [B][T_enc][2H] gradient w.r.t. the encoder output (already summed over its consumers)."""
+    from .autograd import _p, _ru
+    sv, m, P, st = bw.sv, bw.m, bw.eng.prep, bw.st
+    enc = m.encoder
+    lstm = enc.lstm
+    ids = sv["enc_ids"]
+    B, T = ids.shape
+    H = P["H"]
+    memory = sv["memory"]
+    T_out = memory.size(1)
+    halo, Lp = 2, sv["enc_Lp"]
+    # ---- BiLSTM BPTT ----
+    dgx = bw.zeros(B, T, 8 * H)
+    hprev = bw.zeros(B, T, 2 * H)
+    whh = [_f32(lstm.weight_hh_l0), _f32(lstm.weight_hh_l0_reverse)]
+    _lib.call("t2s_taco_encoder_lstm_bwd", _p(d_memory), _p(memory), _p(sv["enc_gates"]), _p(sv["enc_c"]), _p(whh[0]),
+              _p(whh[1]), _p(sv["enc_len32"]), _p(dgx), _p(hprev), B, T, H, T_out, st)
+    items = B * T
+    for d, (w_hh, b_hh) in enumerate([(lstm.weight_hh_l0, lstm.bias_hh_l0), (lstm.weight_hh_l0_reverse, lstm.bias_hh_l0_reverse)]):
+        Pw, ks, M4, N = bw.items_wgrad(items, [(_p(dgx, d * 4 * H), 8 * H, 4 * H, 0, 0)], [(_p(hprev, d * H), 2 * H, H, 0, 0)],
+                                       4 * H, H)
+        bw.slab_to_grad(Pw, ks, M4, N, w_hh, 4 * H, H, 0, b_hh)
+    # ---- input projection gx = W_ih x + b: weight gradient contracts over time per batch element ----
+    nt = -(-Lp // 32)
+    items_pad = nt * 32
+    M = 8 * H
+    Mpad = _lib.padded_rows(M)
+    A = (bw.bf(B, nt, Mpad, 32), bw.bf(B, nt, Mpad, 32))
+    for b in range(B):
+        _lib.call("t2s_rows_to_tm", _p(dgx, b * T * M), M, T, items_pad, halo, M, _p(A[0], b * nt * Mpad * 32),
+                  _p(A[1], b * nt * Mpad * 32), Mpad, 0, st)
+    Cin = lstm.input_size
+    icc = _ru(Cin, 32) // 32
+    N = Cin + 1
+    Npad = _ru(N, 256)
+    X = (bw.bf(B, nt, Npad, 32), bw.bf(B, nt, Npad, 32))
+    _lib.call("t2s_plane_transpose", _p(sv["enc_Xh"]), _p(sv["enc_Xl"]), B, icc, icc, Lp, 0, _p(X[0]), _p(X[1]), Npad, 0, st)
+    _lib.call("t2s_tm_ones_row", _p(X[0]), _p(X[1]), B, Lp, halo, T, Npad, Cin, st)
+    Pi = bw.new(B, M, N)
+    _lib.call("t2s_wgrad_gemm", _p(A[0]), _p(A[1]), _p(X[0]), _p(X[1]), _p(bw.zero_bias), _p(Pi), B, M, N, Mpad, Npad, nt, 0, nt,
+              1, st)
+    bw.slab_to_grad(Pi, B, M, N, lstm.weight_ih_l0, 4 * H, Cin, 0, lstm.bias_ih_l0, row_off=0)
+    bw.slab_to_grad(Pi, B, M, N, lstm.weight_ih_l0_reverse, 4 * H, Cin, 0, lstm.bias_ih_l0_reverse, row_off=4 * H)
+    # ---- data gradient of the projection: d_x = W_ih^T dgx, as a 1-tap convolution over planes ----
+    w_cat = P["lstm_in"]["keep"][0]                                  # [8H][Cin] (both directions)
+    Mi = _lib.padded_rows(Cin)
+    At = (bw.bf(M // 32, Mi, 32), bw.bf(M // 32, Mi, 32))
+    _lib.call("t2s_pack_transposed", _p(w_cat), None, M, Cin, 1, 0, M, Mi, 0, _p(At[0]), _p(At[1]), st)
+    dgp = (bw.bf(B, M // 32, Lp, 32), bw.bf(B, M // 32, Lp, 32))
+    _lib.call("t2s_rows_to_planes", _p(dgx), B, T, M, Lp, halo, _p(dgp[0]), _p(dgp[1]), st)
+    dx = (bw.bf(B, icc, Lp, 32), bw.bf(B, icc, Lp, 32))
+    _lib.call("t2s_conv_accumulate", _p(At[0]), _p(At[1]), _p(bw.zero_bias), _p(dgp[0]), _p(dgp[1]), _p(dx[0]), _p(dx[1]), B, M,
+              Cin, 1, 1, 1, T, Lp, halo, Mi, st)
+    # ---- conv + BatchNorm stack, then the embedding ----
+    d_emb_in = bw.conv_bn_stack_backward(sv["enc_convs"], dout_planes=dx)
+    E = m.embedding.embedding_dim
+    V = m.embedding.num_embeddings
+    d_emb = bw.new(V, E)
+    _lib.call("t2s_embedding_grad", _p(ids), _p(d_emb_in[0]), _p(d_emb_in[1]), B, T, E, V, Lp, halo, _p(d_emb), st)
+    bw.grads[id(m.embedding.weight)] = d_emb
+    bw.keep += [dgx, hprev, whh, A, X, Pi, At, dgp, dx, d_emb_in]

@@ -257,8 +257,13 @@ class _TacoEngine:
         else:
             len32, T_out = None, T
         memory = torch.empty(B, T_out, 2 * H, dtype=torch.float32, device=dev)
+        gsave = csave = None
+        if save is not None:
+            gsave = torch.zeros(B, T, 2, 4 * H, dtype=torch.float32, device=dev)
+            csave = torch.zeros(B, T, 2, H, dtype=torch.float32, device=dev)
+            save.update(enc_gates=gsave, enc_c=csave)
         _lib.call("t2s_taco_encoder_lstm", _lib.ptr(gx), _lib.ptr(P["whhT"][0][0]), _lib.ptr(P["whhT"][1][0]),
-                  _lib.ptr(len32), _lib.ptr(memory), B, T, H, T_out, st)
+                  _lib.ptr(len32), _lib.ptr(memory), B, T, H, T_out, _lib.ptr(gsave), _lib.ptr(csave), st)
         if save is not None:
             save.update(enc_ids=ids64, enc_gx=gx, enc_Xh=Xh, enc_Xl=Xl, enc_T=T, enc_Lp=Lp, enc_len32=len32, memory=memory)
         return memory, len32
