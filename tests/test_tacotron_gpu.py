@@ -59,7 +59,7 @@ def test_gemv_and_lstm_cell_primitives():
     _lib.load()
     gen = torch.Generator().manual_seed(1)
     st = _lib.current_stream()
-    for (rows, K, items) in [(128, 1024, 3), (81, 1536, 70), (256, 80, 5)]:
+    for (rows, K, items) in [(128, 1024, 3), (81, 1536, 70), (256, 80, 5), (2560, 4096, 32), (1024, 128, 20), (128, 1024, 9)]:
         W = torch.randn(rows, K, generator=gen)
         x = torch.randn(items, K, generator=gen)
         b = torch.randn(rows, generator=gen)
@@ -70,7 +70,11 @@ def test_gemv_and_lstm_cell_primitives():
         want = torch.relu(x.double() @ W.double().t() + b.double())
         assert _rel(y, want) < 1e-6
     # LSTM cell through the decoder-step driver is covered below; here a direct 3-segment GEMV
-    n1, n2, n3, rows, items = 256, 512, 1024, 64, 4
+    for (n1, n2, n3, rows, items) in [(256, 512, 1024, 64, 4), (256, 512, 1024, 200, 32)]:
+        _three_segment_gemv(gen, st, n1, n2, n3, rows, items)
+
+
+def _three_segment_gemv(gen, st, n1, n2, n3, rows, items):
     W1 = torch.randn(rows, n1 + n2, generator=gen)
     W2 = torch.randn(rows, n3, generator=gen)
     xs = [torch.randn(items, n, generator=gen) for n in (n1, n2, n3)]

@@ -108,3 +108,57 @@ def test_grads_vs_reference_golden(trained):
         flat = trained["got"][name].flatten()
         step = max(1, flat.numel() // 16384)
         assert _rel(flat[::step], g[key]) < 5e-3, name
+
+
+def test_batch12_step_vs_oracle():
+    """Batch 12 (> 8 items: the LSTM cells and the BPTT data gradients take the f32 matrix-core path, csrc/sbgemm.hip):
+    loss and every parameter gradient against CPU autograd through the oracle, seeded masks, ragged lengths."""
+    from oracle import tacotron_oracle as O
+    from text2speech_amd.tacotron import Tacotron
+    _lib.load()
+    B, T_in, T_out = 12, 24, 20
+    gen = torch.Generator().manual_seed(5)
+    in_len = torch.tensor([T_in - (i * 3) // 2 for i in range(B)])
+    out_len = torch.tensor([T_out - i for i in range(B)])
+    text = torch.randint(2, 80, (B, T_in), generator=gen)
+    mel_t = torch.randn(B, 80, T_out, generator=gen)
+    gate_t = torch.zeros(B, T_out)
+    for b in range(B):
+        text[b, in_len[b]:] = 0
+        mel_t[b, :, out_len[b]:] = 0
+        gate_t[b, out_len[b] - 1:] = 1
+    bern = lambda *s: (torch.rand(*s, generator=gen) < 0.5).to(torch.uint8)
+    bern9 = lambda *s: (torch.rand(*s, generator=gen) < 0.9).to(torch.uint8)
+    tm = {"enc": [bern(B, 512, T_in) for _ in range(3)], "att": bern9(T_out, B, 1024), "dec": bern9(T_out, B, 1024),
+          "post": [bern(B, 512, T_out) for _ in range(4)] + [bern(B, 80, T_out)]}
+    pm = bern(T_out + 1, B, 2, 256)
+    sd = synth.tacotron_state()
+    m = Tacotron(HP, 80, num_speakers=2)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).train()
+    out = m((text.to(DEV), in_len.to(DEV), mel_t.to(DEV), int(in_len.max()), torch.zeros(B, device=DEV), out_len.to(DEV)),
+            prenet_masks=pm, train_masks=tm)
+    mt, gt = mel_t.to(DEV), gate_t.to(DEV)
+    loss = torch.nn.functional.mse_loss(out[0], mt) + torch.nn.functional.mse_loss(out[1], mt) + \
+        torch.nn.functional.binary_cross_entropy_with_logits(out[2].reshape(-1, 1), gt.reshape(-1, 1))
+    loss.backward()
+    torch.cuda.synchronize()
+    got = {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}
+    sd_cpu = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    masks = {"enc": [t.float() for t in tm["enc"]], "prenet": pm.float(), "att": tm["att"].float(), "dec": tm["dec"].float(),
+             "post": [t.float() for t in tm["post"]]}
+    oo = O.tacotron_forward(sd_cpu, HP, text, in_len, mel_t, out_len, masks, training=True)
+    lo = O.tacotron_loss(oo, mel_t, gate_t)
+    lo.backward()
+    assert abs(float(loss) - float(lo)) < 2e-4 * max(1.0, abs(float(lo)))
+    for k in range(4):
+        assert _rel(out[k], oo[k].detach()) < 1e-3, k
+    worst = []
+    for n, v in sd_cpu.items():
+        if not (torch.is_tensor(v) and v.is_floating_point() and v.grad is not None):
+            continue
+        assert n in got, n
+        diff = float((got[n].double() - v.grad.double()).norm())
+        worst.append((0.0 if diff < 2e-5 else _rel(got[n], v.grad), n))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 5e-3, worst[:6]

@@ -68,6 +68,11 @@ struct AttArgs {
 };
 
 hipError_t t2s_launch_gemv(const GemvArgs& a, hipStream_t stream);
+// sbgemm.hip: the same two operators on the f32 matrix cores for 9+ items (picked inside t2s_launch_gemv / _lstm_cell)
+bool t2s_sbgemm_plain_ok(const GemvArgs& a);
+hipError_t t2s_launch_sbgemm_plain(const GemvArgs& a, hipStream_t stream);
+bool t2s_sbgemm_lstm_ok(const LstmCellArgs& a);
+hipError_t t2s_launch_sbgemm_lstm(const LstmCellArgs& a, hipStream_t stream);
 hipError_t t2s_launch_lstm_cell(const LstmCellArgs& a, hipStream_t stream);
 hipError_t t2s_launch_att_energy(const AttArgs& a, hipStream_t stream);
 hipError_t t2s_launch_att_softmax_ctx(const AttArgs& a, hipStream_t stream);

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const GemvArgs a) {
 }
 
 hipError_t t2s_launch_gemv(const GemvArgs& a, hipStream_t stream) {
+    if (t2s_sbgemm_plain_ok(a)) return t2s_launch_sbgemm_plain(a, stream);      // 9+ items: f32 matrix cores
     const int K = a.n1 + a.n2 + a.n3;
     const int nv4 = (K + 255) / 256;
     dim3 grid((a.rows + 3) / 4, a.items < 64 ? 1 : (a.items < 4096 ? 16 : 64));
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(UNITS * 256) void lstm_cell_kernel(const LstmCellAr
 }
 
 hipError_t t2s_launch_lstm_cell(const LstmCellArgs& a, hipStream_t stream) {
+    if (t2s_sbgemm_lstm_ok(a)) return t2s_launch_sbgemm_lstm(a, stream);        // 9+ items: f32 matrix cores
     const int K = a.n1 + a.n2 + a.H;
     const int nv4 = (K + 255) / 256;
     const int nvw = (nv4 + 3) / 4;

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Tacotron-2 training step on one MI355X at the BASELINE configs[1] shape: batch 32, T_in 256, T_out 800,
+teacher-forced (zero_grad -> forward -> Tacotron2Loss -> backward -> Adam)."""
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from text2speech_amd import synth  # noqa: E402
+from text2speech_amd.optim import FusedAdam  # noqa: E402
+from text2speech_amd.tacotron import Tacotron  # noqa: E402
+
+
+def main():
+    B, T_in, T_out = int(os.environ.get("B", 32)), 256, int(os.environ.get("T_OUT", 800))
+    hp = dict(synth.TACOTRON_HPARAMS)
+    m = Tacotron(hp, 80, num_speakers=2)
+    m.load_state_dict(synth.tacotron_state())
+    m = m.cuda().train()
+    opt = FusedAdam([p for p in m.parameters()], lr=1e-4, weight_decay=1e-6)      # train.py:187-189
+    gen = torch.Generator().manual_seed(21)
+    text = torch.randint(2, 80, (B, T_in), generator=gen).cuda()
+    mel = torch.randn(B, 80, T_out, generator=gen).cuda()
+    gate = torch.zeros(B, T_out).cuda()
+    gate[:, -1] = 1
+    il = torch.full((B,), T_in, dtype=torch.long).cuda()
+    ol = torch.full((B,), T_out, dtype=torch.long).cuda()
+    inp = (text, il, mel, T_in, torch.zeros(B).cuda(), ol)
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        out = m(inp)
+        loss = F.mse_loss(out[0], mel) + F.mse_loss(out[1], mel) + F.binary_cross_entropy_with_logits(out[2].reshape(-1, 1), gate.reshape(-1, 1))
+        loss.backward()
+        opt.step()
+        return loss
+
+    l0 = float(step())
+    torch.cuda.synchronize()
+    print("[bench] warm-up done, loss %.4f" % l0, file=sys.stderr, flush=True)
+    n = 3
+    t0 = time.perf_counter()
+    for _ in range(n):
+        l = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(json.dumps({"metric": "Tacotron-2 train-step mel frames/sec (B=%d, T_in=%d, T_out=%d, fwd+loss+bwd+Adam)" % (B, T_in, T_out),
+                      "value": B * T_out / dt, "ms_per_step": dt * 1e3, "loss_first": l0, "loss_last": float(l),
+                      "max_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
+
+
+if __name__ == "__main__":
+    main()
