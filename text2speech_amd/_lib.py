@@ -62,6 +62,7 @@ SIGNATURES = {
                           c_vp],
     "t2s_relu_drop_bwd": [c_vp, c_vp, c_float, ctypes.c_size_t, c_vp, c_vp],
     "t2s_taco_att_bwd": [c_vp, c_vp],
+    "t2s_taco_bptt_steps": [c_vp, c_int, c_int, c_vp],
     "t2s_bn_bwd": [c_vp, c_vp],
     "t2s_sum_axis0": [c_vp, c_int, c_int, c_vp, c_vp],
     "t2s_add3": [c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp],

@@ -2,6 +2,7 @@
 #include "../../include/t2s_hip.h"
 #include "t2s_kernels.h"
 #include "taco_bwd_ops.h"
+#include "tacotron_ops.h"
 
 #include <string.h>
 
@@ -45,12 +46,83 @@ int t2s_relu_drop_bwd(const float* dy, const float* y, float scale, size_t n, fl
 int t2s_taco_att_bwd(const t2s_att_bwd* p, void* stream) {
     if (!p || !p->w_cur || !p->q || !p->pmem || !p->memory || !p->w_loc_conv || !p->w_loc_dense || !p->w_v ||
         !p->dw_carry || !p->dwc_carry || !p->d_q || !p->d_pmem || !p->d_memory || !p->dD_part || !p->dK_part ||
-        !p->dv_part || p->B <= 0 || p->T <= 0 || p->T > 256)
+        !p->dv_part || !p->dw_buf || !p->df_buf || !p->dq_part || p->B <= 0 || p->T <= 0)
         return T2S_EINVAL;
     static_assert(sizeof(t2s_att_bwd) == sizeof(AttBwdArgs), "t2s_att_bwd layout");
     AttBwdArgs a;
     memcpy(&a, p, sizeof(a));
     T2S_CHECK_HIP(t2s_launch_att_bwd(a, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+// The reversed decoder loop (BPTT through tacotron.py:355-393): per step, newest first,
+//   decoder LSTMCell pointwise backward -> [W_ih | W_hh]^T dgates -> attention backward (3 launches) -> W_query^T d_q ->
+//   attention LSTMCell pointwise backward -> [W_ih | W_hh]^T dgates.
+// Pure launch sequencing (pointer arithmetic on the caller's buffers), so the host never sits between the kernels.
+int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream_) {
+    if (!p || t_lo < 0 || t_hi <= t_lo || t_hi > p->T_out) return T2S_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int B = p->B, T = p->T_out, Tin = p->T_in, P = p->prenet_dim, E = p->enc_dim, A = p->att_rnn_dim, D = p->dec_rnn_dim;
+    const int ad = p->att_dim;
+    const int KD = A + E + D, KA = P + E + A, DE = D + E;
+    if (B <= 0 || Tin <= 0 || !p->W_dT || !p->W_aT || !p->W_qT || !p->w_loc_conv || !p->w_loc_dense || !p->w_v ||
+        !p->dec_gates_all || !p->dec_c_all || !p->att_gates_all || !p->att_c_all || !p->q_all || !p->wcum_all || !p->align ||
+        !p->pmem || !p->memory || !p->d_hc || !p->out_d || !p->out_a || !p->dg_d || !p->dg_a || !p->dq_all || !p->dah_q ||
+        !p->dc_d || !p->dc_a || !p->dw_c || !p->dwc_c || !p->d_pmem || !p->d_memory || !p->dD_part || !p->dK_part ||
+        !p->dv_part || !p->dw_buf || !p->df_buf || !p->dq_part)
+        return T2S_EINVAL;
+    for (int t = t_hi - 1; t >= t_lo; --t) {
+        const bool nxt = t + 1 < T;
+        // decoder LSTMCell: dh = d[h_dec] from the projection + from step t+1's decoder cell (through W_hh)
+        LstmBwdArgs cd;
+        cd.dh1 = p->d_hc + (size_t)t * B * DE; cd.s1 = DE;
+        cd.dh2 = nxt ? p->out_d + (size_t)(t + 1) * B * KD + A + E : nullptr; cd.s2 = KD;
+        cd.dh3 = nullptr; cd.s3 = 0;
+        cd.drop_mask = p->dec_drop ? p->dec_drop + (size_t)t * B * D : nullptr; cd.drop_scale = p->dec_drop_scale;
+        cd.gates = p->dec_gates_all + (size_t)t * B * 4 * D; cd.c_new = p->dec_c_all + (size_t)t * B * D;
+        cd.c_prev = t > 0 ? p->dec_c_all + (size_t)(t - 1) * B * D : nullptr;
+        cd.dc_carry = p->dc_d; cd.dgates = p->dg_d + (size_t)t * B * 4 * D; cd.B = B; cd.H = D;
+        T2S_CHECK_HIP(t2s_launch_lstm_cell_bwd(cd, stream));
+        GemvArgs g;
+        memset(&g, 0, sizeof(g));
+        g.W1 = p->W_dT; g.ld1 = 4 * D; g.k1 = 4 * D; g.x1 = cd.dgates; g.n1 = 4 * D; g.sx1 = 4 * D;
+        g.y = p->out_d + (size_t)t * B * KD; g.sy_item = KD; g.sy_row = 1; g.rows = KD; g.items = B; g.mask_scale = 1.f;
+        T2S_CHECK_HIP(t2s_launch_gemv(g, stream));
+        // attention: d_ctx = decoder-cell input part + projection part + step t+1's attention-cell input part
+        AttBwdArgs ab;
+        memset(&ab, 0, sizeof(ab));
+        ab.dctx1 = p->out_d + (size_t)t * B * KD + A; ab.sc1 = KD;
+        ab.dctx2 = p->d_hc + (size_t)t * B * DE + D; ab.sc2 = DE;
+        ab.dctx3 = nxt ? p->out_a + (size_t)(t + 1) * B * KA + P : nullptr; ab.sc3 = KA;
+        ab.w_cur = p->align + (size_t)t * Tin; ab.s_wcur = (long)p->T_cap * Tin;
+        ab.w_prev = t > 0 ? p->align + (size_t)(t - 1) * Tin : nullptr; ab.s_wprev = (long)p->T_cap * Tin;
+        ab.wc_prev = t > 0 ? p->wcum_all + (size_t)(t - 1) * B * Tin : nullptr; ab.s_wcprev = Tin;
+        ab.q = p->q_all + (size_t)t * B * ad; ab.pmem = p->pmem; ab.memory = p->memory; ab.lengths = p->lengths;
+        ab.w_loc_conv = p->w_loc_conv; ab.w_loc_dense = p->w_loc_dense; ab.w_v = p->w_v;
+        ab.dw_carry = p->dw_c; ab.dwc_carry = p->dwc_c; ab.d_q = p->dq_all + (size_t)t * B * ad; ab.d_pmem = p->d_pmem;
+        ab.d_memory = p->d_memory; ab.dD_part = p->dD_part; ab.dK_part = p->dK_part; ab.dv_part = p->dv_part;
+        ab.dw_buf = p->dw_buf; ab.df_buf = p->df_buf; ab.dq_part = p->dq_part;
+        ab.B = B; ab.T = Tin; ab.att_dim = ad; ab.enc_dim = E; ab.loc_f = p->loc_filters; ab.loc_ks = p->loc_kernel;
+        T2S_CHECK_HIP(t2s_launch_att_bwd(ab, stream));
+        memset(&g, 0, sizeof(g));
+        g.W1 = p->W_qT; g.ld1 = ad; g.k1 = ad; g.x1 = ab.d_q; g.n1 = ad; g.sx1 = ad;
+        g.y = p->dah_q; g.sy_item = A; g.sy_row = 1; g.rows = A; g.items = B; g.mask_scale = 1.f;
+        T2S_CHECK_HIP(t2s_launch_gemv(g, stream));
+        // attention LSTMCell: dh = from the decoder cell input + from the query + from step t+1's attention cell
+        LstmBwdArgs ca;
+        ca.dh1 = p->out_d + (size_t)t * B * KD; ca.s1 = KD;
+        ca.dh2 = p->dah_q; ca.s2 = A;
+        ca.dh3 = nxt ? p->out_a + (size_t)(t + 1) * B * KA + P + E : nullptr; ca.s3 = KA;
+        ca.drop_mask = p->att_drop ? p->att_drop + (size_t)t * B * A : nullptr; ca.drop_scale = p->att_drop_scale;
+        ca.gates = p->att_gates_all + (size_t)t * B * 4 * A; ca.c_new = p->att_c_all + (size_t)t * B * A;
+        ca.c_prev = t > 0 ? p->att_c_all + (size_t)(t - 1) * B * A : nullptr;
+        ca.dc_carry = p->dc_a; ca.dgates = p->dg_a + (size_t)t * B * 4 * A; ca.B = B; ca.H = A;
+        T2S_CHECK_HIP(t2s_launch_lstm_cell_bwd(ca, stream));
+        memset(&g, 0, sizeof(g));
+        g.W1 = p->W_aT; g.ld1 = 4 * A; g.k1 = 4 * A; g.x1 = ca.dgates; g.n1 = 4 * A; g.sx1 = 4 * A;
+        g.y = p->out_a + (size_t)t * B * KA; g.sy_item = KA; g.sy_row = 1; g.rows = KA; g.items = B; g.mask_scale = 1.f;
+        T2S_CHECK_HIP(t2s_launch_gemv(g, stream));
+    }
     return T2S_OK;
 }
 

@@ -32,7 +32,10 @@ struct AttBwdArgs {
     float* d_q;                  // [B][att_dim] out
     float* d_pmem;               // [B][T][att_dim] +=
     float* d_memory;             // [B][T][enc] +=
-    float* dD_part; float* dK_part; float* dv_part;   // per-batch-element partial parameter gradients, +=
+    float* dD_part; float* dK_part; float* dv_part;   // partial parameter gradients, one slot per (batch element, 32-position chunk), +=
+    float* dw_buf;               // scratch [B][T]
+    float* df_buf;               // scratch [B][T][32]
+    float* dq_part;              // scratch [B][ceil(T/32)][att_dim]
     int B, T, att_dim, enc_dim, loc_f, loc_ks;
 };
 

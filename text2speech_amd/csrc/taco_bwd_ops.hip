@@ -97,159 +97,248 @@ hipError_t t2s_launch_relu_drop_bwd(const float* dy, const float* y, float scale
 }
 
 // ------------------------------------------------------------------------------------------------
-// One step of the location-sensitive attention, backward (reference tacotron.py:124-166,379), one 512-thread
-// workgroup per batch element, T <= ATTB_MAXT.  Forward (recomputed here from the saved query / weights):
+// One step of the location-sensitive attention, backward (reference tacotron.py:124-166,379).  Forward (recomputed here
+// from the saved query / weights):
 //   f = conv1d([w_prev ; wc_prev], K) ; p = q + D f + pm ; e = v . tanh(p) ; w = softmax(e) ; ctx = w . mem ; wc = wc_prev + w
-#define ATTB_MAXT 256
-__global__ __launch_bounds__(512) void att_bwd_kernel(const AttBwdArgs a) {
-    __shared__ float s_cat[2][ATTB_MAXT + 64];
-    __shared__ float s_k[32 * 2 * 63];
-    __shared__ float s_f[ATTB_MAXT][33];
-    __shared__ float s_df[ATTB_MAXT][33];
-    __shared__ float s_d[32 * 128];          // D^T [f][a]
-    __shared__ float s_dw[ATTB_MAXT];
-    __shared__ float s_w[ATTB_MAXT];
-    __shared__ float s_dctx[512];
-    __shared__ float s_dp[8][128];
-    __shared__ float s_acc[128 * 32];        // cross-wave sum of dD, then reused
-    __shared__ float s_vec[2][128];          // dq, dv
-    __shared__ float red[8];
+// Three launches, each over (T_in / 32 chunks) x batch workgroups so the step fills the chip at batch 32:
+//   A  att_bwd_dw      d_w[t] = mem[t] . d_ctx + carries ; d_mem[t] += w[t] d_ctx
+//   B  att_bwd_energy  softmax backward (every workgroup re-reduces sum w d_w over the whole row: T floats), energies
+//                      backward for its 32 positions: d_pmem +=, partial d_q / dv / dD, d_f[t][:] = D^T d_pre[t]
+//   C  att_bwd_conv    location-conv backward from d_f (with a halo of kernel/2 positions): the carries for step t-1 and
+//                      the partial kernel gradient; chunk 0 also folds the partial queries into d_q.
+// Parameter-gradient partials live in one slot per (batch element, chunk) and are summed once after the last step.
+#define ATTB_CH 32
+static __device__ __forceinline__ float attb_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void att_bwd_dw_kernel(const AttBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_dctx[1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
-    const int T = a.T, AD = a.att_dim, KS = a.loc_ks, F = a.loc_f, pad = KS >> 1, E = a.enc_dim;
+    const int b = blockIdx.y, T = a.T, E = a.enc_dim;
+    for (int c = tid; c < E; c += 256) s_dctx[c] = sum3(a.dctx1, a.sc1, a.dctx2, a.sc2, a.dctx3, a.sc3, b, c);
+    __syncthreads();
+    const int tb = blockIdx.x * ATTB_CH + wave * 8;
+    float acc[8], wt[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        acc[r] = 0.f;
+        wt[r] = tb + r < T ? a.w_cur[(size_t)b * a.s_wcur + tb + r] : 0.f;
+    }
+    for (int c = lane * 4; c < E; c += 256) {
+        const f32x4 dc = *(const f32x4*)&s_dctx[c];
+        f32x4 m[8], dm[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (tb + r < T) {
+                const size_t mo = ((size_t)b * T + tb + r) * E + c;
+                m[r] = *(const f32x4*)(a.memory + mo);
+                dm[r] = *(const f32x4*)(a.d_memory + mo);
+            }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (tb + r < T) {
+                acc[r] += m[r][0] * dc[0] + m[r][1] * dc[1] + m[r][2] * dc[2] + m[r][3] * dc[3];
+                dm[r] += wt[r] * dc;
+                *(f32x4*)(a.d_memory + ((size_t)b * T + tb + r) * E + c) = dm[r];
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float v = attb_wave_sum(acc[r]);
+        const int t = tb + r;
+        if (lane == 0 && t < T) a.dw_buf[(size_t)b * T + t] = v + a.dw_carry[(size_t)b * T + t] + a.dwc_carry[(size_t)b * T + t];
+    }
+}
+
+__global__ __launch_bounds__(256) void att_bwd_energy_kernel(const AttBwdArgs a) {
+    __shared__ float s_cat[2][ATTB_CH + 64];
+    __shared__ float s_k[32 * 2 * 63];
+    __shared__ float s_f[ATTB_CH][33];
+    __shared__ float s_d[128 * 32];           // D [a][f]
+    __shared__ float s_acc[32 * 128];         // dD^T [f][a], waves add in turn
+    __shared__ float s_de[ATTB_CH];
+    __shared__ float s_dp[4][128];
+    __shared__ float s_vec[2][128];
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * ATTB_CH;
+    const int T = a.T, AD = a.att_dim, KS = a.loc_ks, F = a.loc_f, pad = KS >> 1;
     const int len = a.lengths ? a.lengths[b] : T;
+    const size_t slot = (size_t)b * gridDim.x + chunk;
     // ---- loads ----
-    for (int c = tid; c < E; c += 512) s_dctx[c] = sum3(a.dctx1, a.sc1, a.dctx2, a.sc2, a.dctx3, a.sc3, b, c);
-    for (int i = tid; i < F * 2 * KS; i += 512) s_k[i] = a.w_loc_conv[i];
-    for (int i = tid; i < 2 * (T + KS - 1); i += 512) {
-        const int c = i / (T + KS - 1), j = i - c * (T + KS - 1);
-        const int t = j - pad;
+    for (int i = tid; i < F * 2 * KS; i += 256) s_k[i] = a.w_loc_conv[i];
+    for (int i = tid; i < 2 * (ATTB_CH + KS - 1); i += 256) {
+        const int c = i / (ATTB_CH + KS - 1), j = i - c * (ATTB_CH + KS - 1);
+        const int t = t0 + j - pad;
         const float* src = c ? a.wc_prev : a.w_prev;
         s_cat[c][j] = (src && t >= 0 && t < T) ? src[(size_t)b * (c ? a.s_wcprev : a.s_wprev) + t] : 0.f;
     }
-    for (int i = tid; i < 32 * 128; i += 512) {
-        const int f = i >> 7, ai = i & 127;
+    for (int i = tid; i < 128 * 32; i += 256) {
+        const int ai = i >> 5, f = i & 31;
         s_d[i] = (f < F && ai < AD) ? a.w_loc_dense[ai * F + f] : 0.f;
-        s_acc[i] = 0.f;
     }
-    for (int t = tid; t < T; t += 512) s_w[t] = a.w_cur[(size_t)b * a.s_wcur + t];
     if (tid < 128) { s_vec[0][tid] = 0.f; s_vec[1][tid] = 0.f; }
+    // softmax backward needs sum_t w[t] d_w[t] over the whole row
+    float part = 0.f;
+    for (int t = tid; t < T; t += 256) part += a.w_cur[(size_t)b * a.s_wcur + t] * a.dw_buf[(size_t)b * T + t];
+    part = attb_wave_sum(part);
+    if (lane == 0) s_red[wave] = part;
     __syncthreads();
-    // ---- location features ----
-    for (int i = tid; i < T * F; i += 512) {
-        const int t = i / F, f = i - t * F;
+    const float sdot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (tid < ATTB_CH) {
+        const int t = t0 + tid;
+        s_de[tid] = (t < T && t < len) ? a.w_cur[(size_t)b * a.s_wcur + t] * (a.dw_buf[(size_t)b * T + t] - sdot) : 0.f;
+    }
+    // ---- location features of this chunk ----
+    for (int i = tid; i < ATTB_CH * F; i += 256) {
+        const int tq = i / F, f = i - tq * F;
         float acc = 0.f;
         for (int c = 0; c < 2; ++c)
-            for (int j = 0; j < KS; ++j) acc += s_k[(f * 2 + c) * KS + j] * s_cat[c][t + j];
-        s_f[t][f] = acc;
-    }
-    // ---- d_w = mem . d_ctx + carries ; d_mem += w (x) d_ctx ----
-    for (int t = wave; t < T; t += 8) {
-        float acc = 0.f;
-        const size_t mo = ((size_t)b * T + t) * E;
-        const float wt = s_w[t];
-        for (int c = lane; c < E; c += 64) {
-            acc += a.memory[mo + c] * s_dctx[c];
-            a.d_memory[mo + c] += wt * s_dctx[c];
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) s_dw[t] = acc + a.dw_carry[(size_t)b * T + t] + a.dwc_carry[(size_t)b * T + t];
+            for (int j = 0; j < KS; ++j) acc += s_k[(f * 2 + c) * KS + j] * s_cat[c][tq + j];
+        s_f[tq][f] = acc;
     }
     __syncthreads();
-    // ---- softmax backward: d_e = w (d_w - sum w d_w) ----
-    float part = 0.f;
-    for (int t = tid; t < T; t += 512) part += s_w[t] * s_dw[t];
-    part = wave_sum(part);
-    if (lane == 0) red[wave] = part;
-    __syncthreads();
-    float sdot = 0.f;
-    for (int i = 0; i < 8; ++i) sdot += red[i];
-    __syncthreads();
-    for (int t = tid; t < T; t += 512) s_dw[t] = (t < len) ? s_w[t] * (s_dw[t] - sdot) : 0.f;      // now d_e
-    __syncthreads();
-    // ---- energies backward: attention_dim on lanes (2 per lane), one wave per time step ----
-    {
-        const float q0 = lane < AD ? a.q[(size_t)b * AD + lane] : 0.f, q1 = lane + 64 < AD ? a.q[(size_t)b * AD + lane + 64] : 0.f;
-        const float v0 = lane < AD ? a.w_v[lane] : 0.f, v1 = lane + 64 < AD ? a.w_v[lane + 64] : 0.f;
-        float dq0 = 0.f, dq1 = 0.f, dv0 = 0.f, dv1 = 0.f;
-        float dD0[32], dD1[32];
+    // ---- energies backward: attention_dim on lanes (a0 = lane, a1 = lane + 64), a wave takes 8 positions ----
+    float d0[32], d1[32], dD0[32], dD1[32];
 #pragma unroll
-        for (int f = 0; f < 32; ++f) { dD0[f] = 0.f; dD1[f] = 0.f; }
-        for (int t = wave; t < T; t += 8) {
-            const size_t po = ((size_t)b * T + t) * AD;
-            float p0 = q0 + (lane < AD ? a.pmem[po + lane] : 0.f), p1 = q1 + (lane + 64 < AD ? a.pmem[po + lane + 64] : 0.f);
+    for (int f = 0; f < 32; ++f) {
+        d0[f] = (lane < AD && f < F) ? a.w_loc_dense[lane * F + f] : 0.f;
+        d1[f] = (lane + 64 < AD && f < F) ? a.w_loc_dense[(lane + 64) * F + f] : 0.f;
+        dD0[f] = 0.f; dD1[f] = 0.f;
+    }
+    const float q0 = lane < AD ? a.q[(size_t)b * AD + lane] : 0.f, q1 = lane + 64 < AD ? a.q[(size_t)b * AD + lane + 64] : 0.f;
+    const float v0 = lane < AD ? a.w_v[lane] : 0.f, v1 = lane + 64 < AD ? a.w_v[lane + 64] : 0.f;
+    float dq0 = 0.f, dq1 = 0.f, dv0 = 0.f, dv1 = 0.f;
+    float pm0[8], pm1[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int t = t0 + wave * 8 + r;
+        const size_t po = ((size_t)b * T + t) * AD;
+        pm0[r] = (t < T && lane < AD) ? a.pmem[po + lane] : 0.f;
+        pm1[r] = (t < T && lane + 64 < AD) ? a.pmem[po + lane + 64] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int tq = wave * 8 + r, t = t0 + tq;
+        if (t >= T) break;                                   // wave-uniform
+        float p0 = q0 + pm0[r], p1 = q1 + pm1[r];
+#pragma unroll
+        for (int f = 0; f < 32; ++f) {
+            const float ff = s_f[tq][f];
+            p0 += d0[f] * ff;
+            p1 += d1[f] * ff;
+        }
+        const float th0 = tanhf(p0), th1 = tanhf(p1);
+        const float de = s_de[tq];
+        const float dp0 = lane < AD ? de * v0 * (1.f - th0 * th0) : 0.f;
+        const float dp1 = lane + 64 < AD ? de * v1 * (1.f - th1 * th1) : 0.f;
+        dq0 += dp0; dq1 += dp1;
+        dv0 += de * th0; dv1 += de * th1;
+        const size_t po = ((size_t)b * T + t) * AD;
+        if (lane < AD) a.d_pmem[po + lane] += dp0;
+        if (lane + 64 < AD) a.d_pmem[po + lane + 64] += dp1;
+#pragma unroll
+        for (int f = 0; f < 32; ++f) {
+            const float ff = s_f[tq][f];
+            dD0[f] += dp0 * ff;
+            dD1[f] += dp1 * ff;
+        }
+        s_dp[wave][lane] = dp0;
+        s_dp[wave][lane + 64] = dp1;
+        __builtin_amdgcn_wave_barrier();
+        // d_f[t][f] = sum_a D[a][f] d_pre[a]: f on lanes 0..31, the two half-waves take even / odd a (bank-disjoint)
+        {
+            const int f = lane & 31, half = lane >> 5;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < 64; ++i) acc += s_d[(2 * i + half) * 32 + f] * s_dp[wave][2 * i + half];
+            acc += __shfl_xor(acc, 32, 64);
+            if (lane < 32) a.df_buf[((size_t)b * T + t) * 32 + lane] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // deterministic cross-wave sums: waves add in turn
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+            s_vec[0][lane] += dq0; s_vec[0][lane + 64] += dq1;
+            s_vec[1][lane] += dv0; s_vec[1][lane + 64] += dv1;
 #pragma unroll
             for (int f = 0; f < 32; ++f) {
-                const float ff = s_f[t][f];
-                p0 += s_d[f * 128 + lane] * ff;
-                p1 += s_d[f * 128 + 64 + lane] * ff;
+                if (w == 0) { s_acc[f * 128 + lane] = dD0[f]; s_acc[f * 128 + 64 + lane] = dD1[f]; }
+                else { s_acc[f * 128 + lane] += dD0[f]; s_acc[f * 128 + 64 + lane] += dD1[f]; }
             }
-            const float th0 = tanhf(p0), th1 = tanhf(p1);
-            const float de = s_dw[t];
-            const float dp0 = lane < AD ? de * v0 * (1.f - th0 * th0) : 0.f;
-            const float dp1 = lane + 64 < AD ? de * v1 * (1.f - th1 * th1) : 0.f;
-            dq0 += dp0; dq1 += dp1;
-            dv0 += de * th0; dv1 += de * th1;
-            if (lane < AD) a.d_pmem[po + lane] += dp0;
-            if (lane + 64 < AD) a.d_pmem[po + lane + 64] += dp1;
-#pragma unroll
-            for (int f = 0; f < 32; ++f) {
-                const float ff = s_f[t][f];
-                dD0[f] += dp0 * ff;
-                dD1[f] += dp1 * ff;
-            }
-            s_dp[wave][lane] = dp0;
-            s_dp[wave][lane + 64] = dp1;
-            // d_f[t][f] = sum_a D[a][f] d_pre[a]   (lanes 0..31 = f); same-wave LDS exchange
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 32) {
-                float acc = 0.f;
-                for (int ai = 0; ai < 128; ++ai) acc += s_d[lane * 128 + ai] * s_dp[wave][ai];
-                s_df[t][lane] = acc;
-            }
-            __builtin_amdgcn_wave_barrier();
         }
-        // deterministic cross-wave sums: waves add in turn
-        for (int w = 0; w < 8; ++w) {
-            if (wave == w) {
-                s_vec[0][lane] += dq0; s_vec[0][lane + 64] += dq1;
-                s_vec[1][lane] += dv0; s_vec[1][lane + 64] += dv1;
-#pragma unroll
-                for (int f = 0; f < 32; ++f) {
-                    s_acc[lane * 32 + f] += dD0[f];
-                    s_acc[(lane + 64) * 32 + f] += dD1[f];
-                }
-            }
-            __syncthreads();
-        }
+        __syncthreads();
     }
     if (tid < AD) {
-        a.d_q[(size_t)b * AD + tid] = s_vec[0][tid];
-        a.dv_part[(size_t)b * AD + tid] += s_vec[1][tid];
+        a.dq_part[slot * AD + tid] = s_vec[0][tid];
+        a.dv_part[slot * AD + tid] += s_vec[1][tid];
     }
-    for (int i = tid; i < AD * F; i += 512) a.dD_part[(size_t)b * AD * F + i] += s_acc[(i / F) * 32 + (i % F)];
-    // ---- location conv backward: carries for step t-1 and the kernel gradient ----
-    for (int i = tid; i < 2 * T; i += 512) {
-        const int c = i / T, tp = i - c * T;           // gradient w.r.t. cat[c][tp]
+    for (int i = tid; i < AD * F; i += 256) a.dD_part[slot * AD * F + i] += s_acc[(i % F) * 128 + (i / F)];
+}
+
+__global__ __launch_bounds__(256) void att_bwd_conv_kernel(const AttBwdArgs a) {
+    __shared__ float s_cat[2][ATTB_CH + 64];
+    __shared__ float s_k[32 * 2 * 63];
+    __shared__ float s_df[ATTB_CH + 64][33];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * ATTB_CH, nchunk = gridDim.x;
+    const int T = a.T, AD = a.att_dim, KS = a.loc_ks, F = a.loc_f, pad = KS >> 1;
+    const size_t slot = (size_t)b * nchunk + chunk;
+    for (int i = tid; i < F * 2 * KS; i += 256) s_k[i] = a.w_loc_conv[i];
+    for (int i = tid; i < 2 * (ATTB_CH + KS - 1); i += 256) {
+        const int c = i / (ATTB_CH + KS - 1), j = i - c * (ATTB_CH + KS - 1);
+        const int t = t0 + j - pad;
+        const float* src = c ? a.wc_prev : a.w_prev;
+        s_cat[c][j] = (src && t >= 0 && t < T) ? src[(size_t)b * (c ? a.s_wcprev : a.s_wprev) + t] : 0.f;
+    }
+    for (int i = tid; i < (ATTB_CH + KS - 1) * 32; i += 256) {
+        const int j = i >> 5, f = i & 31;
+        const int t = t0 + j - pad;
+        s_df[j][f] = (t >= 0 && t < T && f < F) ? a.df_buf[((size_t)b * T + t) * 32 + f] : 0.f;
+    }
+    __syncthreads();
+    // carries: d cat[c][tp] = sum_f sum_j K[f][c][j] d_f[tp - j + pad][f]; 64 outputs x 4 threads (8 filters each)
+    {
+        const int o = tid >> 2, fg = tid & 3;
+        const int c = o >> 5, tl = o & 31;
         float acc = 0.f;
-        for (int f = 0; f < F; ++f)
-            for (int j = 0; j < KS; ++j) {
-                const int t = tp - j + pad;           // cat index tp feeds output t with tap j: tp = t + j - pad
-                if (t >= 0 && t < T) acc += s_k[(f * 2 + c) * KS + j] * s_df[t][f];
-            }
-        if (c == 0) a.dw_carry[(size_t)b * T + tp] = acc;
-        else a.dwc_carry[(size_t)b * T + tp] += acc;
+        for (int f = fg * 8; f < fg * 8 + 8 && f < F; ++f)
+            for (int j = 0; j < KS; ++j) acc += s_k[(f * 2 + c) * KS + j] * s_df[tl - j + 2 * pad][f];   // row (tp - j + pad) - (t0 - pad)
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        const int tp = t0 + tl;
+        if (fg == 0 && tp < T) {
+            if (c == 0) a.dw_carry[(size_t)b * T + tp] = acc;
+            else a.dwc_carry[(size_t)b * T + tp] += acc;
+        }
     }
-    for (int i = tid; i < F * 2 * KS; i += 512) {
+    // kernel gradient partial: dK[f][c][j] += sum_{t in chunk} d_f[t][f] cat[c][t + j - pad]
+    for (int i = tid; i < F * 2 * KS; i += 256) {
         const int f = i / (2 * KS), r = i - f * 2 * KS, c = r / KS, j = r - c * KS;
         float acc = 0.f;
-        for (int t = 0; t < T; ++t) acc += s_df[t][f] * s_cat[c][t + j];
-        a.dK_part[(size_t)b * F * 2 * KS + i] += acc;
+#pragma unroll 8
+        for (int tl = 0; tl < ATTB_CH; ++tl) acc += s_df[tl + pad][f] * s_cat[c][tl + j];
+        a.dK_part[slot * F * 2 * KS + i] += acc;
+    }
+    if (chunk == 0 && tid < AD) {
+        float sum = 0.f;
+        for (int ch = 0; ch < nchunk; ++ch) sum += a.dq_part[((size_t)b * nchunk + ch) * AD + tid];
+        a.d_q[(size_t)b * AD + tid] = sum;
     }
 }
+
 hipError_t t2s_launch_att_bwd(const AttBwdArgs& a, hipStream_t stream) {
-    if (a.T > ATTB_MAXT || a.enc_dim > 512 || a.att_dim > 128 || a.loc_f > 32 || a.loc_ks > 63) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(att_bwd_kernel, dim3(a.B), dim3(512), 0, stream, a);
+    if (a.enc_dim > 1024 || (a.enc_dim & 3) || a.att_dim > 128 || a.loc_f > 32 || a.loc_ks > 63 || !(a.loc_ks & 1) ||
+        !a.dw_buf || !a.df_buf || !a.dq_part)
+        return hipErrorInvalidValue;
+    const dim3 grid((a.T + ATTB_CH - 1) / ATTB_CH, a.B);
+    hipLaunchKernelGGL(att_bwd_dw_kernel, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(att_bwd_energy_kernel, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(att_bwd_conv_kernel, grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -29,8 +29,21 @@ class _AttBwd(ctypes.Structure):
                  ("w_cur", vp), ("s_wcur", lng), ("w_prev", vp), ("wc_prev", vp), ("s_wprev", lng), ("s_wcprev", lng),
                  ("q", vp), ("pmem", vp), ("memory", vp), ("lengths", vp), ("w_loc_conv", vp), ("w_loc_dense", vp),
                  ("w_v", vp), ("dw_carry", vp), ("dwc_carry", vp), ("d_q", vp), ("d_pmem", vp), ("d_memory", vp),
-                 ("dD_part", vp), ("dK_part", vp), ("dv_part", vp)] +
+                 ("dD_part", vp), ("dK_part", vp), ("dv_part", vp), ("dw_buf", vp), ("df_buf", vp), ("dq_part", vp)] +
                 [(n, i32) for n in ("B", "T", "att_dim", "enc_dim", "loc_f", "loc_ks")])
+
+
+class _Bptt(ctypes.Structure):
+    """Mirror of t2s_taco_bptt."""
+    _fields_ = ([(n, i32) for n in ("B", "T_in", "T_out", "T_cap", "prenet_dim", "enc_dim", "att_rnn_dim", "dec_rnn_dim",
+                                    "att_dim", "loc_filters", "loc_kernel")] +
+                [(n, vp) for n in ("W_dT", "W_aT", "W_qT", "w_loc_conv", "w_loc_dense", "w_v", "dec_gates_all", "dec_c_all",
+                                   "att_gates_all", "att_c_all", "q_all", "wcum_all", "align", "pmem", "memory", "lengths",
+                                   "att_drop", "dec_drop")] +
+                [("att_drop_scale", f32c), ("dec_drop_scale", f32c)] +
+                [(n, vp) for n in ("d_hc", "out_d", "out_a", "dg_d", "dg_a", "dq_all", "dah_q", "dc_d", "dc_a", "dw_c",
+                                   "dwc_c", "d_pmem", "d_memory", "dD_part", "dK_part", "dv_part", "dw_buf", "df_buf",
+                                   "dq_part")])
 
 
 class _BnBwd(ctypes.Structure):
@@ -233,42 +246,26 @@ class _Bwd:
         dc_d, dc_a = self.zeros(B, D), self.zeros(B, A)
         dw_c, dwc_c = self.zeros(B, T_in), self.zeros(B, T_in)
         d_pmem, d_memory = self.zeros(B, T_in, ad), self.zeros(B, T_in, E)
-        dD_p, dK_p, dv_p = self.zeros(B, ad * F_), self.zeros(B, F_ * 2 * KS), self.zeros(B, ad)
+        nch = (T_in + 31) // 32                     # partial parameter gradients: one slot per (batch element, 32-position chunk)
+        dD_p, dK_p, dv_p = self.zeros(B * nch, ad * F_), self.zeros(B * nch, F_ * 2 * KS), self.zeros(B * nch, ad)
+        dw_buf, df_buf, dq_part = self.new(B, T_in), self.new(B, T_in, 32), self.new(B, nch, ad)
         align = S["align_out"]                     # [B][T_cap][T_in]
         T_cap = align.size(1)
         att_drop, dec_drop = S.get("att_drop"), S.get("dec_drop")
-        a_scale = 1.0 / (1.0 - dec.p_attention_dropout)
-        d_scale = 1.0 / (1.0 - dec.p_decoder_dropout)
-        len32 = sv["len32"]
         w_v = P["w_v"].reshape(-1).contiguous()
-        for t in reversed(range(T)):
-            nxt = t + 1 < T
-            # decoder LSTMCell
-            _lib.call("t2s_lstm_cell_bwd", _p(d_hc, t * B * DE), DE, _p(out_d, (t + 1) * B * KD + A + E) if nxt else None, KD,
-                      None, 0, _p(dec_drop, t * B * D) if dec_drop is not None else None, d_scale,
-                      _p(S["dec_gates_all"], t * B * 4 * D), _p(S["dec_c_all"], t * B * D),
-                      _p(S["dec_c_all"], (t - 1) * B * D) if t > 0 else None, _p(dc_d), _p(dg_d, t * B * 4 * D), B, D, st)
-            self.gemv(W_dT, 4 * D, 4 * D, _p(dg_d, t * B * 4 * D), 4 * D, _p(out_d, t * B * KD), KD, KD, B)
-            # attention
-            ab = _AttBwd(dctx1=_p(out_d, t * B * KD + A), sc1=KD, dctx2=_p(d_hc, t * B * DE + D), sc2=DE,
-                         dctx3=_p(out_a, (t + 1) * B * KA + Pd) if nxt else None, sc3=KA,
-                         w_cur=_p(align, t * T_in), s_wcur=T_cap * T_in,
-                         w_prev=_p(align, (t - 1) * T_in) if t > 0 else None,
-                         wc_prev=_p(S["wcum_all"], (t - 1) * B * T_in) if t > 0 else None, s_wprev=T_cap * T_in, s_wcprev=T_in,
-                         q=_p(S["q_all"], t * B * ad), pmem=_p(S["pmem"]), memory=_p(memory), lengths=_p(len32),
-                         w_loc_conv=_p(P["w_loc_conv"]), w_loc_dense=_p(P["w_loc_dense"]), w_v=_p(w_v),
-                         dw_carry=_p(dw_c), dwc_carry=_p(dwc_c), d_q=_p(dq_all, t * B * ad), d_pmem=_p(d_pmem),
-                         d_memory=_p(d_memory), dD_part=_p(dD_p), dK_part=_p(dK_p), dv_part=_p(dv_p),
-                         B=B, T=T_in, att_dim=ad, enc_dim=E, loc_f=F_, loc_ks=KS)
-            _lib.call("t2s_taco_att_bwd", ctypes.byref(ab), st)
-            self.gemv(W_qT, ad, ad, _p(dq_all, t * B * ad), ad, _p(dah_q), A, A, B)
-            # attention LSTMCell
-            _lib.call("t2s_lstm_cell_bwd", _p(out_d, t * B * KD), KD, _p(dah_q), A,
-                      _p(out_a, (t + 1) * B * KA + Pd + E) if nxt else None, KA,
-                      _p(att_drop, t * B * A) if att_drop is not None else None, a_scale,
-                      _p(S["att_gates_all"], t * B * 4 * A), _p(S["att_c_all"], t * B * A),
-                      _p(S["att_c_all"], (t - 1) * B * A) if t > 0 else None, _p(dc_a), _p(dg_a, t * B * 4 * A), B, A, st)
-            self.gemv(W_aT, 4 * A, 4 * A, _p(dg_a, t * B * 4 * A), 4 * A, _p(out_a, t * B * KA), KA, KA, B)
+        bp = _Bptt(B=B, T_in=T_in, T_out=T, T_cap=T_cap, prenet_dim=Pd, enc_dim=E, att_rnn_dim=A, dec_rnn_dim=D, att_dim=ad,
+                   loc_filters=F_, loc_kernel=KS, W_dT=_p(W_dT), W_aT=_p(W_aT), W_qT=_p(W_qT), w_loc_conv=_p(P["w_loc_conv"]),
+                   w_loc_dense=_p(P["w_loc_dense"]), w_v=_p(w_v), dec_gates_all=_p(S["dec_gates_all"]),
+                   dec_c_all=_p(S["dec_c_all"]), att_gates_all=_p(S["att_gates_all"]), att_c_all=_p(S["att_c_all"]),
+                   q_all=_p(S["q_all"]), wcum_all=_p(S["wcum_all"]), align=_p(align), pmem=_p(S["pmem"]), memory=_p(memory),
+                   lengths=_p(sv["len32"]), att_drop=_p(att_drop), dec_drop=_p(dec_drop),
+                   att_drop_scale=1.0 / (1.0 - dec.p_attention_dropout), dec_drop_scale=1.0 / (1.0 - dec.p_decoder_dropout),
+                   d_hc=_p(d_hc), out_d=_p(out_d), out_a=_p(out_a), dg_d=_p(dg_d), dg_a=_p(dg_a), dq_all=_p(dq_all),
+                   dah_q=_p(dah_q), dc_d=_p(dc_d), dc_a=_p(dc_a), dw_c=_p(dw_c), dwc_c=_p(dwc_c), d_pmem=_p(d_pmem),
+                   d_memory=_p(d_memory), dD_part=_p(dD_p), dK_part=_p(dK_p), dv_part=_p(dv_p), dw_buf=_p(dw_buf),
+                   df_buf=_p(df_buf), dq_part=_p(dq_part))
+        _lib.call("t2s_taco_bptt_steps", ctypes.byref(bp), T, 0, st)        # the whole reversed loop, enqueued from C++
+        self.keep += [dw_buf, df_buf, dq_part]
         # ---- weight gradients over all (step, batch) items ----
         ar = dec.attention_rnn
         Pa, ks, M4, N = self.items_wgrad(items, [(_p(dg_a), 4 * A, 4 * A, 0, 0)],
@@ -298,7 +295,7 @@ class _Bwd:
         for part, param, n in ((dD_p, loc.location_dense.linear_layer.weight, ad * F_),
                                (dK_p, loc.location_conv.conv.weight, F_ * 2 * KS), (dv_p, al.v.linear_layer.weight, ad)):
             g = self.new(*param.shape)
-            _lib.call("t2s_sum_axis0", _p(part), B, n, _p(g), st)
+            _lib.call("t2s_sum_axis0", _p(part), B * nch, n, _p(g), st)
             self.grads[id(param)] = g
         # prenet (hoisted): pre_all = drop(relu(W2 drop(relu(W1 frames))))
         d_pre = out_a[:, :, :Pd].contiguous().view(items, Pd)
