@@ -343,7 +343,8 @@ typedef struct t2s_att_bwd {
     const float *q, *pmem, *memory; const int *lengths;
     const float *w_loc_conv, *w_loc_dense, *w_v;
     float *dw_carry, *dwc_carry, *d_q, *d_pmem, *d_memory;
-    float *dD_part, *dK_part, *dv_part;   /* += ; one slot per (batch element, 32-position chunk): [B*ceil(T/32)][...] */
+    float *dD_part, *dK_part, *dv_part;   /* += ; one slot per (batch element, 32-position chunk): [B*ceil(T/32)][...];
+                                             dD slots hold the transposed gradient [loc_f][att_dim] */
     float *dw_buf, *df_buf, *dq_part;     /* scratch: [B][T], [B][T][32], [B][ceil(T/32)][att_dim] */
     int B, T, att_dim, enc_dim, loc_f, loc_ks;
 } t2s_att_bwd;
@@ -352,20 +353,20 @@ int t2s_taco_att_bwd(const t2s_att_bwd* a, void* stream);
 
 /* Reversed decoder loop (BPTT through tacotron.py:355-393,418-427): steps t_hi-1 ... t_lo, newest first.  All buffers are the
  * caller's; histories are [T_out][B][...] unless noted.  W_dT = [W_ih | W_hh]^T of decoder_rnn ([A+E+D][4D]), W_aT the same
- * for attention_rnn ([P+E+A][4A]), W_qT = query_layer^T ([A][att_dim]).  out_d / out_a receive d[input | h] of the two
+ * for attention_rnn ([P+E+A][4A]), w_query = query_layer weight as stored ([att_dim][A]).  out_d / out_a receive d[input | h] of the two
  * cells ([T_out][B][A+E+D] and [T_out][B][P+E+A]); dg_d / dg_a / dq_all keep every step's gate / query gradients for the
  * weight-gradient GEMMs that follow the loop. */
 typedef struct t2s_taco_bptt {
     int B, T_in, T_out, T_cap;
     int prenet_dim, enc_dim, att_rnn_dim, dec_rnn_dim, att_dim, loc_filters, loc_kernel;
-    const float *W_dT, *W_aT, *W_qT, *w_loc_conv, *w_loc_dense, *w_v;
+    const float *W_dT, *W_aT, *w_query, *w_loc_conv, *w_loc_dense, *w_v;
     const float *dec_gates_all, *dec_c_all, *att_gates_all, *att_c_all, *q_all, *wcum_all;
     const float *align;                    /* [B][T_cap][T_in] */
     const float *pmem, *memory; const int *lengths;
     const unsigned char *att_drop, *dec_drop; float att_drop_scale, dec_drop_scale;
     const float *d_hc;                     /* [T_out][B][D+E]: gradient of [h_dec | ctx] from projection + gate */
     float *out_d, *out_a, *dg_d, *dg_a, *dq_all;
-    float *dah_q, *dc_d, *dc_a, *dw_c, *dwc_c;          /* carries: [B][A], [B][D], [B][A], [B][T_in] x2 (zero-initialised) */
+    float *dc_d, *dc_a, *dw_c, *dwc_c;                  /* carries: [B][D], [B][A], [B][T_in] x2 (zero-initialised) */
     float *d_pmem, *d_memory;                           /* += [B][T_in][att_dim], [B][T_in][enc] */
     float *dD_part, *dK_part, *dv_part, *dw_buf, *df_buf, *dq_part;   /* as in t2s_att_bwd */
 } t2s_taco_bptt;

@@ -73,12 +73,18 @@ static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow,
     const int nsteps = o.K >> 4;
     const int s0 = (wave * nsteps) >> 3, s1 = ((wave + 1) * nsteps) >> 3;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    SbFrag cur, nxt;
-    sb_load(cur, o, s0, s1, grow, row_ok, item0, q);
-    for (int s = s0; s < s1; s += 4) {
-        sb_load(nxt, o, s + 4, s1, grow, row_ok, item0, q);
-        sb_mma(cur, acc0, acc1);
-        cur = nxt;
+    // ring of three operand groups (4 K-steps each): two groups of loads stay in flight behind the MFMAs of the third
+    SbFrag f0, f1, f2;
+    sb_load(f0, o, s0, s1, grow, row_ok, item0, q);
+    sb_load(f1, o, s0 + 4, s1, grow, row_ok, item0, q);
+    sb_load(f2, o, s0 + 8, s1, grow, row_ok, item0, q);
+    for (int s = s0; s < s1; s += 12) {
+        sb_mma(f0, acc0, acc1);
+        sb_load(f0, o, s + 12, s1, grow, row_ok, item0, q);
+        if (s + 4 < s1) sb_mma(f1, acc0, acc1);
+        sb_load(f1, o, s + 16, s1, grow, row_ok, item0, q);
+        if (s + 8 < s1) sb_mma(f2, acc0, acc1);
+        sb_load(f2, o, s + 20, s1, grow, row_ok, item0, q);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

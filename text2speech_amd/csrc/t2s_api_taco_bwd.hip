@@ -33,6 +33,7 @@ int t2s_lstm_cell_bwd(const float* dh1, long s1, const float* dh2, long s2, cons
     a.dh1 = dh1; a.s1 = s1; a.dh2 = dh2; a.s2 = s2; a.dh3 = dh3; a.s3 = s3;
     a.drop_mask = drop_mask; a.drop_scale = drop_scale; a.gates = gates; a.c_new = c_new; a.c_prev = c_prev;
     a.dc_carry = dc_carry; a.dgates = dgates; a.B = B; a.H = H;
+    a.wq = nullptr; a.dq = nullptr; a.q_dim = 0;
     T2S_CHECK_HIP(t2s_launch_lstm_cell_bwd(a, (hipStream_t)stream));
     return T2S_OK;
 }
@@ -56,8 +57,8 @@ int t2s_taco_att_bwd(const t2s_att_bwd* p, void* stream) {
 }
 
 // The reversed decoder loop (BPTT through tacotron.py:355-393): per step, newest first,
-//   decoder LSTMCell pointwise backward -> [W_ih | W_hh]^T dgates -> attention backward (3 launches) -> W_query^T d_q ->
-//   attention LSTMCell pointwise backward -> [W_ih | W_hh]^T dgates.
+//   decoder LSTMCell pointwise backward -> [W_ih | W_hh]^T dgates -> attention backward (3 launches) ->
+//   attention LSTMCell pointwise backward (+ W_query^T d_q, fused) -> [W_ih | W_hh]^T dgates.
 // Pure launch sequencing (pointer arithmetic on the caller's buffers), so the host never sits between the kernels.
 int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream_) {
     if (!p || t_lo < 0 || t_hi <= t_lo || t_hi > p->T_out) return T2S_EINVAL;
@@ -65,9 +66,9 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
     const int B = p->B, T = p->T_out, Tin = p->T_in, P = p->prenet_dim, E = p->enc_dim, A = p->att_rnn_dim, D = p->dec_rnn_dim;
     const int ad = p->att_dim;
     const int KD = A + E + D, KA = P + E + A, DE = D + E;
-    if (B <= 0 || Tin <= 0 || !p->W_dT || !p->W_aT || !p->W_qT || !p->w_loc_conv || !p->w_loc_dense || !p->w_v ||
+    if (B <= 0 || Tin <= 0 || !p->W_dT || !p->W_aT || !p->w_query || !p->w_loc_conv || !p->w_loc_dense || !p->w_v ||
         !p->dec_gates_all || !p->dec_c_all || !p->att_gates_all || !p->att_c_all || !p->q_all || !p->wcum_all || !p->align ||
-        !p->pmem || !p->memory || !p->d_hc || !p->out_d || !p->out_a || !p->dg_d || !p->dg_a || !p->dq_all || !p->dah_q ||
+        !p->pmem || !p->memory || !p->d_hc || !p->out_d || !p->out_a || !p->dg_d || !p->dg_a || !p->dq_all ||
         !p->dc_d || !p->dc_a || !p->dw_c || !p->dwc_c || !p->d_pmem || !p->d_memory || !p->dD_part || !p->dK_part ||
         !p->dv_part || !p->dw_buf || !p->df_buf || !p->dq_part)
         return T2S_EINVAL;
@@ -82,6 +83,7 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         cd.gates = p->dec_gates_all + (size_t)t * B * 4 * D; cd.c_new = p->dec_c_all + (size_t)t * B * D;
         cd.c_prev = t > 0 ? p->dec_c_all + (size_t)(t - 1) * B * D : nullptr;
         cd.dc_carry = p->dc_d; cd.dgates = p->dg_d + (size_t)t * B * 4 * D; cd.B = B; cd.H = D;
+        cd.wq = nullptr; cd.dq = nullptr; cd.q_dim = 0;
         T2S_CHECK_HIP(t2s_launch_lstm_cell_bwd(cd, stream));
         GemvArgs g;
         memset(&g, 0, sizeof(g));
@@ -104,15 +106,12 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         ab.dw_buf = p->dw_buf; ab.df_buf = p->df_buf; ab.dq_part = p->dq_part;
         ab.B = B; ab.T = Tin; ab.att_dim = ad; ab.enc_dim = E; ab.loc_f = p->loc_filters; ab.loc_ks = p->loc_kernel;
         T2S_CHECK_HIP(t2s_launch_att_bwd(ab, stream));
-        memset(&g, 0, sizeof(g));
-        g.W1 = p->W_qT; g.ld1 = ad; g.k1 = ad; g.x1 = ab.d_q; g.n1 = ad; g.sx1 = ad;
-        g.y = p->dah_q; g.sy_item = A; g.sy_row = 1; g.rows = A; g.items = B; g.mask_scale = 1.f;
-        T2S_CHECK_HIP(t2s_launch_gemv(g, stream));
         // attention LSTMCell: dh = from the decoder cell input + from the query + from step t+1's attention cell
         LstmBwdArgs ca;
         ca.dh1 = p->out_d + (size_t)t * B * KD; ca.s1 = KD;
-        ca.dh2 = p->dah_q; ca.s2 = A;
-        ca.dh3 = nxt ? p->out_a + (size_t)(t + 1) * B * KA + P + E : nullptr; ca.s3 = KA;
+        ca.dh2 = nxt ? p->out_a + (size_t)(t + 1) * B * KA + P + E : nullptr; ca.s2 = KA;
+        ca.dh3 = nullptr; ca.s3 = 0;
+        ca.wq = p->w_query; ca.dq = ab.d_q; ca.q_dim = ad;           // + W_query^T d_q, fused
         ca.drop_mask = p->att_drop ? p->att_drop + (size_t)t * B * A : nullptr; ca.drop_scale = p->att_drop_scale;
         ca.gates = p->att_gates_all + (size_t)t * B * 4 * A; ca.c_new = p->att_c_all + (size_t)t * B * A;
         ca.c_prev = t > 0 ? p->att_c_all + (size_t)(t - 1) * B * A : nullptr;

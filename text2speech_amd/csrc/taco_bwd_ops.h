@@ -16,6 +16,7 @@ struct LstmBwdArgs {
     float* dc_carry;             // [B][H] in/out
     float* dgates;               // [B][4H] out
     int B, H;
+    const float* wq; const float* dq; int q_dim;   // optional: dh += wq^T dq  (wq [q_dim][H], dq [B][q_dim])
 };
 
 struct AttBwdArgs {

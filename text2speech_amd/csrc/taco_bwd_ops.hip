@@ -67,6 +67,17 @@ __global__ void lstm_cell_bwd_kernel(const LstmBwdArgs a) {
     const int b = blockIdx.y;
     if (u >= a.H) return;
     float dh = sum3(a.dh1, a.s1, a.dh2, a.s2, a.dh3, a.s3, b, u);
+    if (a.wq) {                  // + W_q^T d_q: the query Linear hangs off this cell's output (tacotron.py:137)
+        float e0 = 0.f, e1 = 0.f;
+        const float* dq = a.dq + (size_t)b * a.q_dim;
+        int k = 0;
+        for (; k + 2 <= a.q_dim; k += 2) {
+            e0 += dq[k] * a.wq[(size_t)k * a.H + u];
+            e1 += dq[k + 1] * a.wq[(size_t)(k + 1) * a.H + u];
+        }
+        if (k < a.q_dim) e0 += dq[k] * a.wq[(size_t)k * a.H + u];
+        dh += e0 + e1;
+    }
     const size_t idx = (size_t)b * a.H + u;
     if (a.drop_mask) dh = a.drop_mask[idx] ? dh * a.drop_scale : 0.f;
     const float* g4 = a.gates + (size_t)b * 4 * a.H + u;
@@ -103,7 +114,7 @@ hipError_t t2s_launch_relu_drop_bwd(const float* dy, const float* y, float scale
 // Three launches, each over (T_in / 32 chunks) x batch workgroups so the step fills the chip at batch 32:
 //   A  att_bwd_dw      d_w[t] = mem[t] . d_ctx + carries ; d_mem[t] += w[t] d_ctx
 //   B  att_bwd_energy  softmax backward (every workgroup re-reduces sum w d_w over the whole row: T floats), energies
-//                      backward for its 32 positions: d_pmem +=, partial d_q / dv / dD, d_f[t][:] = D^T d_pre[t]
+//                      backward for its 32 positions: d_pmem +=, partial d_q / dv / dD^T ([f][a] per slot), d_f[t][:] = D^T d_pre[t]
 //   C  att_bwd_conv    location-conv backward from d_f (with a halo of kernel/2 positions): the carries for step t-1 and
 //                      the partial kernel gradient; chunk 0 also folds the partial queries into d_q.
 // Parameter-gradient partials live in one slot per (batch element, chunk) and are summed once after the last step.
@@ -153,47 +164,66 @@ __global__ __launch_bounds__(256) void att_bwd_dw_kernel(const AttBwdArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void att_bwd_energy_kernel(const AttBwdArgs a) {
+__global__ __launch_bounds__(512) void att_bwd_energy_kernel(const AttBwdArgs a) {
     __shared__ float s_cat[2][ATTB_CH + 64];
-    __shared__ float s_k[32 * 2 * 63];
+    __shared__ float s_k[32 * 128];           // location-conv kernel [F][2][KS] (<= 4032 floats), then D^T [f][a]
     __shared__ float s_f[ATTB_CH][33];
     __shared__ float s_d[128 * 32];           // D [a][f]
-    __shared__ float s_acc[32 * 128];         // dD^T [f][a], waves add in turn
+    __shared__ float s_dpre[ATTB_CH][129];    // d_pre [t][a]
     __shared__ float s_de[ATTB_CH];
-    __shared__ float s_dp[4][128];
-    __shared__ float s_vec[2][128];
-    __shared__ float s_red[4];
+    __shared__ float s_vec[8][2][128];        // per-wave dq, dv
+    __shared__ float s_red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * ATTB_CH;
     const int T = a.T, AD = a.att_dim, KS = a.loc_ks, F = a.loc_f, pad = KS >> 1;
     const int len = a.lengths ? a.lengths[b] : T;
     const size_t slot = (size_t)b * gridDim.x + chunk;
     // ---- loads ----
-    for (int i = tid; i < F * 2 * KS; i += 256) s_k[i] = a.w_loc_conv[i];
-    for (int i = tid; i < 2 * (ATTB_CH + KS - 1); i += 256) {
+    for (int i = tid; i < F * 2 * KS; i += 512) s_k[i] = a.w_loc_conv[i];
+    for (int i = tid; i < 2 * (ATTB_CH + KS - 1); i += 512) {
         const int c = i / (ATTB_CH + KS - 1), j = i - c * (ATTB_CH + KS - 1);
         const int t = t0 + j - pad;
         const float* src = c ? a.wc_prev : a.w_prev;
         s_cat[c][j] = (src && t >= 0 && t < T) ? src[(size_t)b * (c ? a.s_wcprev : a.s_wprev) + t] : 0.f;
     }
-    for (int i = tid; i < 128 * 32; i += 256) {
+    for (int i = tid; i < 128 * 32; i += 512) {
         const int ai = i >> 5, f = i & 31;
         s_d[i] = (f < F && ai < AD) ? a.w_loc_dense[ai * F + f] : 0.f;
     }
-    if (tid < 128) { s_vec[0][tid] = 0.f; s_vec[1][tid] = 0.f; }
+    // this thread's slice of the parameter-gradient slot, fetched early (it is read-modify-write at the very end):
+    // dD^T [f][a]: a = tid % 128, f = (tid / 128) * 8 + i
+    const int ga = tid & 127, gf0 = (tid >> 7) * 8;
+    float dD_old[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dD_old[i] = (ga < AD && gf0 + i < F) ? a.dD_part[slot * AD * F + (size_t)(gf0 + i) * AD + ga] : 0.f;
+    const float dv_old = tid < AD ? a.dv_part[slot * AD + tid] : 0.f;
+    // attention_dim on lanes (a0 = lane, a1 = lane + 64); a wave takes 4 positions
+    const float q0 = lane < AD ? a.q[(size_t)b * AD + lane] : 0.f, q1 = lane + 64 < AD ? a.q[(size_t)b * AD + lane + 64] : 0.f;
+    const float v0 = lane < AD ? a.w_v[lane] : 0.f, v1 = lane + 64 < AD ? a.w_v[lane + 64] : 0.f;
+    float pm0[4], pm1[4], dpm0[4], dpm1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = t0 + wave * 4 + r;
+        const size_t po = ((size_t)b * T + t) * AD;
+        const bool ok0 = t < T && lane < AD, ok1 = t < T && lane + 64 < AD;
+        pm0[r] = ok0 ? a.pmem[po + lane] : 0.f;
+        pm1[r] = ok1 ? a.pmem[po + lane + 64] : 0.f;
+        dpm0[r] = ok0 ? a.d_pmem[po + lane] : 0.f;
+        dpm1[r] = ok1 ? a.d_pmem[po + lane + 64] : 0.f;
+    }
     // softmax backward needs sum_t w[t] d_w[t] over the whole row
     float part = 0.f;
-    for (int t = tid; t < T; t += 256) part += a.w_cur[(size_t)b * a.s_wcur + t] * a.dw_buf[(size_t)b * T + t];
+    for (int t = tid; t < T; t += 512) part += a.w_cur[(size_t)b * a.s_wcur + t] * a.dw_buf[(size_t)b * T + t];
     part = attb_wave_sum(part);
     if (lane == 0) s_red[wave] = part;
     __syncthreads();
-    const float sdot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    const float sdot = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
     if (tid < ATTB_CH) {
         const int t = t0 + tid;
         s_de[tid] = (t < T && t < len) ? a.w_cur[(size_t)b * a.s_wcur + t] * (a.dw_buf[(size_t)b * T + t] - sdot) : 0.f;
     }
     // ---- location features of this chunk ----
-    for (int i = tid; i < ATTB_CH * F; i += 256) {
+    for (int i = tid; i < ATTB_CH * F; i += 512) {
         const int tq = i / F, f = i - tq * F;
         float acc = 0.f;
         for (int c = 0; c < 2; ++c)
@@ -201,83 +231,76 @@ __global__ __launch_bounds__(256) void att_bwd_energy_kernel(const AttBwdArgs a)
         s_f[tq][f] = acc;
     }
     __syncthreads();
-    // ---- energies backward: attention_dim on lanes (a0 = lane, a1 = lane + 64), a wave takes 8 positions ----
-    float d0[32], d1[32], dD0[32], dD1[32];
-#pragma unroll
-    for (int f = 0; f < 32; ++f) {
-        d0[f] = (lane < AD && f < F) ? a.w_loc_dense[lane * F + f] : 0.f;
-        d1[f] = (lane + 64 < AD && f < F) ? a.w_loc_dense[(lane + 64) * F + f] : 0.f;
-        dD0[f] = 0.f; dD1[f] = 0.f;
-    }
-    const float q0 = lane < AD ? a.q[(size_t)b * AD + lane] : 0.f, q1 = lane + 64 < AD ? a.q[(size_t)b * AD + lane + 64] : 0.f;
-    const float v0 = lane < AD ? a.w_v[lane] : 0.f, v1 = lane + 64 < AD ? a.w_v[lane + 64] : 0.f;
+    for (int i = tid; i < 32 * 128; i += 512) s_k[i] = s_d[(i & 127) * 32 + (i >> 7)];      // D^T [f][a]: a on lanes below
+    __syncthreads();
+    // ---- energies backward ----
     float dq0 = 0.f, dq1 = 0.f, dv0 = 0.f, dv1 = 0.f;
-    float pm0[8], pm1[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int t = t0 + wave * 8 + r;
-        const size_t po = ((size_t)b * T + t) * AD;
-        pm0[r] = (t < T && lane < AD) ? a.pmem[po + lane] : 0.f;
-        pm1[r] = (t < T && lane + 64 < AD) ? a.pmem[po + lane + 64] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int tq = wave * 8 + r, t = t0 + tq;
-        if (t >= T) break;                                   // wave-uniform
-        float p0 = q0 + pm0[r], p1 = q1 + pm1[r];
-#pragma unroll
-        for (int f = 0; f < 32; ++f) {
-            const float ff = s_f[tq][f];
-            p0 += d0[f] * ff;
-            p1 += d1[f] * ff;
-        }
-        const float th0 = tanhf(p0), th1 = tanhf(p1);
-        const float de = s_de[tq];
-        const float dp0 = lane < AD ? de * v0 * (1.f - th0 * th0) : 0.f;
-        const float dp1 = lane + 64 < AD ? de * v1 * (1.f - th1 * th1) : 0.f;
-        dq0 += dp0; dq1 += dp1;
-        dv0 += de * th0; dv1 += de * th1;
-        const size_t po = ((size_t)b * T + t) * AD;
-        if (lane < AD) a.d_pmem[po + lane] += dp0;
-        if (lane + 64 < AD) a.d_pmem[po + lane + 64] += dp1;
-#pragma unroll
-        for (int f = 0; f < 32; ++f) {
-            const float ff = s_f[tq][f];
-            dD0[f] += dp0 * ff;
-            dD1[f] += dp1 * ff;
-        }
-        s_dp[wave][lane] = dp0;
-        s_dp[wave][lane + 64] = dp1;
-        __builtin_amdgcn_wave_barrier();
-        // d_f[t][f] = sum_a D[a][f] d_pre[a]: f on lanes 0..31, the two half-waves take even / odd a (bank-disjoint)
-        {
-            const int f = lane & 31, half = lane >> 5;
-            float acc = 0.f;
+    for (int r = 0; r < 4; ++r) {
+        const int tq = wave * 4 + r, t = t0 + tq;
+        float dp0 = 0.f, dp1 = 0.f;
+        if (t < T) {                                          // wave-uniform
+            float p0 = q0 + pm0[r], p1 = q1 + pm1[r];
 #pragma unroll 8
-            for (int i = 0; i < 64; ++i) acc += s_d[(2 * i + half) * 32 + f] * s_dp[wave][2 * i + half];
-            acc += __shfl_xor(acc, 32, 64);
-            if (lane < 32) a.df_buf[((size_t)b * T + t) * 32 + lane] = acc;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    // deterministic cross-wave sums: waves add in turn
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-            s_vec[0][lane] += dq0; s_vec[0][lane + 64] += dq1;
-            s_vec[1][lane] += dv0; s_vec[1][lane + 64] += dv1;
-#pragma unroll
             for (int f = 0; f < 32; ++f) {
-                if (w == 0) { s_acc[f * 128 + lane] = dD0[f]; s_acc[f * 128 + 64 + lane] = dD1[f]; }
-                else { s_acc[f * 128 + lane] += dD0[f]; s_acc[f * 128 + 64 + lane] += dD1[f]; }
+                const float ff = s_f[tq][f];
+                p0 += s_k[f * 128 + lane] * ff;
+                p1 += s_k[f * 128 + 64 + lane] * ff;
             }
+            const float th0 = tanhf(p0), th1 = tanhf(p1);
+            const float de = s_de[tq];
+            dp0 = lane < AD ? de * v0 * (1.f - th0 * th0) : 0.f;
+            dp1 = lane + 64 < AD ? de * v1 * (1.f - th1 * th1) : 0.f;
+            dq0 += dp0; dq1 += dp1;
+            dv0 += de * th0; dv1 += de * th1;
+            const size_t po = ((size_t)b * T + t) * AD;
+            if (lane < AD) a.d_pmem[po + lane] = dpm0[r] + dp0;
+            if (lane + 64 < AD) a.d_pmem[po + lane + 64] = dpm1[r] + dp1;
         }
-        __syncthreads();
+        s_dpre[tq][lane] = dp0;
+        s_dpre[tq][lane + 64] = dp1;
+        __builtin_amdgcn_sched_barrier(0);                   // keep the four positions' LDS reads from being hoisted together
+    }
+    s_vec[wave][0][lane] = dq0; s_vec[wave][0][lane + 64] = dq1;
+    s_vec[wave][1][lane] = dv0; s_vec[wave][1][lane + 64] = dv1;
+    __syncthreads();
+    // ---- dD^T[f][a] += sum_t f[t][f] d_pre[t][a]   (thread: one a, eight f) ----
+    {
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll 4
+        for (int tq = 0; tq < ATTB_CH; ++tq) {
+            const float dp = s_dpre[tq][ga];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += dp * s_f[tq][gf0 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (ga < AD && gf0 + i < F) a.dD_part[slot * AD * F + (size_t)(gf0 + i) * AD + ga] = dD_old[i] + acc[i];
+    }
+    // ---- d_f[t][f] = sum_a D[a][f] d_pre[t][a]   (thread: one t, f and f + 16) ----
+    {
+        const int tq = tid >> 4, f = tid & 15;
+        float e0 = 0.f, e1 = 0.f;
+#pragma unroll 8
+        for (int ai = 0; ai < 128; ++ai) {
+            const float dp = s_dpre[tq][ai];
+            e0 += s_d[ai * 32 + f] * dp;
+            e1 += s_d[ai * 32 + 16 + f] * dp;
+        }
+        if (t0 + tq < T) {
+            a.df_buf[((size_t)b * T + t0 + tq) * 32 + f] = e0;
+            a.df_buf[((size_t)b * T + t0 + tq) * 32 + 16 + f] = e1;
+        }
     }
     if (tid < AD) {
-        a.dq_part[slot * AD + tid] = s_vec[0][tid];
-        a.dv_part[slot * AD + tid] += s_vec[1][tid];
+        float sq = 0.f, sv = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { sq += s_vec[w][0][tid]; sv += s_vec[w][1][tid]; }
+        a.dq_part[slot * AD + tid] = sq;
+        a.dv_part[slot * AD + tid] = dv_old + sv;
     }
-    for (int i = tid; i < AD * F; i += 256) a.dD_part[slot * AD * F + i] += s_acc[(i % F) * 128 + (i / F)];
 }
 
 __global__ __launch_bounds__(256) void att_bwd_conv_kernel(const AttBwdArgs a) {
@@ -319,10 +342,11 @@ __global__ __launch_bounds__(256) void att_bwd_conv_kernel(const AttBwdArgs a) {
     // kernel gradient partial: dK[f][c][j] += sum_{t in chunk} d_f[t][f] cat[c][t + j - pad]
     for (int i = tid; i < F * 2 * KS; i += 256) {
         const int f = i / (2 * KS), r = i - f * 2 * KS, c = r / KS, j = r - c * KS;
+        const float old = a.dK_part[slot * F * 2 * KS + i];
         float acc = 0.f;
 #pragma unroll 8
         for (int tl = 0; tl < ATTB_CH; ++tl) acc += s_df[tl + pad][f] * s_cat[c][tl + j];
-        a.dK_part[slot * F * 2 * KS + i] += acc;
+        a.dK_part[slot * F * 2 * KS + i] = old + acc;
     }
     if (chunk == 0 && tid < AD) {
         float sum = 0.f;
@@ -337,7 +361,7 @@ hipError_t t2s_launch_att_bwd(const AttBwdArgs& a, hipStream_t stream) {
         return hipErrorInvalidValue;
     const dim3 grid((a.T + ATTB_CH - 1) / ATTB_CH, a.B);
     hipLaunchKernelGGL(att_bwd_dw_kernel, grid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(att_bwd_energy_kernel, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(att_bwd_energy_kernel, grid, dim3(512), 0, stream, a);
     hipLaunchKernelGGL(att_bwd_conv_kernel, grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }

@@ -272,7 +272,17 @@ __global__ __launch_bounds__(256) void att_energy_kernel(const AttArgs a) {
     const float v0 = lane < AD ? a.w_v[lane] : 0.f;
     const float v1 = lane + 64 < AD ? a.w_v[lane + 64] : 0.f;
     const int len = a.lengths ? a.lengths[b] : a.T;
-    for (int tq = wave; tq < ATT_TQ; tq += 4) {
+    float pm0[ATT_TQ / 4], pm1[ATT_TQ / 4];              // processed-memory rows of this wave's steps, fetched up front
+#pragma unroll
+    for (int r = 0; r < ATT_TQ / 4; ++r) {
+        const int t = t0 + wave + 4 * r;
+        const float* pm = a.pmem + ((size_t)b * a.T + t) * AD;
+        pm0[r] = (t < a.T && lane < AD) ? pm[lane] : 0.f;
+        pm1[r] = (t < a.T && lane + 64 < AD) ? pm[lane + 64] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < ATT_TQ / 4; ++r) {
+        const int tq = wave + 4 * r;
         const int t = t0 + tq;
         if (t >= a.T) break;
         float p0 = q0, p1 = q1;
@@ -282,19 +292,21 @@ __global__ __launch_bounds__(256) void att_energy_kernel(const AttArgs a) {
             p0 += d0[f] * ff;
             p1 += d1[f] * ff;
         }
-        const float* pm = a.pmem + ((size_t)b * a.T + t) * AD;
         float e = 0.f;
-        if (lane < AD) e += v0 * tanhf(p0 + pm[lane]);
-        if (lane + 64 < AD) e += v1 * tanhf(p1 + pm[lane + 64]);
+        if (lane < AD) e += v0 * tanhf(p0 + pm0[r]);
+        if (lane + 64 < AD) e += v1 * tanhf(p1 + pm1[r]);
         e = wave_sum(e);
         if (lane == 0) a.energies[(size_t)b * a.T + t] = t < len ? e : -INFINITY;
     }
 }
 
-// softmax over T_in, context = weights . memory, cumulative weights (reference tacotron.py:159-164,379)
+// softmax over T_in, context = weights . memory, cumulative weights (reference tacotron.py:159-164,379).
+// Workgroup = (batch element, 64 context channels): the softmax over the T energies is recomputed by each of the
+// enc_dim/64 workgroups of an element (T floats - cheaper than a second launch), chunk 0 publishes the weights.
 __global__ __launch_bounds__(256) void att_softmax_ctx_kernel(const AttArgs a) {
     extern __shared__ float s_w[];                       // [T]
     __shared__ float red[4];
+    __shared__ float s_part[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int T = a.T;
@@ -323,23 +335,30 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_kernel(const AttArgs a) {
     for (int t = tid; t < T; t += 256) {
         const float w = s_w[t] * inv;
         s_w[t] = w;
-        a.w_prev[(size_t)b * T + t] = w;
-        const float wc = a.w_cum[(size_t)b * T + t] + w;
-        a.w_cum[(size_t)b * T + t] = wc;
-        if (a.wcum_save) a.wcum_save[(size_t)b * T + t] = wc;
-        if (a.align_out) a.align_out[(size_t)b * a.s_align_b + t] = w;
+        if (blockIdx.y == 0) {
+            a.w_prev[(size_t)b * T + t] = w;
+            const float wc = a.w_cum[(size_t)b * T + t] + w;
+            a.w_cum[(size_t)b * T + t] = wc;
+            if (a.wcum_save) a.wcum_save[(size_t)b * T + t] = wc;
+            if (a.align_out) a.align_out[(size_t)b * a.s_align_b + t] = w;
+        }
     }
     __syncthreads();
-    for (int c = tid; c < a.enc_dim; c += 256) {
+    const int c = blockIdx.y * 64 + lane;
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < a.enc_dim) {
         const float* mem = a.memory + (size_t)b * T * a.enc_dim + c;
-        float a4[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int t = 0;
-        for (; t + 8 <= T; t += 8) {
+        int t = wave;
+        for (; t + 12 < T; t += 16) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a4[u] += s_w[t + u] * mem[(size_t)(t + u) * a.enc_dim];
+            for (int u = 0; u < 4; ++u) a4[u] += s_w[t + 4 * u] * mem[(size_t)(t + 4 * u) * a.enc_dim];
         }
-        for (; t < T; ++t) a4[0] += s_w[t] * mem[(size_t)t * a.enc_dim];
-        const float acc = ((a4[0] + a4[1]) + (a4[2] + a4[3])) + ((a4[4] + a4[5]) + (a4[6] + a4[7]));
+        for (; t < T; t += 4) a4[0] += s_w[t] * mem[(size_t)t * a.enc_dim];
+    }
+    s_part[wave][lane] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    __syncthreads();
+    if (wave == 0 && c < a.enc_dim) {
+        const float acc = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);
         a.ctx[(size_t)b * a.enc_dim + c] = acc;
         if (a.ctx_copy) a.ctx_copy[(size_t)b * a.s_ctx_copy + c] = acc;
     }
@@ -351,7 +370,7 @@ hipError_t t2s_launch_att_energy(const AttArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 hipError_t t2s_launch_att_softmax_ctx(const AttArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(att_softmax_ctx_kernel, dim3(a.B), dim3(256), (size_t)a.T * sizeof(float), stream, a);
+    hipLaunchKernelGGL(att_softmax_ctx_kernel, dim3(a.B, (a.enc_dim + 63) / 64), dim3(256), (size_t)a.T * sizeof(float), stream, a);
     return hipGetLastError();
 }
 

@@ -37,11 +37,11 @@ class _Bptt(ctypes.Structure):
     """Mirror of t2s_taco_bptt."""
     _fields_ = ([(n, i32) for n in ("B", "T_in", "T_out", "T_cap", "prenet_dim", "enc_dim", "att_rnn_dim", "dec_rnn_dim",
                                     "att_dim", "loc_filters", "loc_kernel")] +
-                [(n, vp) for n in ("W_dT", "W_aT", "W_qT", "w_loc_conv", "w_loc_dense", "w_v", "dec_gates_all", "dec_c_all",
+                [(n, vp) for n in ("W_dT", "W_aT", "w_query", "w_loc_conv", "w_loc_dense", "w_v", "dec_gates_all", "dec_c_all",
                                    "att_gates_all", "att_c_all", "q_all", "wcum_all", "align", "pmem", "memory", "lengths",
                                    "att_drop", "dec_drop")] +
                 [("att_drop_scale", f32c), ("dec_drop_scale", f32c)] +
-                [(n, vp) for n in ("d_hc", "out_d", "out_a", "dg_d", "dg_a", "dq_all", "dah_q", "dc_d", "dc_a", "dw_c",
+                [(n, vp) for n in ("d_hc", "out_d", "out_a", "dg_d", "dg_a", "dq_all", "dc_d", "dc_a", "dw_c",
                                    "dwc_c", "d_pmem", "d_memory", "dD_part", "dK_part", "dv_part", "dw_buf", "df_buf",
                                    "dq_part")])
 
@@ -236,13 +236,11 @@ class _Bwd:
         # ---- decoder BPTT ----
         W_dT = self.transpose(torch.cat([P["dec_w_ih"], P["dec_w_hh"]], 1).contiguous())      # [A+E+D][4D]
         W_aT = self.transpose(torch.cat([P["att_w_ih"], P["att_w_hh"]], 1).contiguous())      # [Pd+E+A][4A]
-        W_qT = self.transpose(P["w_query"])                                                    # [A][ad]
         KD, KA = A + E + D, Pd + E + A
         out_d = self.zeros(T, B, KD)
         out_a = self.zeros(T, B, KA)
         dg_d, dg_a = self.zeros(T, B, 4 * D), self.zeros(T, B, 4 * A)
         dq_all = self.zeros(T, B, ad)
-        dah_q = self.new(B, A)
         dc_d, dc_a = self.zeros(B, D), self.zeros(B, A)
         dw_c, dwc_c = self.zeros(B, T_in), self.zeros(B, T_in)
         d_pmem, d_memory = self.zeros(B, T_in, ad), self.zeros(B, T_in, E)
@@ -254,14 +252,14 @@ class _Bwd:
         att_drop, dec_drop = S.get("att_drop"), S.get("dec_drop")
         w_v = P["w_v"].reshape(-1).contiguous()
         bp = _Bptt(B=B, T_in=T_in, T_out=T, T_cap=T_cap, prenet_dim=Pd, enc_dim=E, att_rnn_dim=A, dec_rnn_dim=D, att_dim=ad,
-                   loc_filters=F_, loc_kernel=KS, W_dT=_p(W_dT), W_aT=_p(W_aT), W_qT=_p(W_qT), w_loc_conv=_p(P["w_loc_conv"]),
+                   loc_filters=F_, loc_kernel=KS, W_dT=_p(W_dT), W_aT=_p(W_aT), w_query=_p(P["w_query"]), w_loc_conv=_p(P["w_loc_conv"]),
                    w_loc_dense=_p(P["w_loc_dense"]), w_v=_p(w_v), dec_gates_all=_p(S["dec_gates_all"]),
                    dec_c_all=_p(S["dec_c_all"]), att_gates_all=_p(S["att_gates_all"]), att_c_all=_p(S["att_c_all"]),
                    q_all=_p(S["q_all"]), wcum_all=_p(S["wcum_all"]), align=_p(align), pmem=_p(S["pmem"]), memory=_p(memory),
                    lengths=_p(sv["len32"]), att_drop=_p(att_drop), dec_drop=_p(dec_drop),
                    att_drop_scale=1.0 / (1.0 - dec.p_attention_dropout), dec_drop_scale=1.0 / (1.0 - dec.p_decoder_dropout),
                    d_hc=_p(d_hc), out_d=_p(out_d), out_a=_p(out_a), dg_d=_p(dg_d), dg_a=_p(dg_a), dq_all=_p(dq_all),
-                   dah_q=_p(dah_q), dc_d=_p(dc_d), dc_a=_p(dc_a), dw_c=_p(dw_c), dwc_c=_p(dwc_c), d_pmem=_p(d_pmem),
+                   dc_d=_p(dc_d), dc_a=_p(dc_a), dw_c=_p(dw_c), dwc_c=_p(dwc_c), d_pmem=_p(d_pmem),
                    d_memory=_p(d_memory), dD_part=_p(dD_p), dK_part=_p(dK_p), dv_part=_p(dv_p), dw_buf=_p(dw_buf),
                    df_buf=_p(df_buf), dq_part=_p(dq_part))
         _lib.call("t2s_taco_bptt_steps", ctypes.byref(bp), T, 0, st)        # the whole reversed loop, enqueued from C++
@@ -296,6 +294,10 @@ class _Bwd:
                                (dK_p, loc.location_conv.conv.weight, F_ * 2 * KS), (dv_p, al.v.linear_layer.weight, ad)):
             g = self.new(*param.shape)
             _lib.call("t2s_sum_axis0", _p(part), B * nch, n, _p(g), st)
+            if part is dD_p:                        # the slots hold dD^T [F][att_dim]
+                gt = self.new(ad, F_)
+                _lib.call("t2s_transpose", _p(g), _p(gt), F_, ad, st)
+                g = gt
             self.grads[id(param)] = g
         # prenet (hoisted): pre_all = drop(relu(W2 drop(relu(W1 frames))))
         d_pre = out_a[:, :, :Pd].contiguous().view(items, Pd)
