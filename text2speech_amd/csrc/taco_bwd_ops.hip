@@ -71,11 +71,14 @@ __global__ void lstm_cell_bwd_kernel(const LstmBwdArgs a) {
         float e0 = 0.f, e1 = 0.f;
         const float* dq = a.dq + (size_t)b * a.q_dim;
         int k = 0;
-        for (; k + 2 <= a.q_dim; k += 2) {
-            e0 += dq[k] * a.wq[(size_t)k * a.H + u];
-            e1 += dq[k + 1] * a.wq[(size_t)(k + 1) * a.H + u];
+        for (; k + 16 <= a.q_dim; k += 16) {            // sixteen independent loads in flight, then the FMAs
+            float w[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) w[i] = a.wq[(size_t)(k + i) * a.H + u];
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) { e0 += dq[k + i] * w[i]; e1 += dq[k + i + 1] * w[i + 1]; }
         }
-        if (k < a.q_dim) e0 += dq[k] * a.wq[(size_t)k * a.H + u];
+        for (; k < a.q_dim; ++k) e0 += dq[k] * a.wq[(size_t)k * a.H + u];
         dh += e0 + e1;
     }
     const size_t idx = (size_t)b * a.H + u;
@@ -227,6 +230,7 @@ __global__ __launch_bounds__(512) void att_bwd_energy_kernel(const AttBwdArgs a)
         const int tq = i / F, f = i - tq * F;
         float acc = 0.f;
         for (int c = 0; c < 2; ++c)
+#pragma unroll 8
             for (int j = 0; j < KS; ++j) acc += s_k[(f * 2 + c) * KS + j] * s_cat[c][tq + j];
         s_f[tq][f] = acc;
     }
@@ -330,6 +334,7 @@ __global__ __launch_bounds__(256) void att_bwd_conv_kernel(const AttBwdArgs a) {
         const int c = o >> 5, tl = o & 31;
         float acc = 0.f;
         for (int f = fg * 8; f < fg * 8 + 8 && f < F; ++f)
+#pragma unroll 8
             for (int j = 0; j < KS; ++j) acc += s_k[(f * 2 + c) * KS + j] * s_df[tl - j + 2 * pad][f];   // row (tp - j + pad) - (t0 - pad)
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);

@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256) void att_energy_kernel(const AttArgs a) {
         const int tq = i / F, f = i - tq * F;
         float acc = 0.f;
         for (int c = 0; c < 2; ++c)
+#pragma unroll 8
             for (int j = 0; j < KS; ++j) acc += s_k[(f * 2 + c) * KS + j] * s_cat[c][tq + j];
         s_f[tq][f] = acc;
     }
@@ -264,8 +265,15 @@ __global__ __launch_bounds__(256) void att_energy_kernel(const AttArgs a) {
     float d0[32], d1[32];
 #pragma unroll
     for (int f = 0; f < 32; ++f) {
-        d0[f] = (lane < AD && f < F) ? a.w_loc_dense[lane * F + f] : 0.f;
-        d1[f] = (lane + 64 < AD && f < F) ? a.w_loc_dense[(lane + 64) * F + f] : 0.f;
+        // the transposed copy [F][att_dim] reads coalesced (lanes along att_dim); the row-major weight costs one
+        // cache line per lane per load
+        if (a.w_loc_denseT) {
+            d0[f] = (lane < AD && f < F) ? a.w_loc_denseT[f * AD + lane] : 0.f;
+            d1[f] = (lane + 64 < AD && f < F) ? a.w_loc_denseT[f * AD + lane + 64] : 0.f;
+        } else {
+            d0[f] = (lane < AD && f < F) ? a.w_loc_dense[lane * F + f] : 0.f;
+            d1[f] = (lane + 64 < AD && f < F) ? a.w_loc_dense[(lane + 64) * F + f] : 0.f;
+        }
     }
     const float q0 = lane < AD ? a.q[(size_t)b * AD + lane] : 0.f;
     const float q1 = lane + 64 < AD ? a.q[(size_t)b * AD + lane + 64] : 0.f;
@@ -464,6 +472,7 @@ __global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
         const int t = i / F, f = i - t * F;
         float acc = 0.f;
         for (int c = 0; c < 2; ++c)
+#pragma unroll 8
             for (int j = 0; j < KS; ++j) acc += s_k[(f * 2 + c) * KS + j] * s_cat[c][t + j];
         s_f[t * 33 + f] = acc;
     }
