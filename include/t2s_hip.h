@@ -388,6 +388,25 @@ int t2s_add3(const float* a, const float* b, const float* c, size_t n, float* ou
 int t2s_planes_to_f32(const void* X_hi, const void* X_lo, int B, int C, int L, int Lp, int halo, float* out,
                       int accumulate, void* stream);
 
+/* ---- audio front-end / back-end ------------------------------------------------------------------
+ * STFT.transform (utils/stft.py:72-99): audio [B][T] -> frames F = T/hop + 1, bins c = n_fft/2 + 1.
+ *   fwd_basis [2c][n_fft] (windowed Fourier basis, real rows then imaginary rows); scratch xp [B][ldp] (ldp >= T + n_fft,
+ *   ldp % 4 == 0) and ft [B][F][2c]; outputs (each optional) mag / phase [B][c][F] and magT [B*F][ld_mt] (zero padded rows:
+ *   the operand of t2s_mel_from_mag, ld_mt % 16 == 0). */
+int t2s_stft_transform(const float* audio, int B, int T, const float* fwd_basis, int n_fft, int hop, float* xp, long ldp,
+                       float* ft, float* mag, float* phase, float* magT, long ld_mt, void* stream);
+/* TacotronSTFT.mel_spectrogram after the STFT (utils/layers.py:76-78): mel [B][n_mel][F] = log(max(mel_basis . mag, clip));
+ * mel_basis_p [n_mel][ld_mt] zero padded; clip <= 0 skips the log. */
+int t2s_mel_from_mag(const float* magT, long ld_mt, int B, int F, const float* mel_basis_p, int n_mel, float clip, float* mel,
+                     void* stream);
+/* STFT.inverse (utils/stft.py:101-129) with the Denoiser's spectral subtraction fused when bias != NULL
+ * (waveglow/denoiser.py:36-38: m = max(mag - strength * bias[bin], 0)).  inv_basis_t [n_fft][ld_rc] = inverse basis transposed,
+ * zero padded to ld_rc >= 2c (% 16 == 0); win_sq [n_fft] squared window or NULL; scratch rc [B*F][ld_rc], frames [B][F][n_fft];
+ * out [B][hop * (F - 1)]. */
+int t2s_stft_inverse(const float* mag, const float* phase, int B, int F, int n_fft, int hop, const float* inv_basis_t, long ld_rc,
+                     const float* bias, float strength, const float* win_sq, float tiny, float* rc, float* frames, float* out,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,75 @@
+"""CPU: the audio oracle (oracle/audio_oracle.py) against outputs of the reference's own STFT class
+(tests/golden/audio_stft.npz, made by tools/gen_golden_audio.py), plus self-consistency of the pieces that have no
+reference-side pin (mel filterbank: librosa is absent and unpinned upstream)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import audio_oracle as A
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).double().flatten()
+    b = torch.as_tensor(b).double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_stft_transform_and_inverse_vs_reference(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "audio_stft.npz"))
+    n_fft, hop, B, T = [int(v) for v in g[tag + "_cfg"]]
+    fwd, inv = A.stft_basis(n_fft, hop, n_fft)
+    audio = torch.from_numpy(g[tag + "_audio"])
+    mag, ph = A.stft_transform(audio, fwd, n_fft, hop)
+    assert mag.shape == g[tag + "_mag"].shape
+    assert _rel(mag, g[tag + "_mag"]) < 1e-6
+    # phase compared through cos / sin (atan2 is discontinuous at +-pi), weighted by magnitude
+    w = torch.from_numpy(g[tag + "_mag"])
+    assert _rel(torch.cos(ph) * w, torch.from_numpy(g[tag + "_cos"].astype(np.float32)) * w) < 2e-3
+    assert _rel(torch.sin(ph) * w, torch.from_numpy(g[tag + "_sin"].astype(np.float32)) * w) < 2e-3
+    rec = A.stft_inverse(mag, ph, inv, n_fft, hop, n_fft)
+    assert rec.shape == g[tag + "_rec"].shape
+    assert _rel(rec, g[tag + "_rec"]) < 1e-5
+    if tag == "c":
+        assert _rel(fwd, g["c_fwd_basis"]) < 1e-7
+        assert _rel(inv, g["c_inv_basis"]) < 1e-6
+
+
+def test_reconstruction_property():
+    """transform -> inverse returns the input away from the edges (the property the reference's STFT.forward relies on)."""
+    gen = torch.Generator().manual_seed(3)
+    audio = torch.rand(2, 8192, generator=gen) - 0.5
+    fwd, inv = A.stft_basis(1024, 256, 1024)
+    mag, ph = A.stft_transform(audio, fwd)
+    rec = A.stft_inverse(mag, ph, inv)[:, 0]
+    assert rec.shape[1] == 8192
+    assert _rel(rec[:, 1024:-1024], audio[:, 1024:-1024]) < 1e-4
+
+
+def test_mel_filterbank_shape_and_normalisation():
+    w = A.mel_filterbank(22050, 1024, 80, 0.0, 8000.0)
+    assert w.shape == (80, 513) and w.dtype == np.float32
+    assert (w >= 0).all()
+    # Slaney area normalisation: every triangle integrates to ~1 Hz^-1 * bin width
+    freqs = np.linspace(0, 22050 / 2, 513)
+    area = (w * (freqs[1] - freqs[0])).sum(1)
+    assert np.allclose(area, 1.0, atol=0.08)
+    assert w[:, freqs > 8000.0 + 22].sum() == 0       # nothing above fmax
+    peaks = freqs[w.argmax(1)]
+    assert (np.diff(peaks) > 0).all()
+
+
+def test_mel_spectrogram_and_denoise_shapes():
+    gen = torch.Generator().manual_seed(4)
+    audio = torch.rand(2, 4096, generator=gen) * 1.8 - 0.9
+    fwd, inv = A.stft_basis(1024, 256, 1024)
+    mel = A.mel_spectrogram(audio, fwd, A.mel_filterbank(22050, 1024))
+    assert mel.shape == (2, 80, 17) and float(mel.min()) >= np.log(1e-5) - 1e-6
+    bias = torch.rand(1, 513, 1, generator=gen) * 0.01
+    out = A.denoise(audio, bias, fwd, inv, strength=0.1)
+    assert out.shape == (2, 1, 4096)
+    # zero strength = plain reconstruction
+    out0 = A.denoise(audio, bias, fwd, inv, strength=0.0)
+    assert _rel(out0[:, 0, 1024:-1024], audio[:, 1024:-1024]) < 1e-4
