@@ -57,9 +57,10 @@ int t2s_pack_conv_weight(const float* v, const float* g, int g_is_scale, const f
                          float* bias_out, int bias_accumulate, void* stream);
 
 /* Table-driven form of t2s_pack_conv_weight: ONE launch packs every listed weight (the per-forward
- * weight-norm recompute of all 288 WN convolutions).  `jobs` is a DEVICE array of t2s_pack_job; job i owns
- * blocks [row_start, row_start + O), row_start being the running sum of O.  bias_out[p] = bias_in[o] +
- * bias_in2[o] (either may be NULL); leave bias_out NULL on a job that shares its rows' bias with another. */
+ * weight-norm recompute of all 288 WN convolutions).  `jobs` is a DEVICE array of t2s_pack_job; a workgroup packs 16
+ * consecutive output rows, job i owns workgroups [row_start, row_start + ceil(O/16)), row_start being the running sum of
+ * ceil(O/16) and total_groups the grand total.  bias_out[p] = bias_in[o] + bias_in2[o] (either may be NULL); leave bias_out
+ * NULL on a job that shares its rows' bias with another. */
 typedef struct t2s_pack_job {
     const float *v, *g, *bias_in, *bias_in2;
     void *A_hi, *A_lo;
@@ -68,7 +69,7 @@ typedef struct t2s_pack_job {
     long O, Cin, Kt, perm, C_gate, Mpad, koff, Cin_pad, row_off, g_is_scale;
     float* scale_out; /* optional [O]: per-row factor g/|v| that was applied, kept for the backward pass */
 } t2s_pack_job;
-int t2s_pack_conv_weight_table(const t2s_pack_job* jobs, int n_jobs, long total_rows, void* stream);
+int t2s_pack_conv_weight_table(const t2s_pack_job* jobs, int n_jobs, long total_groups, void* stream);
 
 /* w[O][K] = v * g / ||v||  for a small weight-normed 1x1 conv (WN.start; reference glow.py:122-124) */
 int t2s_weightnorm_small(const float* v, const float* g, int O, int K, float* w, void* stream);

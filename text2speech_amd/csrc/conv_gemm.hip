@@ -54,8 +54,13 @@ static __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 }
 
 // MT = rows of the M (output-channel) tile: 256, or 128 for short GEMMs that would otherwise leave CUs idle.
-template <int EPI, int MT>
-__global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a) {
+// WN = waves along N (time): 4 -> 8 waves of 128 x 64 (two per SIMD); 2 -> 4 waves of 128 x 128 (one per SIMD, 256
+// accumulator registers): a third fewer LDS fragment bytes per MFMA, the resource this kernel runs out of first.
+template <int EPI, int MT, int WN>
+__global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs a) {
+    constexpr int NTH = 128 * WN;                    // threads per workgroup
+    constexpr int NWT = 16 / WN;                     // 16-column MFMA tiles per wave
+    constexpr int CALL_BYTES = NTH * 16;             // bytes one workgroup-wide global_load_lds moves
     constexpr int A_PLANE = MT * 64;                 // bytes of one A plane tile
     constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE_BYTES;
     constexpr int MW = MT / 32;                      // 16-row MFMA tiles per wave (waves are 2 (M) x 4 (N))
@@ -63,8 +68,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2;          // 0..1  : which 128-row half of the M tile
-    const int wc = wave & 3;           // 0..3  : which 64-column quarter of the N tile
+    const int wr = wave / WN;          // 0..1  : which half of the M tile
+    const int wc = wave % WN;          // which (NWT * 16)-column slice of the N tile
 
     // ---- XCD-aware, bijective block remap (guide section 5, T1) ----
     const int nwg = gridDim.x;
@@ -85,8 +90,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     }
 
     // ---- per-thread DMA source offsets (bytes) ----
-    // LDS linear slot p = j*512 + tid (16 B each): row = p>>2 = j*128 + (tid>>2), slot q = tid&3.
-    // The slot holds logical k-chunk q ^ s[(row>>2)&3]; (row>>2)&3 == (tid>>4)&3 for both j.
+    // LDS linear slot p = j*NTH + tid (16 B each): row = p>>2 = j*NTH/4 + (tid>>2), slot q = tid&3.
+    // The slot holds logical k-chunk q ^ s[(row>>2)&3]; (row>>2)&3 == (tid>>4)&3 for every j (NTH/4 is a multiple of 16).
     const int thr_off = (tid >> 2) * 64 + (((tid & 3) ^ swz4((tid >> 4) & 3)) * 16);
     const char* A_hi = (const char*)a.A_hi + (size_t)b * a.a_bstride * 2 + (size_t)mt * MT * 64 + thr_off;
     const char* A_lo = (const char*)a.A_lo + (size_t)b * a.a_bstride * 2 + (size_t)mt * MT * 64 + thr_off;
@@ -116,26 +121,28 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
             bh = S_hi + off;
             bl = S_lo + off;
         }
-        glds16(ah, dst);
-        if (MT == 256) glds16(ah + 8192, dst + 8192);
-        glds16(al, dst + A_PLANE);
-        if (MT == 256) glds16(al + 8192, dst + A_PLANE + 8192);
-        glds16(bh, dst + 2 * A_PLANE);
-        glds16(bh + 8192, dst + 2 * A_PLANE + 8192);
-        glds16(bl, dst + 2 * A_PLANE + B_PLANE_BYTES);
-        glds16(bl + 8192, dst + 2 * A_PLANE + B_PLANE_BYTES + 8192);
+#pragma unroll
+        for (int j = 0; j < A_PLANE / CALL_BYTES; ++j) {
+            glds16(ah + j * CALL_BYTES, dst + j * CALL_BYTES);
+            glds16(al + j * CALL_BYTES, dst + A_PLANE + j * CALL_BYTES);
+        }
+#pragma unroll
+        for (int j = 0; j < B_PLANE_BYTES / CALL_BYTES; ++j) {
+            glds16(bh + j * CALL_BYTES, dst + 2 * A_PLANE + j * CALL_BYTES);
+            glds16(bl + j * CALL_BYTES, dst + 2 * A_PLANE + B_PLANE_BYTES + j * CALL_BYTES);
+        }
     };
 
     // ---- per-lane fragment read offset: row = lane&15, logical k-chunk = lane>>4 ----
     const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ swz4((lane >> 2) & 3)) * 16);
     const int a_frag = wr * (MT / 2) * 64 + frag_off;
-    const int b_frag = 2 * A_PLANE + wc * 64 * 64 + frag_off;
+    const int b_frag = 2 * A_PLANE + wc * (NWT * 16) * 64 + frag_off;
 
-    f32x4 acc[MW][4];
+    f32x4 acc[MW][NWT];
 #pragma unroll
     for (int m = 0; m < MW; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NWT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = nk_split;
     if (nk > 0) stage(0, 0);
@@ -149,11 +156,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
         // Fragment reads are ordered for the earliest possible first MFMA (it needs only a_lo(0) and b_hi(0)), and the
         // A fragments of m-tile m+1 are fetched while m's 12 MFMAs issue: the LDS-read burst that follows every
         // barrier overlaps matrix work instead of preceding it.
-        bf16x8 bh[4], bl[4];
+        bf16x8 bh[NWT], bl[NWT];
         bf16x8 ah = *(const bf16x8*)(sb + a_frag);
         bf16x8 al = *(const bf16x8*)(sb + a_frag + A_PLANE);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < NWT; ++n) {
             bh[n] = *(const bf16x8*)(sb + b_frag + n * 1024);
             bl[n] = *(const bf16x8*)(sb + b_frag + B_PLANE_BYTES + n * 1024);
         }
@@ -166,11 +173,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
             }
             if (!(T2S_ABLATE(a) & 2)) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
             } else {
                 asm volatile("" :: "v"(al), "v"(ah));
             }
@@ -190,12 +197,12 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
         // itself a small GEMM whose B operand is the gate output as it sits in the accumulator layout (col = time on
         // the lane, 4 consecutive channels per 16-lane group): two 16-channel tiles form one K = 32 step, with the
         // matching K permutation baked into fold_A by endfold_weights_kernel.  3 MFMAs per (pair, n), no shuffles.
-        f32x4 facc[4];
+        f32x4 facc[NWT];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) facc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NWT; ++n) facc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int pair = 0; pair < 2; ++pair) {
-            u16x4 hv[2][4], lv[2][4];
+            u16x4 hv[2][NWT], lv[2][NWT];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int mp = pair * 2 + half;
@@ -206,8 +213,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
                 const bool chv = ch < a.C;
                 const size_t obase = (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const int t = t0 + wc * 64 + n * 16 + tcol;
+                for (int n = 0; n < NWT; ++n) {
+                    const int t = t0 + wc * (NWT * 16) + n * 16 + tcol;
                     u16x4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
                     if (chv && t < a.L) {
                         u16x4 thi, tlo, ghi, glo;
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
                 const bf16x8 wh = *(const bf16x8*)fa;
                 const bf16x8 wl = *(const bf16x8*)(fa + 64 * 8);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
+                for (int n = 0; n < NWT; ++n) {
                     typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
                     const u16x8 bh8 = {hv[0][n][0], hv[0][n][1], hv[0][n][2], hv[0][n][3],
                                        hv[1][n][0], hv[1][n][1], hv[1][n][2], hv[1][n][3]};
@@ -262,8 +269,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
         if (a.fold_A && lane < 32) {     // D rows j = 4*(lane>>4) + reg < 8, col = time
             const int slot = mt * 2 + wr;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int t = t0 + wc * 64 + n * 16 + tcol;
+            for (int n = 0; n < NWT; ++n) {
+                const int t = t0 + wc * (NWT * 16) + n * 16 + tcol;
                 if (t >= a.L) continue;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -282,8 +289,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
                 u16* xhi = a.O_hi + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
                 u16* xlo = a.O_lo + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const int t = t0 + wc * 64 + n * 16 + tcol;
+                for (int n = 0; n < NWT; ++n) {
+                    const int t = t0 + wc * (NWT * 16) + n * 16 + tcol;
                     if (t >= a.L) continue;
                     u16x4 oh = {0, 0, 0, 0}, ol = {0, 0, 0, 0};
                     if (!a.res_init) {
@@ -308,8 +315,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
                 if (ch >= a.C) continue;
                 float* sk = a.skip + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const int t = t0 + wc * 64 + n * 16 + tcol;
+                for (int n = 0; n < NWT; ++n) {
+                    const int t = t0 + wc * (NWT * 16) + n * 16 + tcol;
                     if (t >= a.L) continue;
                     f32x4 v = acc[m][n] + bv;
                     if (!a.skip_init) v += *(const f32x4*)(sk + (size_t)t * 32);
@@ -330,8 +337,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
             const size_t o1 = (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
             const size_t o2 = (((size_t)b * a.oc + (ch2 >> 5)) * a.Lp + a.halo) * 32 + (ch2 & 31);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int t = t0 + wc * 64 + n * 16 + tcol;
+            for (int n = 0; n < NWT; ++n) {
+                const int t = t0 + wc * (NWT * 16) + n * 16 + tcol;
                 if (t >= a.L) continue;
                 const u16x4 th = *(const u16x4*)(a.T_hi + tgb + (size_t)t * 32);
                 const u16x4 tl = *(const u16x4*)(a.T_lo + tgb + (size_t)t * 32);
@@ -365,8 +372,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
             u16* ohi = a.O_hi ? a.O_hi + (((size_t)bs * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31) : nullptr;
             u16* olo = a.O_lo ? a.O_lo + (((size_t)bs * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31) : nullptr;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int t = t0 + wc * 64 + n * 16 + tcol;
+            for (int n = 0; n < NWT; ++n) {
+                const int t = t0 + wc * (NWT * 16) + n * 16 + tcol;
                 if (t >= a.L) continue;
                 u16x4 hi, lo;
 #pragma unroll
@@ -392,18 +399,18 @@ __global__ __launch_bounds__(512, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     }
 }
 
-template <int EPI, int MT>
+template <int EPI, int MT, int WN = 4>
 static hipError_t launch_one(const ConvGemmArgs& a, hipStream_t stream) {
     const int nwg = a.n_mtiles * a.n_ttiles * a.B;
     constexpr size_t lds = 2 * (2 * MT * 64 + 2 * B_PLANE_BYTES);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<EPI, MT>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<EPI, MT, WN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<EPI, MT>), dim3(nwg), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<EPI, MT, WN>), dim3(nwg), dim3(128 * WN), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -416,6 +423,8 @@ hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a_in, int epi, hipStream_t s
         if (epi == EPI_RESSKIP) return launch_one<EPI_RESSKIP, 128>(a, stream);
         return hipErrorInvalidValue;
     }
+    static const int wn2 = getenv("T2S_GEMM_WN2") ? atoi(getenv("T2S_GEMM_WN2")) : 0;
+    if (epi == EPI_GATE && wn2) return launch_one<EPI_GATE, 256, 2>(a, stream);
     if (epi == EPI_GATE) return launch_one<EPI_GATE, 256>(a, stream);
     if (epi == EPI_RESSKIP) return launch_one<EPI_RESSKIP, 256>(a, stream);
     if (epi == EPI_GATE_BWD) return launch_one<EPI_GATE_BWD, 256>(a, stream);

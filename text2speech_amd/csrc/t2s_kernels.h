@@ -74,7 +74,7 @@ hipError_t t2s_launch_pack(const PackArgs& a, hipStream_t stream);
 struct PackJob {               // mirrors t2s_pack_job in include/t2s_hip.h (all 8-byte fields)
     const float* v; const float* g; const float* bias_in; const float* bias_in2;
     u16* A_hi; u16* A_lo; float* bias_out;
-    long row_start;            // first block index of this job (prefix sum of O)
+    long row_start;            // first workgroup of this job (prefix sum of ceil(O/16): 16 rows per workgroup)
     long O, Cin, Kt, perm, C_gate, Mpad, koff, Cin_pad, row_off, g_is_scale;
     float* scale_out;          // optional [O]: the per-row factor applied (g/|v|), kept for the backward pass
 };

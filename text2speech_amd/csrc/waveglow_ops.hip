@@ -70,8 +70,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
              a.koff, a.Cin_pad, a.A_hi, a.A_lo, a.bias_in, nullptr, a.bias_out, a.bias_accumulate);
 }
 
-// One launch for the whole model: block -> (job, row) by binary search over the jobs' row_start prefix.
+// One launch for the whole model.  A workgroup packs 16 consecutive output rows of one job (block -> (job, group) by binary
+// search over the jobs' row_start prefix, which counts 16-row groups): the per-row kernel above is latency-bound (three
+// dependent round trips for 6 KB of work), here the same chain moves 16x the bytes and the 16 packed rows of a K-chunk are
+// one contiguous 1 KB store per plane (rows p..p+15 are adjacent for both permutations).
 __global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restrict__ jobs, int n_jobs) {
+    __shared__ float s_scale[16];
     const long blk = blockIdx.x;
     int lo = 0, hi = n_jobs - 1;
     while (lo < hi) {
@@ -79,13 +83,83 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restri
         if (jobs[mid].row_start <= blk) lo = mid; else hi = mid - 1;
     }
     const PackJob j = jobs[lo];
-    const int o = (int)(blk - j.row_start);
-    pack_row(j.v + (size_t)o * j.Cin * j.Kt, j.g, (int)j.g_is_scale, o, (int)j.Cin, (int)j.Kt, (int)j.perm, (int)j.C_gate,
-             (int)j.row_off, (int)j.Mpad, (int)j.koff, (int)j.Cin_pad, j.A_hi, j.A_lo, j.bias_in, j.bias_in2, j.bias_out, 0,
-             j.scale_out);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int O = (int)j.O, Cin = (int)j.Cin, Kt = (int)j.Kt, Cin_pad = (int)j.Cin_pad, Mpad = (int)j.Mpad, koff = (int)j.koff;
+    const int o0 = (int)(blk - j.row_start) * 16;
+    const int n = Cin * Kt;
+    // ---- per-row scale g / |v| (weight_norm), or the given scale, or 1 ----
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave * 4 + rr, o = o0 + r;
+        float scale = 1.0f;
+        if (o < O && j.g) {
+            if (j.g_is_scale) {
+                scale = j.g[o];
+            } else {
+                const float* vrow = j.v + (size_t)o * n;
+                float ss = 0.f;
+                for (int i = lane; i < n; i += 64) {
+                    const float x = vrow[i];
+                    ss += x * x;
+                }
+                ss = wave_sum(ss);
+                scale = j.g[o] / sqrtf(ss);
+            }
+        }
+        if (lane == 0) {
+            s_scale[r] = scale;
+            if (o < O) {
+                if (j.scale_out) j.scale_out[o] = scale;
+                if (j.bias_out) {
+                    int p;
+                    if (j.perm == PERM_GATE) {
+                        const int gate = o >= (int)j.C_gate;
+                        const int ch = gate ? o - (int)j.C_gate : o;
+                        p = (ch >> 7) * 256 + ((ch >> 6) & 1) * 128 + (((ch >> 4) & 3) * 2 + gate) * 16 + (ch & 15);
+                    } else {
+                        p = o + (int)j.row_off;
+                    }
+                    float bi = j.bias_in ? j.bias_in[o] : 0.f;
+                    if (j.bias_in2) bi += j.bias_in2[o];
+                    j.bias_out[p] = bi;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- pack: thread = (row r, channel pair); per (tap, 32-channel chunk) the 16 rows are one 1 KB run per plane ----
+    const int r = tid >> 4, cp = tid & 15;
+    const int o = o0 + r;
+    if (o >= O) return;
+    int p;
+    if (j.perm == PERM_GATE) {
+        const int gate = o >= (int)j.C_gate;
+        const int ch = gate ? o - (int)j.C_gate : o;
+        p = (ch >> 7) * 256 + ((ch >> 6) & 1) * 128 + (((ch >> 4) & 3) * 2 + gate) * 16 + (ch & 15);
+    } else {
+        p = o + (int)j.row_off;
+    }
+    const float scale = s_scale[r];
+    const float* vrow = j.v + (size_t)o * n;
+    const int nchunk = (Cin + 31) >> 5;
+    for (int tap = 0; tap < Kt; ++tap) {
+#pragma unroll 4
+        for (int cc = 0; cc < nchunk; ++cc) {
+            const int c = cc * 32 + cp * 2;
+            const float w0 = c < Cin ? vrow[c * Kt + tap] * scale : 0.f;
+            const float w1 = c + 1 < Cin ? vrow[(c + 1) * Kt + tap] * scale : 0.f;
+            const int k = koff + tap * Cin_pad + c;
+            const size_t idx = ((size_t)(k >> 5) * Mpad + p) * 32 + (k & 31);
+            u16 h0, l0, h1, l1;
+            split_bf16(w0, h0, l0);
+            split_bf16(w1, h1, l1);
+            *(uint32_t*)(j.A_hi + idx) = h0 | ((uint32_t)h1 << 16);
+            *(uint32_t*)(j.A_lo + idx) = l0 | ((uint32_t)l1 << 16);
+        }
+    }
 }
-hipError_t t2s_launch_pack_table(const PackJob* jobs, int n_jobs, long total_rows, hipStream_t stream) {
-    hipLaunchKernelGGL(pack_table_kernel, dim3((unsigned)total_rows), dim3(256), 0, stream, jobs, n_jobs);
+hipError_t t2s_launch_pack_table(const PackJob* jobs, int n_jobs, long total_groups, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_table_kernel, dim3((unsigned)total_groups), dim3(256), 0, stream, jobs, n_jobs);
     return hipGetLastError();
 }
 

@@ -182,7 +182,7 @@ class _Engine:
             for (v, gg, b1, b2, Ah, Al, bo, O, Cin, Kt, perm, Cg, Mpad, koff, Cin_pad, so) in specs:
                 rows.append([dp(v), dp(gg), dp(b1), dp(b2), dp(Ah), dp(Al), dp(bo), row_start,
                              O, Cin, Kt, perm, Cg, Mpad, koff, Cin_pad, 0, 0, dp(so)])
-                row_start += O
+                row_start += -(-O // 16)          # the table kernel packs 16 rows per workgroup
             self.packed["jobs"] = torch.tensor(rows, dtype=torch.int64).to(device)
             self.packed["n_jobs"], self.packed["total_rows"] = len(rows), row_start
             self.packed["job_key"] = ptr_key
