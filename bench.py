@@ -146,8 +146,12 @@ def main():
     dist = None
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     _lib.load()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # T2S_BENCH_REHEARSE=gloo: functional rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks share
+    # the visible devices, collectives over gloo).  The JSON line is tagged; it is not a measurement.
+    rehearse = os.environ.get("T2S_BENCH_REHEARSE", "")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1 or os.environ.get("T2S_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -158,7 +162,10 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            if rehearse:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -215,7 +222,7 @@ def main():
         dt = time.perf_counter() - t0
     log("rank %d: %d steps in %.3f s" % (rank, args.steps, dt))
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -262,6 +269,8 @@ def main():
                        else "dp%d, 13 bucketed RCCL all-reduces overlapped with backward" % args.gpus},
             "roofline": roof,
         }
+        if rehearse:
+            out["rehearsal"] = "NOT A MEASUREMENT: %d ranks share %d GPU(s), collectives over %s" % (world, torch.cuda.device_count(), rehearse)
         if args.gpus == 1 and args.mode == "forward" and not args.no_tacotron:
             log("tacotron metrics")
             del model, eng

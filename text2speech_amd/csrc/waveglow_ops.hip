@@ -433,8 +433,10 @@ __global__ __launch_bounds__(256) void start_kernel(const float* __restrict__ z,
     const int b = blockIdx.z;
     const int c8 = chunk * 32 + q * 8;
     if (t >= L) return;
+    // static trip counts with guards (nh <= 8): a0 / weights stay in registers, every load is issued up front
     float a0[8];
-    for (int j = 0; j < nh; ++j) a0[j] = z[((size_t)b * G + c_off + j) * L + t];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a0[j] = j < nh ? z[((size_t)b * G + c_off + j) * L + t] : 0.f;
     u16 hi[8], lo[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -442,7 +444,9 @@ __global__ __launch_bounds__(256) void start_kernel(const float* __restrict__ z,
         float v = 0.f;
         if (c < C) {
             v = bias[c];
-            for (int j = 0; j < nh; ++j) v += w[c * nh + j] * a0[j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nh) v += w[c * nh + j] * a0[j];
         }
         split_bf16(v, hi[e], lo[e]);
     }
