@@ -105,11 +105,8 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
     const char* S_lo = (const char*)a.S_lo + ((size_t)b * a.sc * a.Lp + a.halo + t0) * 64 + thr_off;
     char* lds_wave = smem + wave * 1024;                   // + lane*16 is implicit in the DMA
 
-    auto stage = [&](int ks, int buf) {
-        char* dst = lds_wave + buf * STAGE;
-        const char* ah = A_hi + (size_t)ks * a_kstride;
-        const char* al = A_lo + (size_t)ks * a_kstride;
-        const char *bh, *bl;
+    // B-operand source of K-step ks (tap-major over the conv input, then the conditioning channels)
+    auto b_source = [&](int ks, const char*& bh, const char*& bl) {
         if (ks < a.nk_x) {
             const int tap = ks / a.xc;
             const int kc = ks - tap * a.xc;
@@ -121,6 +118,11 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
             bh = S_hi + off;
             bl = S_lo + off;
         }
+    };
+    auto issue = [&](int ks, int buf, const char* bh, const char* bl) {
+        char* dst = lds_wave + buf * STAGE;
+        const char* ah = A_hi + (size_t)ks * a_kstride;
+        const char* al = A_lo + (size_t)ks * a_kstride;
 #pragma unroll
         for (int j = 0; j < A_PLANE / CALL_BYTES; ++j) {
             glds16(ah + j * CALL_BYTES, dst + j * CALL_BYTES);
@@ -145,17 +147,23 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
         for (int n = 0; n < NWT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = nk_split;
-    if (nk > 0) stage(0, 0);
+    const char *nbh = nullptr, *nbl = nullptr;       // B sources of the next K-step, computed one step ahead
+    if (nk > 0) {
+        b_source(0, nbh, nbl);
+        issue(0, 0, nbh, nbl);
+    }
+    if (nk > 1) b_source(1, nbh, nbl);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int ks = 0; ks < nk; ++ks) {
         const int cur = ks & 1;
-        if (ks + 1 < nk && !(T2S_ABLATE(a) & 1)) stage(ks + 1, cur ^ 1);
         const char* sb = smem + cur * STAGE;
-        // Fragment reads are ordered for the earliest possible first MFMA (it needs only a_lo(0) and b_hi(0)), and the
-        // A fragments of m-tile m+1 are fetched while m's 12 MFMAs issue: the LDS-read burst that follows every
-        // barrier overlaps matrix work instead of preceding it.
+        // Order after the barrier: (1) the DMA of the next stage, whose addresses were computed during the previous step
+        // (measured: issuing it after the fragment reads instead costs 6 us per launch - the fill needs the whole step to
+        // land); (2) the fragment reads the first MFMAs need; (3) the scalar address arithmetic for the step after next,
+        // hidden under the MFMAs.  The A fragments of m-tile m+1 are fetched while m's 12 MFMAs issue.
+        if (ks + 1 < nk && !(T2S_ABLATE(a) & 1)) issue(ks + 1, cur ^ 1, nbh, nbl);
         bf16x8 bh[NWT], bl[NWT];
         bf16x8 ah = *(const bf16x8*)(sb + a_frag);
         bf16x8 al = *(const bf16x8*)(sb + a_frag + A_PLANE);
@@ -164,6 +172,7 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
             bh[n] = *(const bf16x8*)(sb + b_frag + n * 1024);
             bl[n] = *(const bf16x8*)(sb + b_frag + B_PLANE_BYTES + n * 1024);
         }
+        if (ks + 2 < nk) b_source(ks + 2, nbh, nbl);
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
             bf16x8 ah_n = ah, al_n = al;
