@@ -74,20 +74,85 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
 // search over the jobs' row_start prefix, which counts 16-row groups): the per-row kernel above is latency-bound (three
 // dependent round trips for 6 KB of work), here the same chain moves 16x the bytes and the 16 packed rows of a K-chunk are
 // one contiguous 1 KB store per plane (rows p..p+15 are adjacent for both permutations).
-__global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restrict__ jobs, int n_jobs) {
-    __shared__ float s_scale[16];
-    const long blk = blockIdx.x;
-    int lo = 0, hi = n_jobs - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (jobs[mid].row_start <= blk) lo = mid; else hi = mid - 1;
+// Thread = (row r = tid / 16, channel pair cp = tid % 16).  Single pass when the slice fits in registers (Kt in {1, 3},
+// <= 20 channel chunks - every WaveGlow convolution): the thread reads the 2*Kt contiguous floats of its channel pair in
+// every 32-channel chunk (a row's 16 threads cover 32*Kt contiguous floats), the row's sum of squares is a 16-lane
+// shuffle reduction, and the scaled values go out from registers.  Otherwise two passes over the row.
+static __device__ __forceinline__ int pack_dst_row(const PackJob& j, int o) {
+    if (j.perm == PERM_GATE) {
+        const int gate = o >= (int)j.C_gate;
+        const int ch = gate ? o - (int)j.C_gate : o;
+        return (ch >> 7) * 256 + ((ch >> 6) & 1) * 128 + (((ch >> 4) & 3) * 2 + gate) * 16 + (ch & 15);
     }
-    const PackJob j = jobs[lo];
+    return o + (int)j.row_off;
+}
+static __device__ __forceinline__ void pack_store2(const PackJob& j, int k, int p, float w0, float w1) {
+    const size_t idx = ((size_t)(k >> 5) * (int)j.Mpad + p) * 32 + (k & 31);
+    u16 h0, l0, h1, l1;
+    split_bf16(w0, h0, l0);
+    split_bf16(w1, h1, l1);
+    *(uint32_t*)(j.A_hi + idx) = h0 | ((uint32_t)h1 << 16);
+    *(uint32_t*)(j.A_lo + idx) = l0 | ((uint32_t)l1 << 16);
+}
+static __device__ __forceinline__ float sum16(float v) {      // over the 16 lanes that share a row
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+#define PACK_MAX_CHUNKS 20
+template <int KT>
+static __device__ __forceinline__ void pack_rows_regs(const PackJob& j, int o0) {
+    const int tid = threadIdx.x, r = tid >> 4, cp = tid & 15;
+    const int O = (int)j.O, Cin = (int)j.Cin, Cin_pad = (int)j.Cin_pad, koff = (int)j.koff;
+    const int o = o0 + r;
+    const bool row_ok = o < O;
+    const int n = Cin * KT;
+    const int nchunk = (Cin + 31) >> 5;
+    const float* vrow = j.v + (size_t)(row_ok ? o : 0) * n;
+    float x[PACK_MAX_CHUNKS][2 * KT];
+    float ss = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < PACK_MAX_CHUNKS; ++cc) {
+        const int c = cc * 32 + cp * 2;
+#pragma unroll
+        for (int e = 0; e < 2 * KT; ++e) {
+            const int ce = c + e / KT;                       // element e of the pair: channel c or c + 1, tap e % KT
+            x[cc][e] = (cc < nchunk && row_ok && ce < Cin) ? vrow[c * KT + e] : 0.f;
+            ss += x[cc][e] * x[cc][e];
+        }
+    }
+    float scale = 1.0f;
+    if (j.g) {
+        if (j.g_is_scale) scale = row_ok ? j.g[o] : 1.f;
+        else {
+            ss = sum16(ss);
+            scale = row_ok ? j.g[o] / sqrtf(ss) : 1.f;
+        }
+    }
+    if (!row_ok) return;
+    const int p = pack_dst_row(j, o);
+    if (cp == 0) {
+        if (j.scale_out) j.scale_out[o] = scale;
+        if (j.bias_out) {
+            float bi = j.bias_in ? j.bias_in[o] : 0.f;
+            if (j.bias_in2) bi += j.bias_in2[o];
+            j.bias_out[p] = bi;
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < PACK_MAX_CHUNKS; ++cc) {
+        if (cc < nchunk) {
+            const int c = cc * 32 + cp * 2;
+#pragma unroll
+            for (int tap = 0; tap < KT; ++tap)
+                pack_store2(j, koff + tap * Cin_pad + c, p, x[cc][tap] * scale, x[cc][KT + tap] * scale);
+        }
+    }
+}
+
+static __device__ __forceinline__ void pack_rows_two_pass(const PackJob& j, int o0, float* s_scale) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int O = (int)j.O, Cin = (int)j.Cin, Kt = (int)j.Kt, Cin_pad = (int)j.Cin_pad, Mpad = (int)j.Mpad, koff = (int)j.koff;
-    const int o0 = (int)(blk - j.row_start) * 16;
+    const int O = (int)j.O, Cin = (int)j.Cin, Kt = (int)j.Kt, Cin_pad = (int)j.Cin_pad, koff = (int)j.koff;
     const int n = Cin * Kt;
-    // ---- per-row scale g / |v| (weight_norm), or the given scale, or 1 ----
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int r = wave * 4 + rr, o = o0 + r;
@@ -111,52 +176,46 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restri
             if (o < O) {
                 if (j.scale_out) j.scale_out[o] = scale;
                 if (j.bias_out) {
-                    int p;
-                    if (j.perm == PERM_GATE) {
-                        const int gate = o >= (int)j.C_gate;
-                        const int ch = gate ? o - (int)j.C_gate : o;
-                        p = (ch >> 7) * 256 + ((ch >> 6) & 1) * 128 + (((ch >> 4) & 3) * 2 + gate) * 16 + (ch & 15);
-                    } else {
-                        p = o + (int)j.row_off;
-                    }
                     float bi = j.bias_in ? j.bias_in[o] : 0.f;
                     if (j.bias_in2) bi += j.bias_in2[o];
-                    j.bias_out[p] = bi;
+                    j.bias_out[pack_dst_row(j, o)] = bi;
                 }
             }
         }
     }
     __syncthreads();
-    // ---- pack: thread = (row r, channel pair); per (tap, 32-channel chunk) the 16 rows are one 1 KB run per plane ----
     const int r = tid >> 4, cp = tid & 15;
     const int o = o0 + r;
     if (o >= O) return;
-    int p;
-    if (j.perm == PERM_GATE) {
-        const int gate = o >= (int)j.C_gate;
-        const int ch = gate ? o - (int)j.C_gate : o;
-        p = (ch >> 7) * 256 + ((ch >> 6) & 1) * 128 + (((ch >> 4) & 3) * 2 + gate) * 16 + (ch & 15);
-    } else {
-        p = o + (int)j.row_off;
-    }
+    const int p = pack_dst_row(j, o);
     const float scale = s_scale[r];
     const float* vrow = j.v + (size_t)o * n;
     const int nchunk = (Cin + 31) >> 5;
-    for (int tap = 0; tap < Kt; ++tap) {
-#pragma unroll 4
-        for (int cc = 0; cc < nchunk; ++cc) {
-            const int c = cc * 32 + cp * 2;
+    for (int cc = 0; cc < nchunk; ++cc) {
+        const int c = cc * 32 + cp * 2;
+        for (int tap = 0; tap < Kt; ++tap) {
             const float w0 = c < Cin ? vrow[c * Kt + tap] * scale : 0.f;
             const float w1 = c + 1 < Cin ? vrow[(c + 1) * Kt + tap] * scale : 0.f;
-            const int k = koff + tap * Cin_pad + c;
-            const size_t idx = ((size_t)(k >> 5) * Mpad + p) * 32 + (k & 31);
-            u16 h0, l0, h1, l1;
-            split_bf16(w0, h0, l0);
-            split_bf16(w1, h1, l1);
-            *(uint32_t*)(j.A_hi + idx) = h0 | ((uint32_t)h1 << 16);
-            *(uint32_t*)(j.A_lo + idx) = l0 | ((uint32_t)l1 << 16);
+            pack_store2(j, koff + tap * Cin_pad + c, p, w0, w1);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restrict__ jobs, int n_jobs) {
+    __shared__ float s_scale[16];
+    const long blk = blockIdx.x;
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].row_start <= blk) lo = mid; else hi = mid - 1;
+    }
+    const PackJob j = jobs[lo];
+    const int o0 = (int)(blk - j.row_start) * 16;
+    const int nchunk = ((int)j.Cin + 31) >> 5;
+    // Cin even keeps a thread's 2*Kt floats inside the row; the register path also needs whole channel pairs
+    if (nchunk <= PACK_MAX_CHUNKS && !((int)j.Cin & 1) && j.Kt == 3) pack_rows_regs<3>(j, o0);
+    else if (nchunk <= PACK_MAX_CHUNKS && !((int)j.Cin & 1) && j.Kt == 1) pack_rows_regs<1>(j, o0);
+    else pack_rows_two_pass(j, o0, s_scale);
 }
 hipError_t t2s_launch_pack_table(const PackJob* jobs, int n_jobs, long total_groups, hipStream_t stream) {
     hipLaunchKernelGGL(pack_table_kernel, dim3((unsigned)total_groups), dim3(256), 0, stream, jobs, n_jobs);
