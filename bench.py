@@ -243,14 +243,14 @@ def main():
             # --pmc WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note): profiles/r01_pmc_traffic.json
             traffic = None
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                traffic = pm["kernels"]["void conv_gemm_kernel<0>(ConvGemmArgs)"]["traffic_bytes_per_launch"]
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v4.json")))
+                traffic = pm["kernels"]["_Z16conv_gemm_kernelILi0ELi256ELi4EEv12ConvGemmArgs.kd"]["traffic_bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 pass
             roof = {"bound": "mfma", "kernel": "conv_gemm_kernel<EPI_GATE> (in_layers+cond_layers+gate)",
                     "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
-                    "traffic_note": "bytes/launch at batch 8x16000 from profiles/r01_pmc_traffic.json (separate --pmc passes); "
+                    "traffic_note": "bytes/launch at batch 8x16000 from profiles/r01_pmc_traffic_v4.json (separate --pmc passes, tools/pmc_traffic.py); "
                                     "compulsory bytes are 83 MB read + 33 MB written",
                     "avg_launch_ms": avg_ms, "launches": len(ms), "algorithmic_flops_per_launch": flops_per_launch,
                     "note": "split-bf16: 3 bf16 MFMA products per algorithmic MAC, so frac <= 1/3 by construction"}
