@@ -279,6 +279,12 @@ int t2s_conv_accumulate(const void* A_hi, const void* A_lo, const float* zero_bi
 int t2s_wgrad_gemm(const void* A_hi, const void* A_lo, const void* X_hi, const void* X_lo, const float* zero_bias,
                    float* out, int B, int M, int N, int Mpad, int Npad, int n_tchunks, int k0, int k1, int ksplit,
                    void* stream);
+/* Same contraction with K flattened over (batch element, time chunk): out = [nsplit][M][N] slabs, slab s covering
+ * ceil(B*(k1-k0)/nsplit) consecutive flattened K-steps, so the split count can be chosen to fill the chip in one round
+ * (nsplit ~ 256 / (ceil(M/256)*ceil(N/256))) instead of being a multiple of B. */
+int t2s_wgrad_gemm_flat(const void* A_hi, const void* A_lo, const void* X_hi, const void* X_lo, const float* zero_bias,
+                        float* out, int B, int M, int N, int Mpad, int Npad, int n_tchunks, int k0, int k1, int nsplit,
+                        void* stream);
 
 int t2s_plane_transpose(const void* src_hi, const void* src_lo, int B, int src_chunks, int n_chunks, int Lp, int shift,
                         void* dst_hi, void* dst_lo, int Npad, int n_off, void* stream);

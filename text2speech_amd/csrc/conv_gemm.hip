@@ -81,7 +81,14 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
     const int bs = tt_all / a.n_ttiles;              // batch entry (x K-split): also the output slab index
     const int t0 = (tt_all % a.n_ttiles) * T2S_TILE_N;
     int b = bs, kbeg = 0, nk_split = a.nk;
-    if (a.ksplit > 1 || a.k0 > 0) {                  // split-K over time chunks (weight-gradient GEMMs)
+    const int kper = a.kend - a.k0;                  // flattened mode: K-steps per batch entry
+    int kf0 = 0;
+    if (a.kflat > 0) {                               // split-K over (batch entry, time chunk) flattened
+        b = 0;
+        kf0 = bs * a.kchunk;
+        nk_split = min(a.kchunk, a.kflat * kper - kf0);
+        if (nk_split < 0) nk_split = 0;
+    } else if (a.ksplit > 1 || a.k0 > 0) {           // split-K over time chunks (weight-gradient GEMMs)
         const int sp = a.ksplit > 1 ? bs % a.ksplit : 0;
         b = a.ksplit > 1 ? bs / a.ksplit : bs;
         kbeg = a.k0 + sp * a.kchunk;
@@ -107,7 +114,12 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
 
     // B-operand source of K-step ks (tap-major over the conv input, then the conditioning channels)
     auto b_source = [&](int ks, const char*& bh, const char*& bl) {
-        if (ks < a.nk_x) {
+        if (a.kflat > 0) {
+            const int kf = kf0 + ks, bb = kf / kper, kk = a.k0 + kf - bb * kper;
+            const long off = ((long)bb * a.xc + kk) * (long)x_cstride;
+            bh = X_hi + off;
+            bl = X_lo + off;
+        } else if (ks < a.nk_x) {
             const int tap = ks / a.xc;
             const int kc = ks - tap * a.xc;
             const long off = (long)kc * (long)x_cstride + (long)((tap - (a.taps >> 1)) * a.dil) * 64;
@@ -121,8 +133,13 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
     };
     auto issue = [&](int ks, int buf, const char* bh, const char* bl) {
         char* dst = lds_wave + buf * STAGE;
-        const char* ah = A_hi + (size_t)ks * a_kstride;
-        const char* al = A_lo + (size_t)ks * a_kstride;
+        size_t a_off = (size_t)ks * a_kstride;
+        if (a.kflat > 0) {
+            const int kf = kf0 + ks, bb = kf / kper, kk = a.k0 + kf - bb * kper;
+            a_off = (size_t)bb * a.a_bstride * 2 + (size_t)kk * a_kstride;
+        }
+        const char* ah = A_hi + a_off;
+        const char* al = A_lo + a_off;
 #pragma unroll
         for (int j = 0; j < A_PLANE / CALL_BYTES; ++j) {
             glds16(ah + j * CALL_BYTES, dst + j * CALL_BYTES);

@@ -153,6 +153,29 @@ int t2s_wgrad_gemm(const void* A_hi, const void* A_lo, const void* X_hi, const v
     return T2S_OK;
 }
 
+int t2s_wgrad_gemm_flat(const void* A_hi, const void* A_lo, const void* X_hi, const void* X_lo, const float* zero_bias,
+                        float* out, int B, int M, int N, int Mpad, int Npad, int n_tchunks, int k0, int k1, int nsplit,
+                        void* stream) {
+    if (!planes_ok(A_hi, A_lo) || !planes_ok(X_hi, X_lo) || !zero_bias || !out) return T2S_EINVAL;
+    if (B <= 0 || M <= 0 || N <= 0 || M % 4 || Mpad % 256 || Mpad < M || Npad != cdiv(N, 256) * 256 || n_tchunks <= 0)
+        return T2S_EINVAL;
+    if (k0 < 0 || k1 > n_tchunks || k0 >= k1 || nsplit < 1 || nsplit > B * (k1 - k0)) return T2S_EINVAL;
+    ConvGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A_hi = (const u16*)A_hi; a.A_lo = (const u16*)A_lo; a.a_bstride = (long)n_tchunks * Mpad * 32;
+    a.X_hi = (const u16*)X_hi; a.X_lo = (const u16*)X_lo;
+    a.bias = zero_bias; a.out_f32 = out;
+    a.xc = n_tchunks; a.sc = 0; a.oc = cdiv(M, 32);
+    a.taps = 1; a.dil = 1; a.nk_x = n_tchunks; a.nk = n_tchunks;
+    a.Mpad = Mpad; a.Lp = Npad; a.halo = 0; a.L = N; a.B = nsplit;
+    a.ksplit = 1; a.k0 = k0; a.kend = k1; a.kflat = B; a.kchunk = cdiv(B * (k1 - k0), nsplit);
+    if ((long)a.kchunk * (nsplit - 1) >= (long)B * (k1 - k0)) return T2S_EINVAL;      // every slab must own >= 1 K-step
+    a.n_mtiles = cdiv(M, 256); a.n_ttiles = cdiv(N, 256);
+    a.C = M; a.act = ACT_NONE;
+    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_BIAS_ACT, (hipStream_t)stream));
+    return T2S_OK;
+}
+
 int t2s_plane_transpose(const void* src_hi, const void* src_lo, int B, int src_chunks, int n_chunks, int Lp, int shift,
                         void* dst_hi, void* dst_lo, int Npad, int n_off, void* stream) {
     if (!planes_ok(src_hi, src_lo) || !planes_ok(dst_hi, dst_lo) || B <= 0 || n_chunks <= 0 || n_chunks > src_chunks ||

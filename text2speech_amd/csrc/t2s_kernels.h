@@ -44,6 +44,8 @@ struct ConvGemmArgs {
     long a_bstride;    // elements between the A operands of consecutive batch entries (0: shared weights)
     int ksplit;        // weight-gradient GEMMs: K-range splits per batch entry (0/1 = none); grid batch index = b*ksplit + s
     int k0, kchunk, kend;   // split s covers K-steps [k0 + s*kchunk, min(k0 + (s+1)*kchunk, kend))
+    int kflat;         // >0: K runs over (batch entry, K-step in [k0, kend)) flattened, kflat = number of batch entries; grid batch
+                       // index = slab s covering flattened steps [s*kchunk, (s+1)*kchunk): the split count is free of the batch
     // GATE with WN.end folded in: fold_acc[slot][b][j][t] (+)= sum_c fold_w[c][j] * acts[c][t]
     const u16* fold_A;     // (W_end . W_skip_i) as MFMA A fragments [mt][wr][pair][hi,lo][lane][8] (endfold_weights_kernel)
     float* fold_acc;       // [2*n_mtiles][B][8][L]

@@ -68,11 +68,20 @@ def _alloc_train(eng, B, L, dev):
     st.TM_drs = tm(st.M2pad)
     st.TM_x = tm(st.N2pad)
     st.TM_act = tm(st.N1pad)
-    # split-K of the weight-gradient GEMMs: per batch element, over the non-halo time chunks
+    # split-K of the weight-gradient GEMMs over (batch element, non-halo time chunk) flattened: as many slabs as fill the
+    # chip's 256 CUs in one round of 256x256 tiles (a split tied to the batch gave 288-576 workgroups = 2-3 rounds)
     st.k0, st.k1 = g["halo"] // 32, -(-(g["halo"] + L) // 32)
-    st.ks2, st.ks1 = 2, 3
-    st.P2 = torch.empty(B * st.ks2, 2 * C, st.N2, dtype=torch.float32, device=dev)
-    st.P1 = torch.empty(B * st.ks1, 2 * C, st.N1, dtype=torch.float32, device=dev)
+    ksteps = B * (st.k1 - st.k0)
+
+    def nsplit(M, N):
+        tiles = -(-M // 256) * -(-N // 256)
+        ns = max(1, min(256 // tiles, ksteps // 8))
+        while ns > 1 and -(-ksteps // ns) * (ns - 1) >= ksteps:      # every slab owns at least one K-step
+            ns -= 1
+        return ns
+    st.ks2, st.ks1 = nsplit(2 * C, st.N2), nsplit(2 * C, st.N1)
+    st.P2 = torch.empty(st.ks2, 2 * C, st.N2, dtype=torch.float32, device=dev)
+    st.P1 = torch.empty(st.ks1, 2 * C, st.N1, dtype=torch.float32, device=dev)
     st.Mc = _lib.padded_rows(C)
     st.Ms = _lib.padded_rows(g["n_cond"])
     st.A_rsT = (_bf(2 * C // 32, st.Mc, 32, dev=dev), _bf(2 * C // 32, st.Mc, 32, dev=dev))
@@ -267,9 +276,9 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                       _ptr(ts.TM_drs[1]), Mrs, 0 if last else C, st)
             _lib.call("t2s_plane_transpose", _ptr(sv["A"][0]), _ptr(sv["A"][1]), B, xc, xc, Lp, 0, _ptr(ts.TM_act[0]),
                       _ptr(ts.TM_act[1]), ts.N1pad, 0, st)
-            _lib.call("t2s_wgrad_gemm", _ptr(ts.TM_drs[0]), _ptr(ts.TM_drs[1]), _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]), _ptr(zb),
+            _lib.call("t2s_wgrad_gemm_flat", _ptr(ts.TM_drs[0]), _ptr(ts.TM_drs[1]), _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]), _ptr(zb),
                       _ptr(ts.P1), B, rows2, ts.N1, Mrs, ts.N1pad, nt, ts.k0, ts.k1, ts.ks1, st)
-            wn_grads(conv_rs, ts.P1, B * ts.ks1, rows2, ts.N1, 0, 0, C, rows2, C, 1)
+            wn_grads(conv_rs, ts.P1, ts.ks1, rows2, ts.N1, 0, 0, C, rows2, C, 1)
             # 3. dW_in, dW_cond = d_pre . [x taps | spect | 1]^T
             _lib.call("t2s_plane_transpose", _ptr(ts.DP[0]), _ptr(ts.DP[1]), B, 2 * xc, 2 * xc, Lp, 0, _ptr(ts.TM_dp[0]),
                       _ptr(ts.TM_dp[1]), ts.M2pad, 0, st)
@@ -277,10 +286,10 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             for tap in range(ks):
                 _lib.call("t2s_plane_transpose", _ptr(sv["X"][0]), _ptr(sv["X"][1]), B, xc, xc, Lp, (tap - ks // 2) * d,
                           _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), ts.N2pad, tap * C, st)
-            _lib.call("t2s_wgrad_gemm", _ptr(ts.TM_dp[0]), _ptr(ts.TM_dp[1]), _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), _ptr(zb),
+            _lib.call("t2s_wgrad_gemm_flat", _ptr(ts.TM_dp[0]), _ptr(ts.TM_dp[1]), _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), _ptr(zb),
                       _ptr(ts.P2), B, 2 * C, ts.N2, ts.M2pad, ts.N2pad, nt, ts.k0, ts.k1, ts.ks2, st)
-            wn_grads(conv_in, ts.P2, B * ts.ks2, 2 * C, ts.N2, 0, C, ts.N2 - 1, 2 * C, C, ks)
-            wn_grads(conv_c, ts.P2, B * ts.ks2, 2 * C, ts.N2, ks * C, 0, ts.N2 - 1, 2 * C, n_cond, 1)
+            wn_grads(conv_in, ts.P2, ts.ks2, 2 * C, ts.N2, 0, C, ts.N2 - 1, 2 * C, C, ks)
+            wn_grads(conv_c, ts.P2, ts.ks2, 2 * C, ts.N2, ks * C, 0, ts.N2 - 1, 2 * C, n_cond, 1)
             # 4. dx (+)= W_in^T (*) d_pre ;  d_spect += W_cond^T d_pre
             v_in, s_in = scale_of(conv_in, pk["s_in"])
             _lib.call("t2s_pack_transposed", _ptr(v_in), _ptr(s_in), 2 * C, C, ks, 1, 2 * C, ts.Mc, 0, _ptr(ts.A_inT[0]),
