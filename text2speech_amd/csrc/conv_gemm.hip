@@ -447,6 +447,7 @@ hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a_in, int epi, hipStream_t s
     a.dbg = dbg;
     if (mt_rows == 128) {
         if (epi == EPI_RESSKIP) return launch_one<EPI_RESSKIP, 128>(a, stream);
+        if (epi == EPI_GATE_BWD) return launch_one<EPI_GATE_BWD, 128>(a, stream);
         return hipErrorInvalidValue;
     }
     static const int wn2 = getenv("T2S_GEMM_WN2") ? atoi(getenv("T2S_GEMM_WN2")) : 0;

@@ -102,9 +102,12 @@ int t2s_wg_bwd_gate_dgrad(const void* A_hi, const void* A_lo, const float* zero_
     a.oc = 2 * cc; a.tc = cc;
     a.taps = 1; a.dil = 1; a.nk_x = a.xc; a.nk = a.xc + a.sc;
     a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
-    a.n_mtiles = cdiv(C, 256); a.n_ttiles = cdiv(L, 256);
+    a.n_ttiles = cdiv(L, 256);
     a.C = C;
-    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_GATE_BWD, (hipStream_t)stream));
+    // 128-row tiles when 256-row tiles would leave half the CUs without a workgroup (C = 512: 2 x 64 tiles)
+    const int mt_rows = cdiv(C, 256) * a.n_ttiles * B < 200 ? 128 : 256;
+    a.n_mtiles = cdiv(C, mt_rows);
+    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_GATE_BWD, (hipStream_t)stream, mt_rows));
     return T2S_OK;
 }
 
