@@ -33,6 +33,7 @@ int t2s_gemv(const float* W1, int ld1, int k1, const float* W2, int ld2, int k2,
              const float* bias2, float* y, long sy_item, long sy_row, int rows, int items, int act,
              const unsigned char* mask, long smask_item, float mask_scale, void* stream) {
     GemvArgs a;
+    memset(&a, 0, sizeof(a));
     a.W1 = W1; a.ld1 = ld1; a.k1 = k1; a.W2 = W2; a.ld2 = ld2; a.k2 = k2;
     a.x1 = x1; a.n1 = n1; a.sx1 = sx1; a.x2 = x2; a.n2 = n2; a.sx2 = sx2; a.x3 = x3; a.n3 = n3; a.sx3 = sx3;
     a.bias1 = bias1; a.bias2 = bias2; a.y = y; a.sy_item = sy_item; a.sy_row = sy_row; a.rows = rows; a.items = items;
