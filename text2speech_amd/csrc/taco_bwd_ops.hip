@@ -491,7 +491,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(const float* __restr
                                                             const float* __restrict__ whh_f, const float* __restrict__ whh_r,
                                                             const int* __restrict__ lengths, float* dgx, float* hprev, int T,
                                                             int H, int T_out) {
-    __shared__ float s_dg[1024];
+    __shared__ __attribute__((aligned(16))) float s_dg[1024];
     __shared__ float s_dh[256];
     __shared__ float s_part[4][256];
     const int tid = threadIdx.x;
@@ -527,8 +527,12 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(const float* __restr
             const int jq = tid >> 8, k = tid & 255;
             float acc = 0.f;
             if (k < H) {
-#pragma unroll 8
-                for (int j = jq * H; j < (jq + 1) * H; ++j) acc += W[(size_t)j * H + k] * s_dg[j];
+#pragma unroll 4
+                for (int j = jq * H; j < (jq + 1) * H; j += 4) {       // one 16-byte broadcast LDS read per four rows
+                    const f32x4 d4 = *(const f32x4*)&s_dg[j];
+                    acc += (W[(size_t)j * H + k] * d4[0] + W[(size_t)(j + 1) * H + k] * d4[1]) +
+                           (W[(size_t)(j + 2) * H + k] * d4[2] + W[(size_t)(j + 3) * H + k] * d4[3]);
+                }
             }
             s_part[jq][k] = acc;
         }

@@ -580,7 +580,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_kernel(const float* __restrict_
                                                         const float* __restrict__ whhT_r, const int* __restrict__ lengths,
                                                         float* out, int B, int T, int H, int T_out, float* gates_save,
                                                         float* c_save) {
-    __shared__ float s_h[BT][256];
+    __shared__ __attribute__((aligned(16))) float s_h[BT][256];
     __shared__ float s_g[BT][1024];
     const int j = threadIdx.x;              // gate row, 4H == blockDim.x
     const int dir = blockIdx.y;
@@ -607,11 +607,17 @@ __global__ __launch_bounds__(1024) void lstm_seq_kernel(const float* __restrict_
             const int t = dir ? len[i] - 1 - s : s;
             acc[i] = (s < len[i]) ? gx[((size_t)(b0 + i) * T + t) * (8 * H) + dir * 4 * H + j] : 0.f;
         }
-#pragma unroll 8
-        for (int k = 0; k < H; ++k) {
-            const float w = WT[(size_t)k * 4 * H + j];
+        // four k per trip: one 16-byte broadcast LDS read per item instead of four 4-byte ones (the loop was LDS-issue
+        // bound: 1024 ds_read per thread per step), four independent weight loads in flight
+#pragma unroll 4
+        for (int k = 0; k < H; k += 4) {
+            const float w0 = WT[(size_t)k * 4 * H + j], w1 = WT[(size_t)(k + 1) * 4 * H + j];
+            const float w2 = WT[(size_t)(k + 2) * 4 * H + j], w3 = WT[(size_t)(k + 3) * 4 * H + j];
 #pragma unroll
-            for (int i = 0; i < BT; ++i) acc[i] += w * s_h[i][k];
+            for (int i = 0; i < BT; ++i) {
+                const f32x4 h4 = *(const f32x4*)&s_h[i][k];
+                acc[i] += (w0 * h4[0] + w1 * h4[1]) + (w2 * h4[2] + w3 * h4[3]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < BT; ++i) s_g[i][j] = acc[i];
