@@ -656,7 +656,10 @@ __global__ __launch_bounds__(1024) void lstm_seq_kernel(const float* __restrict_
 hipError_t t2s_launch_lstm_seq(const float* gx, const float* whhT_f, const float* whhT_r, const int* lengths, float* out,
                                int B, int T, int H, int T_out, float* gates_save, float* c_save, hipStream_t stream) {
     if (4 * H != 1024) return hipErrorInvalidValue;
-    if (B >= 8) hipLaunchKernelGGL(lstm_seq_kernel<4>, dim3((B + 3) / 4, 2), dim3(1024), 0, stream, gx, whhT_f, whhT_r, lengths, out, B, T, H, T_out, gates_save, c_save);
+    // elements per workgroup: the recurrent matrix (1 MB per direction) is re-streamed by every workgroup each step, the
+    // FMAs scale with the elements it carries - 2 per workgroup up to 128 elements (<= 128 workgroups), then 4
+    if (B > 128) hipLaunchKernelGGL(lstm_seq_kernel<4>, dim3((B + 3) / 4, 2), dim3(1024), 0, stream, gx, whhT_f, whhT_r, lengths, out, B, T, H, T_out, gates_save, c_save);
+    else if (B >= 8) hipLaunchKernelGGL(lstm_seq_kernel<2>, dim3((B + 1) / 2, 2), dim3(1024), 0, stream, gx, whhT_f, whhT_r, lengths, out, B, T, H, T_out, gates_save, c_save);
     else hipLaunchKernelGGL(lstm_seq_kernel<1>, dim3(B, 2), dim3(1024), 0, stream, gx, whhT_f, whhT_r, lengths, out, B, T, H, T_out, gates_save, c_save);
     return hipGetLastError();
 }
