@@ -353,6 +353,8 @@ typedef struct t2s_att_bwd {
     float *dD_part, *dK_part, *dv_part;   /* += ; one slot per (batch element, 32-position chunk): [B*ceil(T/32)][...];
                                              dD slots hold the transposed gradient [loc_f][att_dim] */
     float *dw_buf, *df_buf, *dq_part;     /* scratch: [B][T], [B][T][32], [B][ceil(T/32)][att_dim] */
+    float *dctx_out;                      /* optional [B][enc]: d_ctx of this step; with it d_memory may be NULL and the caller
+                                           * forms d_memory = sum_t w_t (x) d_ctx_t once after the loop */
     int B, T, att_dim, enc_dim, loc_f, loc_ks;
 } t2s_att_bwd;
 /* one decoder step of the location-sensitive attention, backward (tacotron.py:124-166,379) */
@@ -376,6 +378,8 @@ typedef struct t2s_taco_bptt {
     float *dc_d, *dc_a, *dw_c, *dwc_c;                  /* carries: [B][D], [B][A], [B][T_in] x2 (zero-initialised) */
     float *d_pmem, *d_memory;                           /* += [B][T_in][att_dim], [B][T_in][enc] */
     float *dD_part, *dK_part, *dv_part, *dw_buf, *df_buf, *dq_part;   /* as in t2s_att_bwd */
+    float *dctx_all;                                    /* optional [T_out][B][enc]: every step's d_ctx; then d_memory is not
+                                                         * touched by the loop (deferred, see t2s_att_bwd.dctx_out) */
 } t2s_taco_bptt;
 int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream);
 

@@ -46,7 +46,7 @@ int t2s_relu_drop_bwd(const float* dy, const float* y, float scale, size_t n, fl
 
 int t2s_taco_att_bwd(const t2s_att_bwd* p, void* stream) {
     if (!p || !p->w_cur || !p->q || !p->pmem || !p->memory || !p->w_loc_conv || !p->w_loc_dense || !p->w_v ||
-        !p->dw_carry || !p->dwc_carry || !p->d_q || !p->d_pmem || !p->d_memory || !p->dD_part || !p->dK_part ||
+        !p->dw_carry || !p->dwc_carry || !p->d_q || !p->d_pmem || (!p->d_memory && !p->dctx_out) || !p->dD_part || !p->dK_part ||
         !p->dv_part || !p->dw_buf || !p->df_buf || !p->dq_part || p->B <= 0 || p->T <= 0)
         return T2S_EINVAL;
     static_assert(sizeof(t2s_att_bwd) == sizeof(AttBwdArgs), "t2s_att_bwd layout");
@@ -104,6 +104,7 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         ab.dw_carry = p->dw_c; ab.dwc_carry = p->dwc_c; ab.d_q = p->dq_all + (size_t)t * B * ad; ab.d_pmem = p->d_pmem;
         ab.d_memory = p->d_memory; ab.dD_part = p->dD_part; ab.dK_part = p->dK_part; ab.dv_part = p->dv_part;
         ab.dw_buf = p->dw_buf; ab.df_buf = p->df_buf; ab.dq_part = p->dq_part;
+        if (p->dctx_all) { ab.dctx_out = p->dctx_all + (size_t)t * B * E; ab.d_memory = nullptr; }
         ab.B = B; ab.T = Tin; ab.att_dim = ad; ab.enc_dim = E; ab.loc_f = p->loc_filters; ab.loc_ks = p->loc_kernel;
         T2S_CHECK_HIP(t2s_launch_att_bwd(ab, stream));
         // attention LSTMCell: dh = from the decoder cell input + from the query + from step t+1's attention cell

@@ -37,6 +37,7 @@ struct AttBwdArgs {
     float* dw_buf;               // scratch [B][T]
     float* df_buf;               // scratch [B][T][32]
     float* dq_part;              // scratch [B][ceil(T/32)][att_dim]
+    float* dctx_out;             // optional [B][enc]: d_ctx of this step (then d_memory may be null: deferred accumulation)
     int B, T, att_dim, enc_dim, loc_f, loc_ks;
 };
 

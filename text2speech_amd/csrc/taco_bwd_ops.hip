@@ -132,7 +132,13 @@ __global__ __launch_bounds__(256) void att_bwd_dw_kernel(const AttBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float s_dctx[1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, T = a.T, E = a.enc_dim;
-    for (int c = tid; c < E; c += 256) s_dctx[c] = sum3(a.dctx1, a.sc1, a.dctx2, a.sc2, a.dctx3, a.sc3, b, c);
+    for (int c = tid; c < E; c += 256) {
+        const float v = sum3(a.dctx1, a.sc1, a.dctx2, a.sc2, a.dctx3, a.sc3, b, c);
+        s_dctx[c] = v;
+        // deferred form: keep d_ctx of this step; d_memory = sum_t w_t (x) d_ctx_t is then ONE contraction over the decoder
+        // steps after the loop instead of a read-modify-write of [T_in][enc] per step
+        if (a.dctx_out && blockIdx.x == 0) a.dctx_out[(size_t)b * E + c] = v;
+    }
     __syncthreads();
     const int tb = blockIdx.x * ATTB_CH + wave * 8;
     float acc[8], wt[8];
@@ -149,14 +155,16 @@ __global__ __launch_bounds__(256) void att_bwd_dw_kernel(const AttBwdArgs a) {
             if (tb + r < T) {
                 const size_t mo = ((size_t)b * T + tb + r) * E + c;
                 m[r] = *(const f32x4*)(a.memory + mo);
-                dm[r] = *(const f32x4*)(a.d_memory + mo);
+                if (a.d_memory) dm[r] = *(const f32x4*)(a.d_memory + mo);
             }
 #pragma unroll
         for (int r = 0; r < 8; ++r)
             if (tb + r < T) {
                 acc[r] += m[r][0] * dc[0] + m[r][1] * dc[1] + m[r][2] * dc[2] + m[r][3] * dc[3];
-                dm[r] += wt[r] * dc;
-                *(f32x4*)(a.d_memory + ((size_t)b * T + tb + r) * E + c) = dm[r];
+                if (a.d_memory) {
+                    dm[r] += wt[r] * dc;
+                    *(f32x4*)(a.d_memory + ((size_t)b * T + tb + r) * E + c) = dm[r];
+                }
             }
     }
 #pragma unroll

@@ -29,7 +29,8 @@ class _AttBwd(ctypes.Structure):
                  ("w_cur", vp), ("s_wcur", lng), ("w_prev", vp), ("wc_prev", vp), ("s_wprev", lng), ("s_wcprev", lng),
                  ("q", vp), ("pmem", vp), ("memory", vp), ("lengths", vp), ("w_loc_conv", vp), ("w_loc_dense", vp),
                  ("w_v", vp), ("dw_carry", vp), ("dwc_carry", vp), ("d_q", vp), ("d_pmem", vp), ("d_memory", vp),
-                 ("dD_part", vp), ("dK_part", vp), ("dv_part", vp), ("dw_buf", vp), ("df_buf", vp), ("dq_part", vp)] +
+                 ("dD_part", vp), ("dK_part", vp), ("dv_part", vp), ("dw_buf", vp), ("df_buf", vp), ("dq_part", vp),
+                 ("dctx_out", vp)] +
                 [(n, i32) for n in ("B", "T", "att_dim", "enc_dim", "loc_f", "loc_ks")])
 
 
@@ -43,7 +44,7 @@ class _Bptt(ctypes.Structure):
                 [("att_drop_scale", f32c), ("dec_drop_scale", f32c)] +
                 [(n, vp) for n in ("d_hc", "out_d", "out_a", "dg_d", "dg_a", "dq_all", "dc_d", "dc_a", "dw_c",
                                    "dwc_c", "d_pmem", "d_memory", "dD_part", "dK_part", "dv_part", "dw_buf", "df_buf",
-                                   "dq_part")])
+                                   "dq_part", "dctx_all")])
 
 
 class _BnBwd(ctypes.Structure):
@@ -247,6 +248,8 @@ class _Bwd:
         nch = (T_in + 31) // 32                     # partial parameter gradients: one slot per (batch element, 32-position chunk)
         dD_p, dK_p, dv_p = self.zeros(B * nch, ad * F_), self.zeros(B * nch, F_ * 2 * KS), self.zeros(B * nch, ad)
         dw_buf, df_buf, dq_part = self.new(B, T_in), self.new(B, T_in, 32), self.new(B, nch, ad)
+        # deferred d_memory (needs T_in % 4 == 0 for the slab layout); otherwise the loop accumulates it step by step
+        dctx_all = self.new(T, B, E) if T_in % 4 == 0 else None
         align = S["align_out"]                     # [B][T_cap][T_in]
         T_cap = align.size(1)
         att_drop, dec_drop = S.get("att_drop"), S.get("dec_drop")
@@ -261,8 +264,16 @@ class _Bwd:
                    d_hc=_p(d_hc), out_d=_p(out_d), out_a=_p(out_a), dg_d=_p(dg_d), dg_a=_p(dg_a), dq_all=_p(dq_all),
                    dc_d=_p(dc_d), dc_a=_p(dc_a), dw_c=_p(dw_c), dwc_c=_p(dwc_c), d_pmem=_p(d_pmem),
                    d_memory=_p(d_memory), dD_part=_p(dD_p), dK_part=_p(dK_p), dv_part=_p(dv_p), dw_buf=_p(dw_buf),
-                   df_buf=_p(df_buf), dq_part=_p(dq_part))
+                   df_buf=_p(df_buf), dq_part=_p(dq_part), dctx_all=_p(dctx_all))
         _lib.call("t2s_taco_bptt_steps", ctypes.byref(bp), T, 0, st)        # the whole reversed loop, enqueued from C++
+        if dctx_all is not None:
+            # d_memory[b] = sum_t w[t][b][:] (x) d_ctx[t][b][:]: one contraction over the decoder steps per batch element
+            for b in range(B):
+                Pm_, ks_, M4_, N_ = self.items_wgrad(T, [(_p(align, b * T_cap * T_in), T_in, T_in, 0, 0)],
+                                                     [(_p(dctx_all, b * E), B * E, E, 0, 0)], T_in, E)
+                _lib.call("t2s_wn_backward", _p(Pm_), ks_, M4_, N_, 0, 0, 0, N_ - 1, _p(memory), None, T_in, E, 1,
+                          _p(d_memory, b * T_in * E), None, None, 0, st)
+            self.keep.append(dctx_all)
         self.keep += [dw_buf, df_buf, dq_part]
         # ---- weight gradients over all (step, batch) items ----
         ar = dec.attention_rnn
