@@ -13,6 +13,8 @@ Reference lines are cited per method.
 """
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F  # noqa: F401  (kept for API parity with the reference module)
 
@@ -328,23 +330,33 @@ class _Engine:
         up = m.upsample
         if (mel.size(2) - 1) * up.stride[0] + up.kernel_size[0] < T:
             raise AssertionError("upsampled spectrogram shorter than audio (reference glow.py:216)")
-        self.pack_weights(dev, force=True)
         w = self.workspace(B, L, dev)
-        st = _lib.current_stream()
-        self._upsample(mel, B, L, w)
+        # The input-side work (conditioning upsampler: compute-bound; audio squeeze; 12 log-determinants) does not depend on
+        # the per-forward weight pack (HBM-bound): it runs on a second HIP stream next to the pack and joins before flow 0.
+        main = torch.cuda.current_stream(dev)
+        side = self.side_stream if getattr(self, "side_stream", None) is not None else torch.cuda.Stream(device=dev)
+        self.side_stream = side
+        if os.environ.get("T2S_NO_SIDE_STREAM"):          # A/B switch: everything on the caller's stream
+            side = main
         audio32 = _f32c(audio)
         z = torch.empty(B, G, L, dtype=torch.float32, device=dev)
-        _lib.call("t2s_wg_audio_squeeze", _lib.ptr(audio32), _lib.ptr(z), B, T, G, L, 0, st)
         log_s_list, log_det_list = [], []
         log_det = torch.empty(m.n_flows, dtype=torch.float32, device=dev)
         Ws = [_f32c(m.convinv[k].conv.weight) for k in range(m.n_flows)]
         keep = list(Ws)
         # B*L*logdet(W_k) of all flows in one launch (reference glow.py:100)
-        jkey = tuple(w_.data_ptr() for w_ in Ws) + (log_det.data_ptr(),)
         jobs = torch.tensor([[Ws[k].data_ptr(), log_det.data_ptr() + 4 * k, 0, self._flow_geom(k)[1]]
                              for k in range(m.n_flows)], dtype=torch.int64).to(dev)
         keep.append(jobs)
-        _lib.call("t2s_small_logdet_inv_batch", _lib.ptr(jobs), m.n_flows, float(B * L), st)
+        side.wait_stream(main)               # inputs, the job table and earlier users of the workspace are ordered before
+        with torch.cuda.stream(side):
+            st2 = _lib.current_stream()
+            self._upsample(mel, B, L, w)
+            _lib.call("t2s_wg_audio_squeeze", _lib.ptr(audio32), _lib.ptr(z), B, T, G, L, 0, st2)
+            _lib.call("t2s_small_logdet_inv_batch", _lib.ptr(jobs), m.n_flows, float(B * L), st2)
+        self.pack_weights(dev, force=True)
+        main.wait_stream(side)
+        st = _lib.current_stream()
         for k in range(m.n_flows):
             c_off, n_rem, n_half = self._flow_geom(k)
             Wk = Ws[k]
