@@ -56,7 +56,9 @@ static __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // MT = rows of the M (output-channel) tile: 256, or 128 for short GEMMs that would otherwise leave CUs idle.
 // WN = waves along N (time): 4 -> 8 waves of 128 x 64 (two per SIMD); 2 -> 4 waves of 128 x 128 (one per SIMD, 256
 // accumulator registers): a third fewer LDS fragment bytes per MFMA, the resource this kernel runs out of first.
-template <int EPI, int MT, int WN>
+// BD = B operand direct: the activation fragments go global -> registers (in the plane layout a 16-row x 32-channel fragment
+// is one contiguous KiB, so the loads are perfectly coalesced and need no swizzle), one K-step ahead; LDS then only carries A.
+template <int EPI, int MT, int WN, bool BD = false>
 __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs a) {
     constexpr int NTH = 128 * WN;                    // threads per workgroup
     constexpr int NWT = 16 / WN;                     // 16-column MFMA tiles per wave
@@ -145,10 +147,21 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
             glds16(ah + j * CALL_BYTES, dst + j * CALL_BYTES);
             glds16(al + j * CALL_BYTES, dst + A_PLANE + j * CALL_BYTES);
         }
+        if (!BD) {
 #pragma unroll
-        for (int j = 0; j < B_PLANE_BYTES / CALL_BYTES; ++j) {
-            glds16(bh + j * CALL_BYTES, dst + 2 * A_PLANE + j * CALL_BYTES);
-            glds16(bl + j * CALL_BYTES, dst + 2 * A_PLANE + B_PLANE_BYTES + j * CALL_BYTES);
+            for (int j = 0; j < B_PLANE_BYTES / CALL_BYTES; ++j) {
+                glds16(bh + j * CALL_BYTES, dst + 2 * A_PLANE + j * CALL_BYTES);
+                glds16(bl + j * CALL_BYTES, dst + 2 * A_PLANE + B_PLANE_BYTES + j * CALL_BYTES);
+            }
+        }
+    };
+    // BD: this lane's 16 bytes of B fragment n of the tile whose DMA source would be (bh, bl)
+    const long bd_adj = (long)((wc * (NWT * 16) + (lane & 15)) * 64 + (lane >> 4) * 16) - (long)thr_off;
+    auto b_direct = [&](const char* bh, const char* bl, bf16x8 (&rh)[NWT], bf16x8 (&rl)[NWT]) {
+#pragma unroll
+        for (int n = 0; n < NWT; ++n) {
+            rh[n] = *(const bf16x8*)(bh + bd_adj + n * 1024);
+            rl[n] = *(const bf16x8*)(bl + bd_adj + n * 1024);
         }
     };
 
@@ -165,9 +178,11 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
 
     const int nk = nk_split;
     const char *nbh = nullptr, *nbl = nullptr;       // B sources of the next K-step, computed one step ahead
+    bf16x8 bh[NWT], bl[NWT], bhn[NWT], bln[NWT];
     if (nk > 0) {
         b_source(0, nbh, nbl);
         issue(0, 0, nbh, nbl);
+        if (BD) b_direct(nbh, nbl, bh, bl);
     }
     if (nk > 1) b_source(1, nbh, nbl);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -180,14 +195,18 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
         // (measured: issuing it after the fragment reads instead costs 6 us per launch - the fill needs the whole step to
         // land); (2) the fragment reads the first MFMAs need; (3) the scalar address arithmetic for the step after next,
         // hidden under the MFMAs.  The A fragments of m-tile m+1 are fetched while m's 12 MFMAs issue.
-        if (ks + 1 < nk && !(T2S_ABLATE(a) & 1)) issue(ks + 1, cur ^ 1, nbh, nbl);
-        bf16x8 bh[NWT], bl[NWT];
+        if (ks + 1 < nk && !(T2S_ABLATE(a) & 1)) {
+            issue(ks + 1, cur ^ 1, nbh, nbl);
+            if (BD) b_direct(nbh, nbl, bhn, bln);
+        }
         bf16x8 ah = *(const bf16x8*)(sb + a_frag);
         bf16x8 al = *(const bf16x8*)(sb + a_frag + A_PLANE);
+        if (!BD) {
 #pragma unroll
-        for (int n = 0; n < NWT; ++n) {
-            bh[n] = *(const bf16x8*)(sb + b_frag + n * 1024);
-            bl[n] = *(const bf16x8*)(sb + b_frag + B_PLANE_BYTES + n * 1024);
+            for (int n = 0; n < NWT; ++n) {
+                bh[n] = *(const bf16x8*)(sb + b_frag + n * 1024);
+                bl[n] = *(const bf16x8*)(sb + b_frag + B_PLANE_BYTES + n * 1024);
+            }
         }
         if (ks + 2 < nk) b_source(ks + 2, nbh, nbl);
 #pragma unroll
@@ -211,6 +230,10 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
             al = al_n;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (BD) {
+#pragma unroll
+            for (int n = 0; n < NWT; ++n) { bh[n] = bhn[n]; bl[n] = bln[n]; }
+        }
         __syncthreads();
     }
 
@@ -425,18 +448,18 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
     }
 }
 
-template <int EPI, int MT, int WN = 4>
+template <int EPI, int MT, int WN = 4, bool BD = false>
 static hipError_t launch_one(const ConvGemmArgs& a, hipStream_t stream) {
     const int nwg = a.n_mtiles * a.n_ttiles * a.B;
     constexpr size_t lds = 2 * (2 * MT * 64 + 2 * B_PLANE_BYTES);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<EPI, MT, WN>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<EPI, MT, WN, BD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<EPI, MT, WN>), dim3(nwg), dim3(128 * WN), lds, stream, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<EPI, MT, WN, BD>), dim3(nwg), dim3(128 * WN), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -451,7 +474,9 @@ hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a_in, int epi, hipStream_t s
         return hipErrorInvalidValue;
     }
     static const int wn2 = getenv("T2S_GEMM_WN2") ? atoi(getenv("T2S_GEMM_WN2")) : 0;
+    static const int bdir = getenv("T2S_GEMM_BD") ? atoi(getenv("T2S_GEMM_BD")) : 0;
     if (epi == EPI_GATE && wn2) return launch_one<EPI_GATE, 256, 2>(a, stream);
+    if (epi == EPI_GATE && bdir) return launch_one<EPI_GATE, 256, 4, true>(a, stream);
     if (epi == EPI_GATE) return launch_one<EPI_GATE, 256>(a, stream);
     if (epi == EPI_RESSKIP) return launch_one<EPI_RESSKIP, 256>(a, stream);
     if (epi == EPI_GATE_BWD) return launch_one<EPI_GATE_BWD, 256>(a, stream);
