@@ -58,7 +58,11 @@ static __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // accumulator registers): a third fewer LDS fragment bytes per MFMA, the resource this kernel runs out of first.
 // BD = B operand direct: the activation fragments go global -> registers (in the plane layout a 16-row x 32-channel fragment
 // is one contiguous KiB, so the loads are perfectly coalesced and need no swizzle), one K-step ahead; LDS then only carries A.
-template <int EPI, int MT, int WN, bool BD = false>
+// SH = shared B tile (gate GEMM, taps == 3, dilation <= 32): the three taps of a 32-channel block read rows t0-d.., t0..,
+// t0+d.. of the SAME activation plane, so one extended tile of 256 + 2d rows is filled once per block and the three K-steps
+// read it at row offsets 0, d, 2d - 40 KB of B per block instead of 96 KB.  The K order becomes block-major for the tap part
+// (A is indexed tap*xc + c as packed, no repack); the conditioning part keeps the one-tile-per-step scheme.
+template <int EPI, int MT, int WN, bool BD = false, bool SH = false>
 __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs a) {
     constexpr int NTH = 128 * WN;                    // threads per workgroup
     constexpr int NWT = 16 / WN;                     // 16-column MFMA tiles per wave
@@ -176,6 +180,7 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
 #pragma unroll
         for (int n = 0; n < NWT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (!SH) {
     const int nk = nk_split;
     const char *nbh = nullptr, *nbl = nullptr;       // B sources of the next K-step, computed one step ahead
     bf16x8 bh[NWT], bl[NWT], bhn[NWT], bln[NWT];
@@ -236,6 +241,110 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
         }
         __syncthreads();
     }
+
+  } else {
+    // ------------------------------------------------------------------ shared-B main loop
+    constexpr int BX_PLANE = 320 * 64;                     // bytes of one plane of the extended tile (<= 320 rows)
+    constexpr int AR = 2 * A_PLANE;                        // one A stage (hi, lo)
+    char* const Ar0 = smem;
+    char* const Bx0 = smem + 2 * AR;
+    const int d = a.dil, xc = a.xc;
+    const int n_units = (T2S_TILE_N + 2 * d + 15) >> 4;    // 16-row units of the extended tile
+    const int unit_off = (lane >> 2) * 64 + (((lane & 3) ^ swz4((lane >> 4) & 3)) * 16);
+    // extended-tile sources without the workgroup-wide DMA thread offset
+    const char* Xe_hi = (const char*)a.X_hi + (((size_t)b * xc) * a.Lp + a.halo + t0 - d) * 64 + unit_off;
+    const char* Xe_lo = (const char*)a.X_lo + (((size_t)b * xc) * a.Lp + a.halo + t0 - d) * 64 + unit_off;
+    auto issue_a = [&](int kidx, int buf) {
+        char* dst = lds_wave + buf * AR;
+        const char* ah = A_hi + (size_t)kidx * a_kstride;
+        const char* al = A_lo + (size_t)kidx * a_kstride;
+#pragma unroll
+        for (int j = 0; j < A_PLANE / CALL_BYTES; ++j) {
+            glds16(ah + j * CALL_BYTES, dst + j * CALL_BYTES);
+            glds16(al + j * CALL_BYTES, dst + A_PLANE + j * CALL_BYTES);
+        }
+    };
+    auto issue_bunit = [&](int c, int u, int buf) {       // one 16-row unit of block c's extended tile (both planes)
+        char* dst = Bx0 + buf * 2 * BX_PLANE + u * 1024;
+        const size_t off = (size_t)c * x_cstride + (size_t)u * 1024;
+        glds16(Xe_hi + off, dst);
+        glds16(Xe_lo + off, dst + BX_PLANE);
+    };
+    auto issue_cond = [&](int j, int buf) {                // conditioning K-step j: full A and B tiles
+        issue_a(a.nk_x + j, buf);
+        char* dst = Bx0 + buf * 2 * BX_PLANE + wave * 1024;
+        const char* bh = S_hi + (size_t)j * x_cstride;
+        const char* bl = S_lo + (size_t)j * x_cstride;
+#pragma unroll
+        for (int q = 0; q < B_PLANE_BYTES / CALL_BYTES; ++q) {
+            glds16(bh + q * CALL_BYTES, dst + q * CALL_BYTES);
+            glds16(bl + q * CALL_BYTES, dst + BX_PLANE + q * CALL_BYTES);
+        }
+    };
+    auto compute = [&](const char* sa, const char* sbx, int boff) {
+        bf16x8 bh[NWT], bl[NWT];
+        bf16x8 ah = *(const bf16x8*)(sa + a_frag);
+        bf16x8 al = *(const bf16x8*)(sa + a_frag + A_PLANE);
+#pragma unroll
+        for (int n = 0; n < NWT; ++n) {
+            bh[n] = *(const bf16x8*)(sbx + boff + n * 1024);
+            bl[n] = *(const bf16x8*)(sbx + BX_PLANE + boff + n * 1024);
+        }
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            bf16x8 ah_n = ah, al_n = al;
+            if (m + 1 < MW) {
+                ah_n = *(const bf16x8*)(sa + a_frag + (m + 1) * 1024);
+                al_n = *(const bf16x8*)(sa + a_frag + A_PLANE + (m + 1) * 1024);
+            }
+#pragma unroll
+            for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+            ah = ah_n;
+            al = al_n;
+        }
+    };
+    // prologue: A(tap 0, block 0) and the whole extended tile of block 0
+    issue_a(0, 0);
+    for (int u = wave; u < n_units; u += 2 * WN) issue_bunit(0, u, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int rbase = wc * (NWT * 16) + (lane & 15);       // this lane's row inside the (unshifted) tile
+    const int n_tap_steps = 3 * xc;
+    for (int i = 0; i < n_tap_steps; ++i) {
+        const int c = i / 3, tap = i - 3 * c;
+        // next A tile; at the last tap step the first conditioning stage instead
+        if (i + 1 < n_tap_steps) {
+            const int c1 = (i + 1) / 3, tap1 = (i + 1) - 3 * c1;
+            issue_a(tap1 * xc + c1, (i + 1) & 1);
+        } else if (a.sc > 0) {
+            issue_cond(0, (i + 1) & 1);
+        }
+        // a third of the next block's extended tile per step
+        if (c + 1 < xc) {
+            const int u = tap * (2 * WN) + wave;
+            if (u < n_units) issue_bunit(c + 1, u, (c + 1) & 1);
+        }
+        const int row = rbase + tap * d;
+        const int boff = row * 64 + (((lane >> 4) ^ swz4((row >> 2) & 3)) * 16);
+        compute(Ar0 + (i & 1) * AR, Bx0 + (c & 1) * 2 * BX_PLANE, boff);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    {
+        const int boff0 = rbase * 64 + (((lane >> 4) ^ swz4((rbase >> 2) & 3)) * 16);
+        for (int j = 0; j < a.sc; ++j) {
+            const int st = (n_tap_steps + j) & 1;
+            if (j + 1 < a.sc) issue_cond(j + 1, st ^ 1);
+            compute(Ar0 + st * AR, Bx0 + st * 2 * BX_PLANE, boff0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+  }
 
     // ---- epilogue.  C/D map of mfma 16x16: col = lane&15 (time), row = 4*(lane>>4) + reg (channel) ----
     const int tcol = lane & 15;
@@ -448,18 +557,18 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
     }
 }
 
-template <int EPI, int MT, int WN = 4, bool BD = false>
+template <int EPI, int MT, int WN = 4, bool BD = false, bool SH = false>
 static hipError_t launch_one(const ConvGemmArgs& a, hipStream_t stream) {
     const int nwg = a.n_mtiles * a.n_ttiles * a.B;
-    constexpr size_t lds = 2 * (2 * MT * 64 + 2 * B_PLANE_BYTES);
+    constexpr size_t lds = SH ? 2 * (2 * MT * 64) + 4 * 320 * 64 : 2 * (2 * MT * 64 + 2 * B_PLANE_BYTES);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<EPI, MT, WN, BD>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<EPI, MT, WN, BD, SH>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<EPI, MT, WN, BD>), dim3(nwg), dim3(128 * WN), lds, stream, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<EPI, MT, WN, BD, SH>), dim3(nwg), dim3(128 * WN), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -477,6 +586,10 @@ hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a_in, int epi, hipStream_t s
     static const int bdir = getenv("T2S_GEMM_BD") ? atoi(getenv("T2S_GEMM_BD")) : 0;
     if (epi == EPI_GATE && wn2) return launch_one<EPI_GATE, 256, 2>(a, stream);
     if (epi == EPI_GATE && bdir) return launch_one<EPI_GATE, 256, 4, true>(a, stream);
+    static const int shb = getenv("T2S_GEMM_SH") ? atoi(getenv("T2S_GEMM_SH")) : 0;
+    if (epi == EPI_GATE && shb && a.taps == 3 && a.dil <= 32 && a.dil <= a.halo && a.nk_x == 3 * a.xc && a.ksplit <= 1 &&
+        a.k0 == 0 && a.kflat == 0 && a.nk == a.nk_x + a.sc)
+        return launch_one<EPI_GATE, 256, 4, false, true>(a, stream);
     if (epi == EPI_GATE) return launch_one<EPI_GATE, 256>(a, stream);
     if (epi == EPI_RESSKIP) return launch_one<EPI_RESSKIP, 256>(a, stream);
     if (epi == EPI_GATE_BWD) return launch_one<EPI_GATE_BWD, 256>(a, stream);
