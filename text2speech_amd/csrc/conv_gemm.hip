@@ -62,7 +62,9 @@ static __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // t0+d.. of the SAME activation plane, so one extended tile of 256 + 2d rows is filled once per block and the three K-steps
 // read it at row offsets 0, d, 2d - 40 KB of B per block instead of 96 KB.  The K order becomes block-major for the tap part
 // (A is indexed tap*xc + c as packed, no repack); the conditioning part keeps the one-tile-per-step scheme.
-template <int EPI, int MT, int WN, bool BD = false, bool SH = false>
+// EF = early free: a wave reads ALL fragments of the current stage into registers (96 VGPRs), a barrier frees the stage, and
+// the DMA for step k+2 goes into it at once - the fill gets two K-steps to land instead of one (2 LDS stages as before).
+template <int EPI, int MT, int WN, bool BD = false, bool SH = false, bool EF = false>
 __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs a) {
     constexpr int NTH = 128 * WN;                    // threads per workgroup
     constexpr int NWT = 16 / WN;                     // 16-column MFMA tiles per wave
@@ -180,7 +182,47 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
 #pragma unroll
         for (int n = 0; n < NWT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if constexpr (!SH) {
+  if constexpr (EF) {
+    const int nk = nk_split;
+    const char *nbh = nullptr, *nbl = nullptr;
+    if (nk > 0) { b_source(0, nbh, nbl); issue(0, 0, nbh, nbl); }
+    if (nk > 1) { b_source(1, nbh, nbl); issue(1, 1, nbh, nbl); }
+    if (nk > 2) b_source(2, nbh, nbl);
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        const char* sb = smem + cur * STAGE;
+        // stage ks has landed once at most the newer DMA group (step ks+1: 8 instructions per wave) is outstanding
+        if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        bf16x8 fah[MW], fal[MW], fbh[NWT], fbl[NWT];
+#pragma unroll
+        for (int n = 0; n < NWT; ++n) {
+            fbh[n] = *(const bf16x8*)(sb + b_frag + n * 1024);
+            fbl[n] = *(const bf16x8*)(sb + b_frag + B_PLANE_BYTES + n * 1024);
+        }
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            fah[m] = *(const bf16x8*)(sb + a_frag + m * 1024);
+            fal[m] = *(const bf16x8*)(sb + a_frag + A_PLANE + m * 1024);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                     // every wave holds its fragments: the stage is free
+        if (ks + 2 < nk) {
+            issue(ks + 2, cur, nbh, nbl);
+            if (ks + 3 < nk) b_source(ks + 3, nbh, nbl);
+        }
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+#pragma unroll
+            for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[m], fbh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[m], fbl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[m], fbh[n], acc[m][n], 0, 0, 0);
+        }
+    }
+  } else if constexpr (!SH) {
     const int nk = nk_split;
     const char *nbh = nullptr, *nbl = nullptr;       // B sources of the next K-step, computed one step ahead
     bf16x8 bh[NWT], bl[NWT], bhn[NWT], bln[NWT];
@@ -557,18 +599,18 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
     }
 }
 
-template <int EPI, int MT, int WN = 4, bool BD = false, bool SH = false>
+template <int EPI, int MT, int WN = 4, bool BD = false, bool SH = false, bool EF = false>
 static hipError_t launch_one(const ConvGemmArgs& a, hipStream_t stream) {
     const int nwg = a.n_mtiles * a.n_ttiles * a.B;
     constexpr size_t lds = SH ? 2 * (2 * MT * 64) + 4 * 320 * 64 : 2 * (2 * MT * 64 + 2 * B_PLANE_BYTES);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<EPI, MT, WN, BD, SH>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<EPI, MT, WN, BD, SH, EF>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<EPI, MT, WN, BD, SH>), dim3(nwg), dim3(128 * WN), lds, stream, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<EPI, MT, WN, BD, SH, EF>), dim3(nwg), dim3(128 * WN), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -586,7 +628,9 @@ hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a_in, int epi, hipStream_t s
     static const int bdir = getenv("T2S_GEMM_BD") ? atoi(getenv("T2S_GEMM_BD")) : 0;
     if (epi == EPI_GATE && wn2) return launch_one<EPI_GATE, 256, 2>(a, stream);
     if (epi == EPI_GATE && bdir) return launch_one<EPI_GATE, 256, 4, true>(a, stream);
-    static const int shb = getenv("T2S_GEMM_SH") ? atoi(getenv("T2S_GEMM_SH")) : 0;
+    static const int ef = getenv("T2S_GEMM_EF") ? atoi(getenv("T2S_GEMM_EF")) : 0;
+    if (epi == EPI_GATE && ef) return launch_one<EPI_GATE, 256, 4, false, false, true>(a, stream);
+    static const int shb = getenv("T2S_GEMM_SH") ? atoi(getenv("T2S_GEMM_SH")) : 1;      // default on; 0 = one B tile per K-step
     if (epi == EPI_GATE && shb && a.taps == 3 && a.dil <= 32 && a.dil <= a.halo && a.nk_x == 3 * a.xc && a.ksplit <= 1 &&
         a.k0 == 0 && a.kflat == 0 && a.nk == a.nk_x + a.sc)
         return launch_one<EPI_GATE, 256, 4, false, true>(a, stream);
