@@ -224,7 +224,19 @@ class _Bwd:
         w_proj[:n_mel + 1] = P["w_proj"]
         w_projT = self.transpose(w_proj)                                     # [DE][NP]
         d_hc = self.new(items, DE)
-        self.gemv(w_projT, NP, NP, _p(d_proj), NP, _p(d_hc), DE, DE, items)
+        # d[h_dec | ctx] = d_proj . W_proj over all T*B items: a 1x1 "convolution" along the item axis on the split-bf16 GEMM
+        # (K = 81 is too short and 25600 items too many for the GEMV kernels: 4.5 ms there, ~0.1 ms here)
+        Cpad_p, Mpad_p = _ru(NP, 32), _lib.padded_rows(DE)
+        Ap = (self.bf(Cpad_p // 32, Mpad_p, 32), self.bf(Cpad_p // 32, Mpad_p, 32))
+        bias_p = self.zeros(Mpad_p)
+        _lib.call("t2s_pack_conv_weight", _p(w_projT), None, 0, None, DE, NP, 1, 0, 0, 0, Mpad_p, 0, Cpad_p, _p(Ap[0]), _p(Ap[1]),
+                  _p(bias_p), 0, st)
+        Lp_p = _lib.plane_rows(items, 0)
+        Xp = (self.bf(1, Cpad_p // 32, Lp_p, 32), self.bf(1, Cpad_p // 32, Lp_p, 32))
+        _lib.call("t2s_rows_to_planes", _p(d_proj), 1, items, NP, Lp_p, 0, _p(Xp[0]), _p(Xp[1]), st)
+        _lib.call("t2s_conv_bias_act", _p(Ap[0]), _p(Ap[1]), _p(bias_p), _p(Xp[0]), _p(Xp[1]), None, None, _p(d_hc), 1, 1, NP, DE,
+                  1, 1, 0, items, Lp_p, 0, Mpad_p, st)
+        self.keep += [Ap, Xp, bias_p]
         hc_all = sv["hc_all"]
         Pp, ks, M4, N = self.items_wgrad(items, [(_p(d_proj), NP, n_mel + 1, 0, 0)], [(_p(hc_all), DE, DE, 0, 0)], n_mel + 1, DE)
         lp, gl = dec.linear_projection.linear_layer, dec.gate_layer.linear_layer
