@@ -243,14 +243,16 @@ def main():
             # --pmc WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note): profiles/r01_pmc_traffic.json
             traffic = None
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v4.json")))
-                traffic = pm["kernels"]["_Z16conv_gemm_kernelILi0ELi256ELi4EEv12ConvGemmArgs.kd"]["traffic_bytes_per_launch"]
-            except (OSError, KeyError, ValueError):
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v5.json")))
+                # the gate GEMM runs as two instantiations (shared-B tile for dilation <= 32, plain otherwise): launch-weighted mean
+                gk = [v for k, v in pm["kernels"].items() if k.startswith("_Z16conv_gemm_kernelILi0E")]
+                traffic = sum(v["traffic_bytes_per_launch"] * v["launches"] for v in gk) / sum(v["launches"] for v in gk)
+            except (OSError, KeyError, ValueError, ZeroDivisionError):
                 pass
             roof = {"bound": "mfma", "kernel": "conv_gemm_kernel<EPI_GATE> (in_layers+cond_layers+gate)",
                     "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
-                    "traffic_note": "bytes/launch at batch 8x16000 from profiles/r01_pmc_traffic_v4.json (separate --pmc passes, tools/pmc_traffic.py); "
+                    "traffic_note": "bytes/launch at batch 8x16000 from profiles/r01_pmc_traffic_v5.json (separate --pmc passes, tools/pmc_traffic.py; launch-weighted over the two gate-GEMM instantiations); "
                                     "compulsory bytes are 83 MB read + 33 MB written",
                     "avg_launch_ms": avg_ms, "launches": len(ms), "algorithmic_flops_per_launch": flops_per_launch,
                     "note": "split-bf16: 3 bf16 MFMA products per algorithmic MAC, so frac <= 1/3 by construction"}
