@@ -64,7 +64,9 @@ static __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 // (A is indexed tap*xc + c as packed, no repack); the conditioning part keeps the one-tile-per-step scheme.
 // EF = early free: a wave reads ALL fragments of the current stage into registers (96 VGPRs), a barrier frees the stage, and
 // the DMA for step k+2 goes into it at once - the fill gets two K-steps to land instead of one (2 LDS stages as before).
-template <int EPI, int MT, int WN, bool BD = false, bool SH = false, bool EF = false>
+// NS = LDS stages of the plain main loop: 2, or 3 where the stage is small enough (128-row tiles: 3 x 48 KB) - those GEMMs have
+// K-steps of ~0.7 us of MFMA against a ~1.7 us fill turnaround, so the fill must be issued two steps ahead.
+template <int EPI, int MT, int WN, bool BD = false, bool SH = false, bool EF = false, int NS = 2>
 __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs a) {
     constexpr int NTH = 128 * WN;                    // threads per workgroup
     constexpr int NWT = 16 / WN;                     // 16-column MFMA tiles per wave
@@ -223,27 +225,36 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
         }
     }
   } else if constexpr (!SH) {
+    constexpr int DMA_PER_ISSUE = 2 * (A_PLANE / CALL_BYTES) + (BD ? 0 : 2 * (B_PLANE_BYTES / CALL_BYTES));
     const int nk = nk_split;
-    const char *nbh = nullptr, *nbl = nullptr;       // B sources of the next K-step, computed one step ahead
+    const char *nbh = nullptr, *nbl = nullptr;       // B sources of the next stage to issue, computed one step ahead
     bf16x8 bh[NWT], bl[NWT], bhn[NWT], bln[NWT];
     if (nk > 0) {
         b_source(0, nbh, nbl);
         issue(0, 0, nbh, nbl);
         if (BD) b_direct(nbh, nbl, bh, bl);
     }
-    if (nk > 1) b_source(1, nbh, nbl);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NS == 3 && nk > 1) {
+        b_source(1, nbh, nbl);
+        issue(1, 1, nbh, nbl);
+    }
+    if (nk > NS - 1) b_source(NS - 1, nbh, nbl);
+    if (NS == 3 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_ISSUE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    int cur = 0;
     for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
         const char* sb = smem + cur * STAGE;
-        // Order after the barrier: (1) the DMA of the next stage, whose addresses were computed during the previous step
-        // (measured: issuing it after the fragment reads instead costs 6 us per launch - the fill needs the whole step to
-        // land); (2) the fragment reads the first MFMAs need; (3) the scalar address arithmetic for the step after next,
-        // hidden under the MFMAs.  The A fragments of m-tile m+1 are fetched while m's 12 MFMAs issue.
-        if (ks + 1 < nk && !(T2S_ABLATE(a) & 1)) {
-            issue(ks + 1, cur ^ 1, nbh, nbl);
+        int nxt = cur + (NS - 1);                    // stage that step ks + NS - 1 goes into: freed at the end of step ks - 1
+        if (nxt >= NS) nxt -= NS;
+        // Order after the barrier: (1) the DMA of the stage NS-1 steps ahead, whose addresses were computed during the
+        // previous step (measured: issuing it after the fragment reads instead costs 6 us per launch); (2) the fragment
+        // reads the first MFMAs need; (3) the scalar address arithmetic for the next issue, hidden under the MFMAs.  The A
+        // fragments of m-tile m+1 are fetched while m's 12 MFMAs issue.
+        const bool issued = ks + NS - 1 < nk && !(T2S_ABLATE(a) & 1);
+        if (issued) {
+            issue(ks + NS - 1, nxt, nbh, nbl);
             if (BD) b_direct(nbh, nbl, bhn, bln);
         }
         bf16x8 ah = *(const bf16x8*)(sb + a_frag);
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
                 bl[n] = *(const bf16x8*)(sb + b_frag + B_PLANE_BYTES + n * 1024);
             }
         }
-        if (ks + 2 < nk) b_source(ks + 2, nbh, nbl);
+        if (ks + NS < nk) b_source(ks + NS, nbh, nbl);
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
             bf16x8 ah_n = ah, al_n = al;
@@ -276,14 +287,16 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
             ah = ah_n;
             al = al_n;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the next step's stage must have landed; with three stages the group issued in THIS step may still be in flight
+        if (NS == 3 && issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_ISSUE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (BD) {
 #pragma unroll
             for (int n = 0; n < NWT; ++n) { bh[n] = bhn[n]; bl[n] = bln[n]; }
         }
         __syncthreads();
+        cur = cur + 1 == NS ? 0 : cur + 1;
     }
-
   } else {
     // ------------------------------------------------------------------ shared-B main loop
     constexpr int BX_PLANE = 320 * 64;                     // bytes of one plane of the extended tile (<= 320 rows)
@@ -599,18 +612,18 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
     }
 }
 
-template <int EPI, int MT, int WN = 4, bool BD = false, bool SH = false, bool EF = false>
+template <int EPI, int MT, int WN = 4, bool BD = false, bool SH = false, bool EF = false, int NS = 2>
 static hipError_t launch_one(const ConvGemmArgs& a, hipStream_t stream) {
     const int nwg = a.n_mtiles * a.n_ttiles * a.B;
-    constexpr size_t lds = SH ? 2 * (2 * MT * 64) + 4 * 320 * 64 : 2 * (2 * MT * 64 + 2 * B_PLANE_BYTES);
+    constexpr size_t lds = SH ? 2 * (2 * MT * 64) + 4 * 320 * 64 : NS * (2 * MT * 64 + 2 * B_PLANE_BYTES);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<EPI, MT, WN, BD, SH, EF>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<EPI, MT, WN, BD, SH, EF, NS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<EPI, MT, WN, BD, SH, EF>), dim3(nwg), dim3(128 * WN), lds, stream, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<EPI, MT, WN, BD, SH, EF, NS>), dim3(nwg), dim3(128 * WN), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -620,6 +633,9 @@ hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a_in, int epi, hipStream_t s
     ConvGemmArgs a = a_in;
     a.dbg = dbg;
     if (mt_rows == 128) {
+        static const int ns3 = getenv("T2S_GEMM_NS3") ? atoi(getenv("T2S_GEMM_NS3")) : 0;     // 1 = three stages (measured slower)
+        if (epi == EPI_RESSKIP && ns3) return launch_one<EPI_RESSKIP, 128, 4, false, false, false, 3>(a, stream);
+        if (epi == EPI_GATE_BWD && ns3) return launch_one<EPI_GATE_BWD, 128, 4, false, false, false, 3>(a, stream);
         if (epi == EPI_RESSKIP) return launch_one<EPI_RESSKIP, 128>(a, stream);
         if (epi == EPI_GATE_BWD) return launch_one<EPI_GATE_BWD, 128>(a, stream);
         return hipErrorInvalidValue;
