@@ -4,7 +4,7 @@
 # JSON that profiles/r01_summary.md quotes.  Counters are collected in their own passes (no trace domains next to --pmc).
 set -euo pipefail
 R=$(pwd)
-OUT=${1:-$R/gpurun_out/collect}
+OUT=$(realpath -m "${1:-$R/gpurun_out/collect}")
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-tacotron"
