@@ -72,6 +72,23 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         !p->dc_d || !p->dc_a || !p->dw_c || !p->dwc_c || !p->d_pmem || !p->d_memory || !p->dD_part || !p->dK_part ||
         !p->dv_part || !p->dw_buf || !p->df_buf || !p->dq_part)
         return T2S_EINVAL;
+    // Two chains, two streams.  The decoder-cell chain of step t (pointwise backward, then [W_ih | W_hh]^T dgates) needs only
+    // the decoder-cell chain of step t+1: h_dec feeds the next decoder cell and the projection, never the attention.  The
+    // attention / attention-cell chain of step t consumes its output out_d[t].  So the former runs ahead on a side stream and
+    // signals one event per step; its ~27 us per step hide behind the ~78 us of the attention chain.
+    static hipStream_t side = nullptr;
+    static hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    static const bool two_streams = !getenv("T2S_BPTT_ONE_STREAM");
+    if (two_streams && !side) {
+        T2S_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        T2S_CHECK_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
+        T2S_CHECK_HIP(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+    }
+    hipStream_t dstream = two_streams ? side : stream;
+    if (two_streams) {                                   // everything enqueued so far (d_hc, the saves) precedes the side chain
+        T2S_CHECK_HIP(hipEventRecord(ev_main, stream));
+        T2S_CHECK_HIP(hipStreamWaitEvent(side, ev_main, 0));
+    }
     for (int t = t_hi - 1; t >= t_lo; --t) {
         const bool nxt = t + 1 < T;
         // decoder LSTMCell: dh = d[h_dec] from the projection + from step t+1's decoder cell (through W_hh)
@@ -84,12 +101,16 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         cd.c_prev = t > 0 ? p->dec_c_all + (size_t)(t - 1) * B * D : nullptr;
         cd.dc_carry = p->dc_d; cd.dgates = p->dg_d + (size_t)t * B * 4 * D; cd.B = B; cd.H = D;
         cd.wq = nullptr; cd.dq = nullptr; cd.q_dim = 0;
-        T2S_CHECK_HIP(t2s_launch_lstm_cell_bwd(cd, stream));
+        T2S_CHECK_HIP(t2s_launch_lstm_cell_bwd(cd, dstream));
         GemvArgs g;
         memset(&g, 0, sizeof(g));
         g.W1 = p->W_dT; g.ld1 = 4 * D; g.k1 = 4 * D; g.x1 = cd.dgates; g.n1 = 4 * D; g.sx1 = 4 * D;
         g.y = p->out_d + (size_t)t * B * KD; g.sy_item = KD; g.sy_row = 1; g.rows = KD; g.items = B; g.mask_scale = 1.f;
-        T2S_CHECK_HIP(t2s_launch_gemv(g, stream));
+        T2S_CHECK_HIP(t2s_launch_gemv(g, dstream));
+        if (two_streams) {       // out_d[t] is ready: the wait below binds to THIS record, so one event object serves every step
+            T2S_CHECK_HIP(hipEventRecord(ev_side, side));
+            T2S_CHECK_HIP(hipStreamWaitEvent(stream, ev_side, 0));
+        }
         // attention: d_ctx = decoder-cell input part + projection part + step t+1's attention-cell input part
         AttBwdArgs ab;
         memset(&ab, 0, sizeof(ab));
