@@ -33,7 +33,7 @@ int t2s_lstm_cell_bwd(const float* dh1, long s1, const float* dh2, long s2, cons
     a.dh1 = dh1; a.s1 = s1; a.dh2 = dh2; a.s2 = s2; a.dh3 = dh3; a.s3 = s3;
     a.drop_mask = drop_mask; a.drop_scale = drop_scale; a.gates = gates; a.c_new = c_new; a.c_prev = c_prev;
     a.dc_carry = dc_carry; a.dgates = dgates; a.B = B; a.H = H;
-    a.wq = nullptr; a.dq = nullptr; a.q_dim = 0;
+    a.wq = nullptr; a.dq = nullptr; a.q_dim = 0; a.dq_part = nullptr; a.dq_nchunk = 0;
     T2S_CHECK_HIP(t2s_launch_lstm_cell_bwd(a, (hipStream_t)stream));
     return T2S_OK;
 }
@@ -76,14 +76,20 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
     // the decoder-cell chain of step t+1: h_dec feeds the next decoder cell and the projection, never the attention.  The
     // attention / attention-cell chain of step t consumes its output out_d[t].  So the former runs ahead on a side stream and
     // signals one event per step; its ~27 us per step hide behind the ~78 us of the attention chain.
-    static hipStream_t side = nullptr;
-    static hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    // A third stream takes the last part of the attention backward (location-conv backward): it only feeds the NEXT step's
+    // carries and the kernel gradient, so it runs beside this step's attention-cell backward and GEMM.
+    static hipStream_t side = nullptr, side2 = nullptr;
+    static hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_energy = nullptr, ev_conv = nullptr;
     static const bool two_streams = !getenv("T2S_BPTT_ONE_STREAM");
     if (two_streams && !side) {
         T2S_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        T2S_CHECK_HIP(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
         T2S_CHECK_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
         T2S_CHECK_HIP(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+        T2S_CHECK_HIP(hipEventCreateWithFlags(&ev_energy, hipEventDisableTiming));
+        T2S_CHECK_HIP(hipEventCreateWithFlags(&ev_conv, hipEventDisableTiming));
     }
+    bool conv_pending = false;
     hipStream_t dstream = two_streams ? side : stream;
     if (two_streams) {                                   // everything enqueued so far (d_hc, the saves) precedes the side chain
         T2S_CHECK_HIP(hipEventRecord(ev_main, stream));
@@ -100,7 +106,7 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         cd.gates = p->dec_gates_all + (size_t)t * B * 4 * D; cd.c_new = p->dec_c_all + (size_t)t * B * D;
         cd.c_prev = t > 0 ? p->dec_c_all + (size_t)(t - 1) * B * D : nullptr;
         cd.dc_carry = p->dc_d; cd.dgates = p->dg_d + (size_t)t * B * 4 * D; cd.B = B; cd.H = D;
-        cd.wq = nullptr; cd.dq = nullptr; cd.q_dim = 0;
+        cd.wq = nullptr; cd.dq = nullptr; cd.q_dim = 0; cd.dq_part = nullptr; cd.dq_nchunk = 0;
         T2S_CHECK_HIP(t2s_launch_lstm_cell_bwd(cd, dstream));
         GemvArgs g;
         memset(&g, 0, sizeof(g));
@@ -127,13 +133,27 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         ab.dw_buf = p->dw_buf; ab.df_buf = p->df_buf; ab.dq_part = p->dq_part;
         if (p->dctx_all) { ab.dctx_out = p->dctx_all + (size_t)t * B * E; ab.d_memory = nullptr; }
         ab.B = B; ab.T = Tin; ab.att_dim = ad; ab.enc_dim = E; ab.loc_f = p->loc_filters; ab.loc_ks = p->loc_kernel;
-        T2S_CHECK_HIP(t2s_launch_att_bwd(ab, stream));
+        if (two_streams) {
+            if (conv_pending) T2S_CHECK_HIP(hipStreamWaitEvent(stream, ev_conv, 0));   // carries of step t+1 are in place
+            T2S_CHECK_HIP(t2s_launch_att_bwd_front(ab, stream));
+            T2S_CHECK_HIP(hipEventRecord(ev_energy, stream));
+            T2S_CHECK_HIP(hipStreamWaitEvent(side2, ev_energy, 0));
+            T2S_CHECK_HIP(t2s_launch_att_bwd_conv(ab, side2));
+            T2S_CHECK_HIP(hipEventRecord(ev_conv, side2));
+            conv_pending = true;
+        } else {
+            T2S_CHECK_HIP(t2s_launch_att_bwd(ab, stream));
+        }
         // attention LSTMCell: dh = from the decoder cell input + from the query + from step t+1's attention cell
         LstmBwdArgs ca;
         ca.dh1 = p->out_d + (size_t)t * B * KD; ca.s1 = KD;
         ca.dh2 = nxt ? p->out_a + (size_t)(t + 1) * B * KA + P + E : nullptr; ca.s2 = KA;
         ca.dh3 = nullptr; ca.s3 = 0;
         ca.wq = p->w_query; ca.dq = ab.d_q; ca.q_dim = ad;           // + W_query^T d_q, fused
+        ca.dq_part = nullptr; ca.dq_nchunk = 0;
+        if (two_streams) {       // d_q is folded on the other stream: sum the per-chunk partials here
+            ca.dq_part = p->dq_part; ca.dq_nchunk = (Tin + 31) / 32;
+        }
         ca.drop_mask = p->att_drop ? p->att_drop + (size_t)t * B * A : nullptr; ca.drop_scale = p->att_drop_scale;
         ca.gates = p->att_gates_all + (size_t)t * B * 4 * A; ca.c_new = p->att_c_all + (size_t)t * B * A;
         ca.c_prev = t > 0 ? p->att_c_all + (size_t)(t - 1) * B * A : nullptr;
@@ -144,6 +164,7 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         g.y = p->out_a + (size_t)t * B * KA; g.sy_item = KA; g.sy_row = 1; g.rows = KA; g.items = B; g.mask_scale = 1.f;
         T2S_CHECK_HIP(t2s_launch_gemv(g, stream));
     }
+    if (conv_pending) T2S_CHECK_HIP(hipStreamWaitEvent(stream, ev_conv, 0));       // dq_all, carries, dK complete for the caller
     return T2S_OK;
 }
 

@@ -16,7 +16,8 @@ struct LstmBwdArgs {
     float* dc_carry;             // [B][H] in/out
     float* dgates;               // [B][4H] out
     int B, H;
-    const float* wq; const float* dq; int q_dim;   // optional: dh += wq^T dq  (wq [q_dim][H], dq [B][q_dim])
+    const float* wq; const float* dq; int q_dim;   // optional: dh += wq^T dq  (wq [q_dim][H], dq [B][q_dim], q_dim <= 256)
+    const float* dq_part; int dq_nchunk;           // optional instead of dq: dq[b][k] = sum_c dq_part[(b*dq_nchunk + c)*q_dim + k]
 };
 
 struct AttBwdArgs {
@@ -57,6 +58,9 @@ hipError_t t2s_launch_rows_to_tm(const float* x, long ld, int items, int items_p
 hipError_t t2s_launch_lstm_cell_bwd(const LstmBwdArgs& a, hipStream_t stream);
 hipError_t t2s_launch_relu_drop_bwd(const float* dy, const float* y, float scale, size_t n, float* dz, hipStream_t stream);
 hipError_t t2s_launch_att_bwd(const AttBwdArgs& a, hipStream_t stream);
+// the same in two parts: (d_w, energies) and (location-conv backward: carries for step t-1, kernel gradient, d_q fold)
+hipError_t t2s_launch_att_bwd_front(const AttBwdArgs& a, hipStream_t stream);
+hipError_t t2s_launch_att_bwd_conv(const AttBwdArgs& a, hipStream_t stream);
 hipError_t t2s_launch_bn_bwd(const BnBwdArgs& a, hipStream_t stream);
 hipError_t t2s_launch_planes_to_f32(const u16* X_hi, const u16* X_lo, int B, int C, int L, int Lp, int halo, float* out,
                                     int accumulate, hipStream_t stream);

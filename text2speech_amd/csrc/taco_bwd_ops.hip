@@ -65,11 +65,26 @@ hipError_t t2s_launch_rows_to_tm(const float* x, long ld, int items, int items_p
 __global__ void lstm_cell_bwd_kernel(const LstmBwdArgs a) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
+    __shared__ float s_dq[256];
+    if (a.wq) {                  // + W_q^T d_q: the query Linear hangs off this cell's output (tacotron.py:137)
+        // d_q of this batch element into LDS first (blockIdx.y = b is block-uniform); when the attention backward runs its
+        // last part on another stream, the per-chunk partials are summed here
+        for (int k = threadIdx.x; k < a.q_dim; k += blockDim.x) {
+            float v = 0.f;
+            if (a.dq_part) {
+                for (int c = 0; c < a.dq_nchunk; ++c) v += a.dq_part[((size_t)b * a.dq_nchunk + c) * a.q_dim + k];
+            } else {
+                v = a.dq[(size_t)b * a.q_dim + k];
+            }
+            s_dq[k] = v;
+        }
+    }
+    if (a.wq) __syncthreads();
     if (u >= a.H) return;
     float dh = sum3(a.dh1, a.s1, a.dh2, a.s2, a.dh3, a.s3, b, u);
-    if (a.wq) {                  // + W_q^T d_q: the query Linear hangs off this cell's output (tacotron.py:137)
+    if (a.wq) {
         float e0 = 0.f, e1 = 0.f;
-        const float* dq = a.dq + (size_t)b * a.q_dim;
+        const float* dq = s_dq;
         int k = 0;
         for (; k + 16 <= a.q_dim; k += 16) {            // sixteen independent loads in flight, then the FMAs
             float w[16];
@@ -368,15 +383,26 @@ __global__ __launch_bounds__(256) void att_bwd_conv_kernel(const AttBwdArgs a) {
     }
 }
 
-hipError_t t2s_launch_att_bwd(const AttBwdArgs& a, hipStream_t stream) {
-    if (a.enc_dim > 1024 || (a.enc_dim & 3) || a.att_dim > 128 || a.loc_f > 32 || a.loc_ks > 63 || !(a.loc_ks & 1) ||
-        !a.dw_buf || !a.df_buf || !a.dq_part)
-        return hipErrorInvalidValue;
+static bool att_bwd_ok(const AttBwdArgs& a) {
+    return !(a.enc_dim > 1024 || (a.enc_dim & 3) || a.att_dim > 128 || a.loc_f > 32 || a.loc_ks > 63 || !(a.loc_ks & 1) ||
+             !a.dw_buf || !a.df_buf || !a.dq_part);
+}
+hipError_t t2s_launch_att_bwd_front(const AttBwdArgs& a, hipStream_t stream) {
+    if (!att_bwd_ok(a)) return hipErrorInvalidValue;
     const dim3 grid((a.T + ATTB_CH - 1) / ATTB_CH, a.B);
     hipLaunchKernelGGL(att_bwd_dw_kernel, grid, dim3(256), 0, stream, a);
     hipLaunchKernelGGL(att_bwd_energy_kernel, grid, dim3(512), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t t2s_launch_att_bwd_conv(const AttBwdArgs& a, hipStream_t stream) {
+    if (!att_bwd_ok(a)) return hipErrorInvalidValue;
+    const dim3 grid((a.T + ATTB_CH - 1) / ATTB_CH, a.B);
     hipLaunchKernelGGL(att_bwd_conv_kernel, grid, dim3(256), 0, stream, a);
     return hipGetLastError();
+}
+hipError_t t2s_launch_att_bwd(const AttBwdArgs& a, hipStream_t stream) {
+    hipError_t e = t2s_launch_att_bwd_front(a, stream);
+    return e != hipSuccess ? e : t2s_launch_att_bwd_conv(a, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
