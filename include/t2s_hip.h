@@ -93,6 +93,8 @@ int t2s_small_logdet_inv(const float* W, int n, float scale, float* logdet_out, 
 /* the same for many small matrices in ONE launch (all 12 flows' 1x1-conv weights): jobs is a DEVICE array */
 typedef struct t2s_small_mat_job { const float* W; float* logdet_out; float* inv_out; long n; } t2s_small_mat_job;
 int t2s_small_logdet_inv_batch(const t2s_small_mat_job* jobs, int n_jobs, float scale, void* stream);
+/* Same, `host_jobs` is a HOST array of at most 16 entries that travels as a kernel argument: no device table to upload. */
+int t2s_small_logdet_inv_batch_host(const t2s_small_mat_job* host_jobs, int n_jobs, float scale, void* stream);
 
 /* WN.start: x = w[C][n_half] * z[:, c_off:c_off+n_half] + bias -> planes X_hi/X_lo (reference glow.py:156) */
 int t2s_wg_start(const float* z, const float* w, const float* bias, int B, int n_group, int c_off, int n_half, int C,

@@ -29,6 +29,7 @@ SIGNATURES = {
     "t2s_wg_convinv": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
     "t2s_small_logdet_inv": [c_vp, c_int, c_float, c_vp, c_vp, c_vp],
     "t2s_small_logdet_inv_batch": [c_vp, c_int, c_float, c_vp],
+    "t2s_small_logdet_inv_batch_host": [c_vp, c_int, c_float, c_vp],
     "t2s_wg_start": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
     "t2s_wg_in_cond_gate": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,
                             c_int, c_int, c_int, c_int, c_vp],

@@ -114,6 +114,14 @@ int t2s_small_logdet_inv_batch(const t2s_small_mat_job* jobs, int n_jobs, float 
     return T2S_OK;
 }
 
+int t2s_small_logdet_inv_batch_host(const t2s_small_mat_job* host_jobs, int n_jobs, float scale, void* stream) {
+    if (!host_jobs || n_jobs <= 0 || n_jobs > 16) return T2S_EINVAL;
+    for (int i = 0; i < n_jobs; ++i)
+        if (!host_jobs[i].W || host_jobs[i].n <= 0 || host_jobs[i].n > 16) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_small_logdet_batch_host((const SmallMatJob*)host_jobs, n_jobs, scale, (hipStream_t)stream));
+    return T2S_OK;
+}
+
 int t2s_wg_start(const float* z, const float* w, const float* bias, int B, int n_group, int c_off, int n_half, int C,
                  int L, int Lp, int halo, void* X_hi, void* X_lo, void* stream) {
     if (!z || !w || !bias || !X_hi || !X_lo) return T2S_EINVAL;

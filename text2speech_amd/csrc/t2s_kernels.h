@@ -92,6 +92,7 @@ hipError_t t2s_launch_convinv(float* z, const float* W, int B, int n_group, int 
                               hipStream_t stream);
 struct SmallMatJob { const float* W; float* logdet_out; float* inv_out; long n; };   // mirrors t2s_small_mat_job
 hipError_t t2s_launch_small_logdet_batch(const SmallMatJob* jobs, int n_jobs, float scale, hipStream_t stream);
+hipError_t t2s_launch_small_logdet_batch_host(const SmallMatJob* host_jobs, int n_jobs, float scale, hipStream_t stream);
 hipError_t t2s_launch_small_logdet_inv(const float* W, int n, float scale, float* logdet_out, float* inv_out,
                                        hipStream_t stream);
 hipError_t t2s_launch_start(const float* z, const float* w, const float* bias, int B, int n_group, int c_off,

@@ -5,6 +5,8 @@
 #include "t2s_common.h"
 #include "t2s_kernels.h"
 
+#include <string.h>
+
 // ------------------------------------------------------------------------------------------------
 // weight_norm (w = v * g / ||v||, reference glow.py:123,138,142,151) fused with the packing of the
 // effective weight into the GEMM's A operand: split to (hi, lo) bf16, K reordered tap-major, rows
@@ -430,10 +432,7 @@ __global__ void small_logdet_inv_kernel(const float* W, int n, float scale, floa
             for (int j = 0; j < n; ++j) inv_out[i * n + j] = (float)a[i][n + j];
 }
 // all flows in one launch: block k handles matrix k (device table of pointers / sizes)
-__global__ void small_logdet_batch_kernel(const SmallMatJob* jobs, float scale) {
-    __shared__ double a[16][32];
-    if (threadIdx.x != 0) return;
-    const SmallMatJob j = jobs[blockIdx.x];
+static __device__ __forceinline__ void small_logdet_one(const SmallMatJob& j, float scale, double (*a)[32]) {
     const int n = (int)j.n;
     for (int i = 0; i < n; ++i)
         for (int c = 0; c < n; ++c) {
@@ -468,8 +467,29 @@ __global__ void small_logdet_batch_kernel(const SmallMatJob* jobs, float scale) 
         for (int i = 0; i < n; ++i)
             for (int c = 0; c < n; ++c) j.inv_out[i * n + c] = (float)a[i][n + c];
 }
+__global__ void small_logdet_batch_kernel(const SmallMatJob* jobs, float scale) {
+    __shared__ double a[16][32];
+    if (threadIdx.x != 0) return;
+    small_logdet_one(jobs[blockIdx.x], scale, a);
+}
+// the same with the table passed BY VALUE (<= 16 matrices): no device table, so no host -> device copy per forward - a
+// pageable copy blocks the host until the stream has drained, and the GPU then idles while the host prepares the next call
+struct SmallMatJobs16 { SmallMatJob j[16]; };
+__global__ void small_logdet_batch_val_kernel(const SmallMatJobs16 jobs, float scale) {
+    __shared__ double a[16][32];
+    if (threadIdx.x != 0) return;
+    small_logdet_one(jobs.j[blockIdx.x], scale, a);
+}
 hipError_t t2s_launch_small_logdet_batch(const SmallMatJob* jobs, int n_jobs, float scale, hipStream_t stream) {
     hipLaunchKernelGGL(small_logdet_batch_kernel, dim3(n_jobs), dim3(64), 0, stream, jobs, scale);
+    return hipGetLastError();
+}
+hipError_t t2s_launch_small_logdet_batch_host(const SmallMatJob* host_jobs, int n_jobs, float scale, hipStream_t stream) {
+    if (n_jobs > 16) return hipErrorInvalidValue;
+    SmallMatJobs16 v;
+    memset(&v, 0, sizeof(v));
+    for (int i = 0; i < n_jobs; ++i) v.j[i] = host_jobs[i];
+    hipLaunchKernelGGL(small_logdet_batch_val_kernel, dim3(n_jobs), dim3(64), 0, stream, v, scale);
     return hipGetLastError();
 }
 

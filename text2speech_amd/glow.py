@@ -11,6 +11,7 @@ eager-PyTorch fallback: without the library, or off-GPU, the calls raise.
 
 Reference lines are cited per method.
 """
+import ctypes
 import math
 
 import os
@@ -345,15 +346,21 @@ class _Engine:
         Ws = [_f32c(m.convinv[k].conv.weight) for k in range(m.n_flows)]
         keep = list(Ws)
         # B*L*logdet(W_k) of all flows in one launch (reference glow.py:100)
+        use_val = m.n_flows <= 16          # the table travels as a kernel argument: no per-forward host -> device copy
         jobs = torch.tensor([[Ws[k].data_ptr(), log_det.data_ptr() + 4 * k, 0, self._flow_geom(k)[1]]
-                             for k in range(m.n_flows)], dtype=torch.int64).to(dev)
+                             for k in range(m.n_flows)], dtype=torch.int64)
+        if not use_val:
+            jobs = jobs.to(dev)
         keep.append(jobs)
         side.wait_stream(main)               # inputs, the job table and earlier users of the workspace are ordered before
         with torch.cuda.stream(side):
             st2 = _lib.current_stream()
             self._upsample(mel, B, L, w)
             _lib.call("t2s_wg_audio_squeeze", _lib.ptr(audio32), _lib.ptr(z), B, T, G, L, 0, st2)
-            _lib.call("t2s_small_logdet_inv_batch", _lib.ptr(jobs), m.n_flows, float(B * L), st2)
+            if use_val:
+                _lib.call("t2s_small_logdet_inv_batch_host", ctypes.c_void_p(jobs.data_ptr()), m.n_flows, float(B * L), st2)
+            else:
+                _lib.call("t2s_small_logdet_inv_batch", _lib.ptr(jobs), m.n_flows, float(B * L), st2)
         self.pack_weights(dev, force=True)
         main.wait_stream(side)
         st = _lib.current_stream()
