@@ -10,6 +10,8 @@ Memory model (sized for 288 GB HBM3E): every WN layer's input, gate output, tanh
 resident as split-bf16 planes (~140 MB per layer, 13.4 GB per step at 8 x 16000) instead of being
 recomputed.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -166,11 +168,26 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
     if g_log_det is not None:
         g_log_det = g_log_det.to(torch.float32).contiguous()
     xc, sc = g["Cpad"] // 32, g["Spad"] // 32
+    # Two streams.  Per layer the weight-gradient work (seven HBM-bound plane transposes, two weight-gradient GEMMs, three
+    # weight-norm reductions) never feeds the data-gradient chain (gate backward -> W_in^T / W_cond^T accumulate), so it runs
+    # on a side stream; events guard the three d-plane buffers the two share (DX / DS: transposed before the chain updates
+    # them in place; DP: transposed before the next layer's gate backward overwrites it).  The time-major planes and the
+    # split-K slabs belong to the side stream alone.
+    main_s = torch.cuda.current_stream(dev)
+    two = not os.environ.get("T2S_WG_BWD_ONE_STREAM")
+    side_s = getattr(eng, "bwd_side_stream", None)
+    if two and side_s is None:
+        side_s = eng.bwd_side_stream = torch.cuda.Stream(device=dev)
+    if not two:
+        side_s = main_s
+    st2 = _lib.c_vp(side_s.cuda_stream)
+    side_s.wait_stream(main_s)
+    ev_dx_ready, ev_tdp_done = None, None
     # conditioning rows + the ones row of the in/cond weight-gradient GEMM are the same for every layer
     _lib.call("t2s_plane_transpose", _ptr(ts.S_planes[0]), _ptr(ts.S_planes[1]), B, sc, sc, Lp, 0, _ptr(ts.TM_x[0]),
-              _ptr(ts.TM_x[1]), ts.N2pad, ks * C, st)
-    _lib.call("t2s_tm_ones_row", _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), B, Lp, halo, L, ts.N2pad, ts.N2 - 1, st)
-    _lib.call("t2s_tm_ones_row", _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]), B, Lp, halo, L, ts.N1pad, C, st)
+              _ptr(ts.TM_x[1]), ts.N2pad, ks * C, st2)
+    _lib.call("t2s_tm_ones_row", _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), B, Lp, halo, L, ts.N2pad, ts.N2 - 1, st2)
+    _lib.call("t2s_tm_ones_row", _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]), B, Lp, halo, L, ts.N1pad, C, st2)
     dsp_init = 1
     keep = []
 
@@ -201,7 +218,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
 
     bucket = None
 
-    def wn_grads(conv, P, nsplit, Prows, Pcols, col_off, tap_stride, col_bias, O, Cin, Kt, with_bias=True):
+    def wn_grads(conv, P, nsplit, Prows, Pcols, col_off, tap_stride, col_bias, O, Cin, Kt, with_bias=True, stream=None):
         v, gg = _vg(conv)
         v32 = _f32c(v)
         g32 = None if gg is None else _f32c(gg)
@@ -210,7 +227,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         db = bucket.take(O) if with_bias else None
         keep.extend([v32, g32])
         _lib.call("t2s_wn_backward", _ptr(P), nsplit, Prows, Pcols, 0, col_off, tap_stride, col_bias, _ptr(v32), _ptr(g32), O,
-                  Cin, Kt, _ptr(dv), _ptr(dg), _ptr(db), 0, st)
+                  Cin, Kt, _ptr(dv), _ptr(dg), _ptr(db), 0, st if stream is None else stream)
         if gg is None:
             grads[id(conv.weight)] = dv
         else:
@@ -259,41 +276,54 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             rows2 = C if last else 2 * C
             Mrs = _lib.padded_rows(rows2)
             conv_rs, conv_in, conv_c = wn.res_skip_layers[i], wn.in_layers[i], wn.cond_layers[i]
-            # 1. d_pre = gate'(T,G) * (W_rs^T [dx ; dS])
+            # 1. d_pre = gate'(T,G) * (W_rs^T [dx ; dS])                                                     [main]
             pk = fl["layers"][i]
             v_rs, s_rs = scale_of(conv_rs, pk["s_rs"])
             _lib.call("t2s_pack_transposed", _ptr(v_rs), _ptr(s_rs), rows2, C, 1, 0, rows2, ts.Mc, 0, _ptr(ts.A_rsT[0]),
                       _ptr(ts.A_rsT[1]), st)
+            ev_in = torch.cuda.Event()          # DX / DS of this layer are final (last written on the main stream)
+            ev_in.record(main_s)
+            if ev_tdp_done is not None:
+                main_s.wait_event(ev_tdp_done)  # the side stream has transposed the previous layer's d_pre out of DP
             _lib.call("t2s_wg_bwd_gate_dgrad", _ptr(ts.A_rsT[0]), _ptr(ts.A_rsT[1]), _ptr(zb),
                       None if last else _ptr(ts.DX[0]), None if last else _ptr(ts.DX[1]), _ptr(ts.DS[0]), _ptr(ts.DS[1]),
                       _ptr(sv["T"][0]), _ptr(sv["T"][1]), _ptr(sv["G"][0]), _ptr(sv["G"][1]), _ptr(ts.DP[0]), _ptr(ts.DP[1]),
                       B, C, L, Lp, halo, ts.Mc, st)
-            # 2. dW_rs = [dx ; dS] . acts^T  (+ bias column)
+            ev_dp = torch.cuda.Event()
+            ev_dp.record(main_s)
+            # 2. dW_rs = [dx ; dS] . acts^T  (+ bias column)                                                 [side]
+            side_s.wait_event(ev_in)
             if not last:
                 _lib.call("t2s_plane_transpose", _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, xc, xc, Lp, 0, _ptr(ts.TM_drs[0]),
-                          _ptr(ts.TM_drs[1]), Mrs, 0, st)
+                          _ptr(ts.TM_drs[1]), Mrs, 0, st2)
             _lib.call("t2s_plane_transpose", _ptr(ts.DS[0]), _ptr(ts.DS[1]), B, xc, xc, Lp, 0, _ptr(ts.TM_drs[0]),
-                      _ptr(ts.TM_drs[1]), Mrs, 0 if last else C, st)
+                      _ptr(ts.TM_drs[1]), Mrs, 0 if last else C, st2)
+            ev_tdrs = torch.cuda.Event()        # DX / DS have been read: the chain may update DX in place
+            ev_tdrs.record(side_s)
             _lib.call("t2s_plane_transpose", _ptr(sv["A"][0]), _ptr(sv["A"][1]), B, xc, xc, Lp, 0, _ptr(ts.TM_act[0]),
-                      _ptr(ts.TM_act[1]), ts.N1pad, 0, st)
+                      _ptr(ts.TM_act[1]), ts.N1pad, 0, st2)
             _lib.call("t2s_wgrad_gemm_flat", _ptr(ts.TM_drs[0]), _ptr(ts.TM_drs[1]), _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]), _ptr(zb),
-                      _ptr(ts.P1), B, rows2, ts.N1, Mrs, ts.N1pad, nt, ts.k0, ts.k1, ts.ks1, st)
-            wn_grads(conv_rs, ts.P1, ts.ks1, rows2, ts.N1, 0, 0, C, rows2, C, 1)
-            # 3. dW_in, dW_cond = d_pre . [x taps | spect | 1]^T
+                      _ptr(ts.P1), B, rows2, ts.N1, Mrs, ts.N1pad, nt, ts.k0, ts.k1, ts.ks1, st2)
+            wn_grads(conv_rs, ts.P1, ts.ks1, rows2, ts.N1, 0, 0, C, rows2, C, 1, stream=st2)
+            # 3. dW_in, dW_cond = d_pre . [x taps | spect | 1]^T                                             [side]
+            side_s.wait_event(ev_dp)
             _lib.call("t2s_plane_transpose", _ptr(ts.DP[0]), _ptr(ts.DP[1]), B, 2 * xc, 2 * xc, Lp, 0, _ptr(ts.TM_dp[0]),
-                      _ptr(ts.TM_dp[1]), ts.M2pad, 0, st)
+                      _ptr(ts.TM_dp[1]), ts.M2pad, 0, st2)
+            ev_tdp_done = torch.cuda.Event()
+            ev_tdp_done.record(side_s)
             d = 2 ** i
             for tap in range(ks):
                 _lib.call("t2s_plane_transpose", _ptr(sv["X"][0]), _ptr(sv["X"][1]), B, xc, xc, Lp, (tap - ks // 2) * d,
-                          _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), ts.N2pad, tap * C, st)
+                          _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), ts.N2pad, tap * C, st2)
             _lib.call("t2s_wgrad_gemm_flat", _ptr(ts.TM_dp[0]), _ptr(ts.TM_dp[1]), _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), _ptr(zb),
-                      _ptr(ts.P2), B, 2 * C, ts.N2, ts.M2pad, ts.N2pad, nt, ts.k0, ts.k1, ts.ks2, st)
-            wn_grads(conv_in, ts.P2, ts.ks2, 2 * C, ts.N2, 0, C, ts.N2 - 1, 2 * C, C, ks)
-            wn_grads(conv_c, ts.P2, ts.ks2, 2 * C, ts.N2, ks * C, 0, ts.N2 - 1, 2 * C, n_cond, 1)
-            # 4. dx (+)= W_in^T (*) d_pre ;  d_spect += W_cond^T d_pre
+                      _ptr(ts.P2), B, 2 * C, ts.N2, ts.M2pad, ts.N2pad, nt, ts.k0, ts.k1, ts.ks2, st2)
+            wn_grads(conv_in, ts.P2, ts.ks2, 2 * C, ts.N2, 0, C, ts.N2 - 1, 2 * C, C, ks, stream=st2)
+            wn_grads(conv_c, ts.P2, ts.ks2, 2 * C, ts.N2, ks * C, 0, ts.N2 - 1, 2 * C, n_cond, 1, stream=st2)
+            # 4. dx (+)= W_in^T (*) d_pre ;  d_spect += W_cond^T d_pre                                       [main]
             v_in, s_in = scale_of(conv_in, pk["s_in"])
             _lib.call("t2s_pack_transposed", _ptr(v_in), _ptr(s_in), 2 * C, C, ks, 1, 2 * C, ts.Mc, 0, _ptr(ts.A_inT[0]),
                       _ptr(ts.A_inT[1]), st)
+            main_s.wait_event(ev_tdrs)
             _lib.call("t2s_conv_accumulate", _ptr(ts.A_inT[0]), _ptr(ts.A_inT[1]), _ptr(zb), _ptr(ts.DP[0]), _ptr(ts.DP[1]),
                       _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, 2 * C, C, ks, d, 1 if last else 0, L, Lp, halo, ts.Mc, st)
             v_c, s_c = scale_of(conv_c, pk["s_cond"])
@@ -325,6 +355,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         _lib.call("t2s_wg_convinv", _ptr(dz), _ptr(WT), B, G, c_off, n_rem, L, st)            # dz <- W^T dz
         grads[id(m.convinv[k].conv.weight)] = dW
         keep.extend([Wk, Winv, WT, d_out])
+        main_s.wait_stream(side_s)          # this flow's weight gradients (side stream) are in the bucket
         bucket.ship()
     # ---- upsampler ----
     up = m.upsample
