@@ -14,6 +14,7 @@ What it restates, and where parity is pinned:
     librosa is an unpinned, un-vendored dependency: restated from its published algorithm, PARITY UNPINNED for the
     filterbank values (SURVEY.md 8c says the same).  mel_spectrogram on top of it (utils/layers.py:63-79) is a matmul and
     log(clamp(x, 1e-5)) (utils/audio_processing.py:78-84).
+  * griffin_lim <- utils/audio_processing.py:50-72 (alternating projections over the two pinned transforms).
   * denoise <- waveglow/denoiser.py:10-40 (bias spectrum of the vocoder at zero input, spectral subtraction, inverse).
     The reference class hard-codes .cuda(); pinned through its two pinned pieces (transform, inverse).
 """
@@ -125,3 +126,12 @@ def denoise(audio, bias_spec, fwd_basis, inv_basis, strength=0.1, filter_length=
     mag, ph = stft_transform(audio, fwd_basis, filter_length, hop_length)
     mag = torch.clamp(mag - bias_spec * strength, 0.0)
     return stft_inverse(mag, ph, inv_basis, filter_length, hop_length, win_length)
+
+
+def griffin_lim(magnitudes, angles, fwd_basis, inv_basis, n_iters=30, filter_length=1024, hop_length=256, win_length=1024):
+    """utils/audio_processing.py:50-72 with the initial phase given explicitly (the reference draws it with numpy)."""
+    signal = stft_inverse(magnitudes, angles, inv_basis, filter_length, hop_length, win_length).squeeze(1)
+    for _ in range(n_iters):
+        _, angles = stft_transform(signal, fwd_basis, filter_length, hop_length)
+        signal = stft_inverse(magnitudes, angles, inv_basis, filter_length, hop_length, win_length).squeeze(1)
+    return signal

@@ -90,3 +90,24 @@ def test_denoiser_vs_oracle():
     want = A.denoise(audio, bias_o, fwd, inv, strength=0.1)
     assert tuple(got.shape) == tuple(want.shape) == (2, 1, 8192)
     assert _rel(got, want) < 1e-3
+
+
+def test_griffin_lim_vs_oracle():
+    """Five alternating-projection iterations from the same initial phase (the iteration amplifies rounding differences, so the
+    comparison is on the spectrogram the result reproduces, plus a loose waveform check)."""
+    from oracle import audio_oracle as A
+    from text2speech_amd.audio import STFT, griffin_lim
+    _lib.load()
+    gen = torch.Generator().manual_seed(17)
+    audio = torch.rand(1, 4096, generator=gen) * 1.2 - 0.6
+    fwd, inv = A.stft_basis(1024, 256, 1024)
+    mag, _ = A.stft_transform(audio, fwd)
+    ang = torch.rand(mag.shape, generator=gen) * 6.28 - 3.14
+    want = A.griffin_lim(mag, ang, fwd, inv, n_iters=5)
+    st = STFT(1024, 256, 1024).to(DEV)
+    got = griffin_lim(mag.to(DEV), st, n_iters=5, angles=ang.to(DEV))
+    assert tuple(got.shape) == tuple(want.shape)
+    assert _rel(got, want) < 2e-2
+    mg, _ = st.transform(got)
+    mw, _ = A.stft_transform(want, fwd)
+    assert _rel(mg, mw) < 5e-3

@@ -19,7 +19,8 @@ from scipy.signal import get_window
 
 from . import _lib
 
-__all__ = ["STFT", "TacotronSTFT", "Denoiser", "mel_filterbank", "dynamic_range_compression", "dynamic_range_decompression"]
+__all__ = ["STFT", "TacotronSTFT", "Denoiser", "griffin_lim", "mel_filterbank", "dynamic_range_compression",
+           "dynamic_range_decompression"]
 
 
 def _ru(a, b):
@@ -60,6 +61,20 @@ def mel_filterbank(sr, n_fft, n_mels=80, fmin=0.0, fmax=None):
     tri = np.clip(np.minimum(rise, fall), 0.0, None)
     tri *= (2.0 / (edges[2:] - edges[:-2]))[:, None]
     return tri.astype(np.float32)
+
+
+def griffin_lim(magnitudes, stft_fn, n_iters=30, angles=None):
+    """Phase reconstruction by alternating projections (reference utils/audio_processing.py:50-72): every transform and
+    inverse runs on the device.  `angles` (radians, same shape as `magnitudes`) replaces the reference's random initial phase
+    when given, which makes the result reproducible."""
+    _need_cuda(magnitudes, "griffin_lim")
+    if angles is None:
+        angles = torch.rand(magnitudes.shape, device=magnitudes.device, dtype=torch.float32) * (2 * np.pi) - np.pi
+    signal = stft_fn.inverse(magnitudes, angles).squeeze(1)
+    for _ in range(n_iters):
+        _, angles = stft_fn.transform(signal)
+        signal = stft_fn.inverse(magnitudes, angles).squeeze(1)
+    return signal
 
 
 class STFT(torch.nn.Module):
