@@ -385,6 +385,13 @@ typedef struct t2s_taco_bptt {
 } t2s_taco_bptt;
 int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream);
 
+/* Tacotron2Loss (tacotron/loss_function.py:3-18): out[0] = mean((mel-target)^2) + mean((post-target)^2) + mean(BCEWithLogits(gate,
+ * gate_target)), out[1] = the two mel terms, out[2] = the gate term; d_mel / d_post / d_gate (each optional) receive the
+ * gradients for an upstream gradient of 1.  partial = scratch of 256*3 doubles (two-stage, order-independent reduction). */
+int t2s_taco_loss(const float* mel, const float* post, const float* target, size_t n_mel, const float* gate,
+                  const float* gate_target, size_t n_gate, float* d_mel, float* d_post, float* d_gate, void* partial,
+                  float* out, void* stream);
+
 typedef struct t2s_bn_bwd_args {
     const float *x, *mean, *var, *gamma, *beta; float eps;
     const float *dout_f32; const void *dout_hi, *dout_lo;

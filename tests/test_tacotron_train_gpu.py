@@ -162,3 +162,28 @@ def test_batch12_step_vs_oracle():
         worst.append((0.0 if diff < 2e-5 else _rel(got[n], v.grad), n))
     worst.sort(reverse=True)
     assert worst[0][0] < 5e-3, worst[:6]
+
+
+def test_tacotron2loss_matches_torch():
+    """Tacotron2Loss (csrc/loss_ops.hip) against the reference's formula in stock torch ops: value and the three gradients."""
+    from text2speech_amd.tacotron.loss_function import Tacotron2Loss
+    _lib.load()
+    gen = torch.Generator().manual_seed(3)
+    B, T = 5, 37
+    mel = torch.randn(B, 80, T, generator=gen)
+    post = torch.randn(B, 80, T, generator=gen)
+    gate = torch.randn(B, T, generator=gen) * 4
+    tgt = torch.randn(B, 80, T, generator=gen)
+    gt = (torch.rand(B, T, generator=gen) < 0.2).float()
+    a = [t.clone().to(DEV).requires_grad_(True) for t in (mel, post, gate)]
+    loss = Tacotron2Loss()([a[0], a[1], a[2], None], (tgt.to(DEV), gt.to(DEV)))
+    (loss * 1.7).backward()
+    b = [t.clone().double().requires_grad_(True) for t in (mel, post, gate)]
+    ref = torch.nn.functional.mse_loss(b[0], tgt.double()) + torch.nn.functional.mse_loss(b[1], tgt.double()) + \
+        torch.nn.functional.binary_cross_entropy_with_logits(b[2].view(-1, 1), gt.double().view(-1, 1))
+    (ref * 1.7).backward()
+    assert abs(float(loss) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+    for x, y in zip(a, b):
+        assert _rel(x.grad, y.grad) < 1e-6
+    with pytest.raises(Exception):
+        Tacotron2Loss()([mel, post, gate, None], (tgt, gt))          # host tensors: no CPU path

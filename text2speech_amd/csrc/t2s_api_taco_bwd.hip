@@ -168,6 +168,15 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
     return T2S_OK;
 }
 
+int t2s_taco_loss(const float* mel, const float* post, const float* target, size_t n_mel, const float* gate,
+                  const float* gate_target, size_t n_gate, float* d_mel, float* d_post, float* d_gate, void* partial,
+                  float* out, void* stream) {
+    if (!mel || !post || !target || !gate || !gate_target || !partial || !out || n_mel == 0 || n_gate == 0) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_taco_loss(mel, post, target, n_mel, gate, gate_target, n_gate, d_mel, d_post, d_gate,
+                                       (double*)partial, out, (hipStream_t)stream));
+    return T2S_OK;
+}
+
 int t2s_bn_bwd(const t2s_bn_bwd_args* p, void* stream) {
     if (!p || !p->x || !p->mean || !p->var || !p->gamma || !p->beta || !p->dgamma || !p->dbeta || !p->dx_hi ||
         !p->dx_lo || (!p->dout_f32 && (!p->dout_hi || !p->dout_lo)) || p->B <= 0 || p->C <= 0 || p->T <= 0)

@@ -73,3 +73,8 @@ hipError_t t2s_launch_rows_to_planes(const float* x, int B, int T, int C, int Lp
                                      hipStream_t stream);
 hipError_t t2s_launch_embedding_grad(const long* ids, const u16* D_hi, const u16* D_lo, int B, int T, int E, int V, int Lp,
                                      int halo, float* d_emb, hipStream_t stream);
+
+// loss_ops.hip
+hipError_t t2s_launch_taco_loss(const float* mel, const float* post, const float* target, size_t n_mel, const float* gate,
+                                const float* gate_t, size_t n_gate, float* d_mel, float* d_post, float* d_gate, double* partial,
+                                float* out, hipStream_t stream);

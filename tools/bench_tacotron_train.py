@@ -7,13 +7,13 @@ import sys
 import time
 
 import torch
-import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from text2speech_amd import synth  # noqa: E402
 from text2speech_amd.optim import FusedAdam  # noqa: E402
 from text2speech_amd.tacotron import Tacotron  # noqa: E402
+from text2speech_amd.tacotron.loss_function import Tacotron2Loss  # noqa: E402
 
 
 def main():
@@ -32,10 +32,12 @@ def main():
     ol = torch.full((B,), T_out, dtype=torch.long).cuda()
     inp = (text, il, mel, T_in, torch.zeros(B).cuda(), ol)
 
+    crit = Tacotron2Loss()
+
     def step():
         m.zero_grad(set_to_none=True)
         out = m(inp)
-        loss = F.mse_loss(out[0], mel) + F.mse_loss(out[1], mel) + F.binary_cross_entropy_with_logits(out[2].reshape(-1, 1), gate.reshape(-1, 1))
+        loss = crit(out, (mel, gate))                 # reference call: criterion(y_pred, y), train.py:219-221
         loss.backward()
         opt.step()
         return loss
