@@ -392,6 +392,13 @@ int t2s_taco_loss(const float* mel, const float* post, const float* target, size
                   const float* gate_target, size_t n_gate, float* d_mel, float* d_post, float* d_gate, void* partial,
                   float* out, void* stream);
 
+/* WaveGlowLoss (waveglow/glow.py:43-59): out[0] = (sum z^2 / (2 sigma^2) - sum_k sum log_s[k] - sum_k log_det[k]) / n_z.
+ * log_s / n_log_s are HOST arrays of n_flows (<= 16) device pointers / element counts, log_det a device array of n_flows
+ * floats.  d_z (optional) receives z / (sigma^2 n_z); the gradients w.r.t. log_s and log_det are the constant -1 / n_z.
+ * partial = scratch of 256*2 doubles. */
+int t2s_waveglow_loss(const float* z, size_t n_z, const float* const* log_s, const size_t* n_log_s, int n_flows,
+                      const float* log_det, float sigma, float* d_z, void* partial, float* out, void* stream);
+
 typedef struct t2s_bn_bwd_args {
     const float *x, *mean, *var, *gamma, *beta; float eps;
     const float *dout_f32; const void *dout_hi, *dout_lo;

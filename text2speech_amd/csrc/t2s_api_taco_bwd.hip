@@ -177,6 +177,17 @@ int t2s_taco_loss(const float* mel, const float* post, const float* target, size
     return T2S_OK;
 }
 
+int t2s_waveglow_loss(const float* z, size_t n_z, const float* const* log_s, const size_t* n_log_s, int n_flows,
+                      const float* log_det, float sigma, float* d_z, void* partial, float* out, void* stream) {
+    if (!z || !log_s || !n_log_s || !log_det || !partial || !out || n_z == 0 || n_flows <= 0 || n_flows > 16 || !(sigma > 0.f))
+        return T2S_EINVAL;
+    for (int k = 0; k < n_flows; ++k)
+        if (!log_s[k]) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_waveglow_loss(z, n_z, log_s, n_log_s, n_flows, log_det, sigma, d_z, (double*)partial, out,
+                                           (hipStream_t)stream));
+    return T2S_OK;
+}
+
 int t2s_bn_bwd(const t2s_bn_bwd_args* p, void* stream) {
     if (!p || !p->x || !p->mean || !p->var || !p->gamma || !p->beta || !p->dgamma || !p->dbeta || !p->dx_hi ||
         !p->dx_lo || (!p->dout_f32 && (!p->dout_hi || !p->dout_lo)) || p->B <= 0 || p->C <= 0 || p->T <= 0)

@@ -78,3 +78,6 @@ hipError_t t2s_launch_embedding_grad(const long* ids, const u16* D_hi, const u16
 hipError_t t2s_launch_taco_loss(const float* mel, const float* post, const float* target, size_t n_mel, const float* gate,
                                 const float* gate_t, size_t n_gate, float* d_mel, float* d_post, float* d_gate, double* partial,
                                 float* out, hipStream_t stream);
+hipError_t t2s_launch_waveglow_loss(const float* z, size_t n_z, const float* const* log_s, const size_t* n_log_s, int n_flows,
+                                    const float* log_det, float sigma, float* d_z, double* partial, float* out,
+                                    hipStream_t stream);

@@ -22,9 +22,41 @@ import torch.nn.functional as F  # noqa: F401  (kept for API parity with the ref
 from . import _lib
 
 
+class _WaveGlowLossFn(torch.autograd.Function):
+    """loss = (sum z^2 / (2 sigma^2) - sum_k sum log_s_k - sum_k log_det_k) / numel(z) in one fused HIP pass
+    (csrc/loss_ops.hip); d/dz = z / (sigma^2 N) comes out of the same pass, d/dlog_s = d/dlog_det = -1/N."""
+
+    @staticmethod
+    def forward(ctx, sigma, n_flows, z, *rest):
+        log_s = [t.detach().to(torch.float32).contiguous() for t in rest[:n_flows]]
+        log_det = torch.stack([t.detach().to(torch.float32).reshape(()) for t in rest[n_flows:]])
+        zc = z.detach().to(torch.float32).contiguous()
+        dev = zc.device
+        d_z = torch.empty_like(zc) if z.requires_grad else None
+        partial = torch.empty(256 * 2, dtype=torch.float64, device=dev)
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        ptrs = (ctypes.c_void_p * n_flows)(*[t.data_ptr() for t in log_s])
+        counts = (ctypes.c_size_t * n_flows)(*[t.numel() for t in log_s])
+        _lib.call("t2s_waveglow_loss", _lib.ptr(zc), zc.numel(), ptrs, counts, n_flows, _lib.ptr(log_det), float(sigma),
+                  _lib.ptr(d_z), _lib.ptr(partial), _lib.ptr(out), _lib.current_stream())
+        ctx.d_z, ctx.n_flows, ctx.inv_n = d_z, n_flows, 1.0 / zc.numel()
+        ctx.meta = [(t.shape, t.requires_grad) for t in rest]
+        ctx.z_shape = z.shape
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        gz = None if ctx.d_z is None else (ctx.d_z * g).view(ctx.z_shape)
+        outs = []
+        for shape, need in ctx.meta:
+            # the constant -1/N times the upstream gradient, broadcast (a view, no kernel per flow)
+            outs.append((-(g * ctx.inv_n)).expand(shape) if need else None)
+        return (None, None, gz, *outs)
+
+
 class WaveGlowLoss(torch.nn.Module):
-    """Reference glow.py:43-59.  Scalar NLL of the flow output; the reductions
-    run on whatever device the outputs live on (tiny: <= B*8*L elements)."""
+    """Reference glow.py:43-59: scalar NLL of the flow output.  Tensors in HBM go through the fused HIP kernel
+    (t2s_waveglow_loss); host tensors (this class is also usable on the oracle's CPU outputs) use the same formula in torch ops."""
 
     def __init__(self, sigma=1.0):
         super().__init__()
@@ -32,6 +64,8 @@ class WaveGlowLoss(torch.nn.Module):
 
     def forward(self, model_output):
         z, log_s_list, log_det_W_list = model_output
+        if z.is_cuda and len(log_s_list) <= 16:
+            return _WaveGlowLossFn.apply(float(self.sigma), len(log_s_list), z, *log_s_list, *log_det_W_list)
         log_s_total = None
         log_det_W_total = None
         for i, log_s in enumerate(log_s_list):
