@@ -55,8 +55,8 @@ class _WaveGlowLossFn(torch.autograd.Function):
 
 
 class WaveGlowLoss(torch.nn.Module):
-    """Reference glow.py:43-59: scalar NLL of the flow output.  Tensors in HBM go through the fused HIP kernel
-    (t2s_waveglow_loss); host tensors (this class is also usable on the oracle's CPU outputs) use the same formula in torch ops."""
+    """Reference glow.py:43-59: scalar NLL of the flow output, computed by the fused HIP kernel t2s_waveglow_loss.  Like every
+    other entry point of this build it needs tensors in HBM; there is no CPU path (tests use oracle.waveglow_oracle's loss)."""
 
     def __init__(self, sigma=1.0):
         super().__init__()
@@ -64,17 +64,11 @@ class WaveGlowLoss(torch.nn.Module):
 
     def forward(self, model_output):
         z, log_s_list, log_det_W_list = model_output
-        if z.is_cuda and len(log_s_list) <= 16:
-            return _WaveGlowLossFn.apply(float(self.sigma), len(log_s_list), z, *log_s_list, *log_det_W_list)
-        log_s_total = None
-        log_det_W_total = None
-        for i, log_s in enumerate(log_s_list):
-            s = torch.sum(log_s)
-            log_s_total = s if log_s_total is None else log_s_total + s
-            d = log_det_W_list[i]
-            log_det_W_total = d if log_det_W_total is None else log_det_W_total + d
-        loss = torch.sum(z * z) / (2 * self.sigma * self.sigma) - log_s_total - log_det_W_total
-        return loss / (z.size(0) * z.size(1) * z.size(2))
+        if not z.is_cuda:
+            raise _lib.T2SError("WaveGlowLoss (MI355X build) needs tensors in HBM; there is no CPU path")
+        if len(log_s_list) > 16 or len(log_s_list) != len(log_det_W_list):
+            raise ValueError("WaveGlowLoss: at most 16 flows, one log_det_W per log_s")
+        return _WaveGlowLossFn.apply(float(self.sigma), len(log_s_list), z, *log_s_list, *log_det_W_list)
 
 
 class Invertible1x1Conv(torch.nn.Module):
