@@ -187,3 +187,40 @@ def test_tacotron2loss_matches_torch():
         assert _rel(x.grad, y.grad) < 1e-6
     with pytest.raises(Exception):
         Tacotron2Loss()([mel, post, gate, None], (tgt, gt))          # host tensors: no CPU path
+
+
+def test_backward_is_bitwise_reproducible():
+    """The BPTT runs on three HIP streams (decoder-cell chain, attention chain, location-conv backward) and uses no atomics:
+    the same step three times must give bit-identical gradients."""
+    from text2speech_amd.tacotron import Tacotron, Tacotron2Loss
+    _lib.load()
+    B, T_in, T_out = 10, 36, 30
+    gen = torch.Generator().manual_seed(8)
+    in_len = torch.tensor([T_in - i for i in range(B)])
+    out_len = torch.tensor([T_out - i for i in range(B)])
+    text = torch.randint(2, 80, (B, T_in), generator=gen)
+    mel_t = torch.randn(B, 80, T_out, generator=gen)
+    gate_t = torch.zeros(B, T_out)
+    for b in range(B):
+        text[b, in_len[b]:] = 0
+        mel_t[b, :, out_len[b]:] = 0
+        gate_t[b, out_len[b] - 1:] = 1
+    bern = lambda *s: (torch.rand(*s, generator=gen) < 0.5).to(torch.uint8)
+    tm = {"enc": [bern(B, 512, T_in) for _ in range(3)], "att": bern(T_out, B, 1024), "dec": bern(T_out, B, 1024),
+          "post": [bern(B, 512, T_out) for _ in range(4)] + [bern(B, 80, T_out)]}
+    pm = bern(T_out + 1, B, 2, 256)
+    m = Tacotron(HP, 80, num_speakers=2)
+    m.load_state_dict(synth.tacotron_state(), strict=True)
+    m = m.to(DEV).train()
+    crit = Tacotron2Loss()
+    runs = []
+    for _ in range(3):
+        m.load_state_dict(synth.tacotron_state(), strict=True)       # BatchNorm running statistics back to the start
+        m.zero_grad(set_to_none=True)
+        out = m((text.to(DEV), in_len.to(DEV), mel_t.to(DEV), int(in_len.max()), torch.zeros(B, device=DEV), out_len.to(DEV)),
+                prenet_masks=pm, train_masks=tm)
+        crit(out, (mel_t.to(DEV), gate_t.to(DEV))).backward()
+        torch.cuda.synchronize()
+        runs.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    for n in runs[0]:
+        assert torch.equal(runs[0][n], runs[1][n]) and torch.equal(runs[0][n], runs[2][n]), n
