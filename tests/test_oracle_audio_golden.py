@@ -73,3 +73,20 @@ def test_mel_spectrogram_and_denoise_shapes():
     # zero strength = plain reconstruction
     out0 = A.denoise(audio, bias, fwd, inv, strength=0.0)
     assert _rel(out0[:, 0, 1024:-1024], audio[:, 1024:-1024]) < 1e-4
+
+
+def test_product_filterbank_and_bases_match_oracle_on_cpu():
+    """Host-side construction in text2speech_amd/audio.py (mel filterbank, windowed Fourier bases) against the oracle's own
+    restatement - no GPU involved; every call that would compute raises without one."""
+    from text2speech_amd.audio import STFT, TacotronSTFT, mel_filterbank
+    for sr, n_fft, n_mels, fmin, fmax in [(22050, 1024, 80, 0.0, 8000.0), (16000, 512, 40, 50.0, 7600.0)]:
+        assert np.abs(mel_filterbank(sr, n_fft, n_mels, fmin, fmax) - A.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)).max() < 1e-7
+    st = STFT(1024, 256, 1024)
+    fwd, inv = A.stft_basis(1024, 256, 1024)
+    assert torch.equal(st.forward_basis, fwd) and torch.equal(st.inverse_basis, inv)
+    ts = TacotronSTFT(1024, 256, 1024, 80, 22050, 0.0, 8000.0)
+    assert tuple(ts.mel_basis.shape) == (80, 513)
+    with pytest.raises(RuntimeError):
+        st.transform(torch.zeros(1, 4096))            # host tensor: there is no CPU path
+    with pytest.raises(RuntimeError):
+        ts.mel_spectrogram(torch.zeros(1, 4096))
