@@ -383,6 +383,10 @@ typedef struct t2s_taco_bptt {
     float *dctx_all;                                    /* optional [T_out][B][enc]: every step's d_ctx; then d_memory is not
                                                          * touched by the loop (deferred, see t2s_att_bwd.dctx_out) */
 } t2s_taco_bptt;
+/* Launch sequencing only.  Unless T2S_BPTT_ONE_STREAM is set, the decoder-cell chain and the location-conv part of the
+ * attention backward run on two library-owned non-blocking streams (created on first use on the current device, kept for the
+ * life of the process), ordered against `stream` with events; everything this call enqueues is complete, as seen from
+ * `stream`, once the call's last wait has been passed.  Not re-entrant across host threads for the same device. */
 int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream);
 
 /* Tacotron2Loss (tacotron/loss_function.py:3-18): out[0] = mean((mel-target)^2) + mean((post-target)^2) + mean(BCEWithLogits(gate,
