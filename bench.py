@@ -7,35 +7,81 @@ including the per-forward weight-norm recompute + weight packing the reference a
 (torch.nn.utils.weight_norm hooks, reference glow.py:123-151).
 
     python bench.py --gpus N --steps K --warmup W
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; the forward pass of
-independent batches needs no collective, so ranks only meet at the timing barriers ("weak" scaling).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused
-in+cond+gate GEMM), timed live with HIP events on the launch stream; `cpu_baseline` is the CPU
-oracle (a port of the reference's torch op sequence) timed on this host at N=1.
+For N > 1 either the driver launches one rank per GPU with torch.distributed.run, or - when the
+command above is run directly (no RANK in the environment) - this script starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process before it
+touches the GPU and exits with the child's code (the reference ships the same kind of launcher,
+waveglow/distributed.py:145-170).  The forward pass of independent batches needs no collective, so
+ranks only meet at the timing barriers ("weak" scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fused in+cond+gate GEMM),
+timed live with HIP events on the launch stream; `cpu_baseline` is the CPU oracle (a port of the
+reference's torch op sequence) timed on this host at N=1 with BASELINE.md section 4's protocol.
+Extra blocks on the same line: `tacotron` (mel-frames/s, the second half of BASELINE.json's metric),
+`waveglow_train` / `tacotron_train` (BASELINE configs[3] / configs[1] train steps at N=1) and, at
+N > 1, `waveglow_train_dp` (the data-parallel train step over RCCL, BASELINE configs[3]).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from text2speech_amd import _lib, synth  # noqa: E402
-from text2speech_amd.glow import WaveGlow  # noqa: E402
-
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s HBM3E
+WG_FWD_FLOP_PER_SAMPLE = 65.36e6  # SURVEY.md 8d: 8.3666 TFLOP per 8 x 16000 forward
+TACO_FWD_FLOP_PER_FRAME = 52.1e6  # SURVEY.md 8d: 1.334 TFLOP per 32 x 800 teacher-forced forward
+GEMM_PMC = "r02_pmc_traffic.json"  # profiles/: HBM-side bytes per launch of the gate GEMM (separate --pmc passes)
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--segment", type=int, default=16000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tacotron", action="store_true", help="skip the Tacotron mel-frames/s block (N=1 only)")
+    ap.add_argument("--no-train", action="store_true", help="skip the train-step blocks")
+    ap.add_argument("--mode", choices=["forward", "train"], default="forward",
+                    help="forward: the headline metric (default); train: value = zero_grad+forward+loss+backward+Adam, "
+                         "data-parallel over RCCL when launched with N > 1 ranks (BASELINE configs[3])")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start the N ranks as a child process tree.  Runs before this
+    process has made any GPU call; it never replaces itself (exec of a GPU-initialised process is not allowed on this pool)."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("no RANK in the environment: launching %d ranks: %s" % (args.gpus, " ".join(cmd[1:])))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 def usable_cores():
-    """CPU cores this process may really use: min(affinity, cgroup quota), not the host's core count."""
-    n = os.cpu_count() or 1
+    """(threads this process may really use, os.cpu_count(), why): min(os.cpu_count(), affinity mask, cgroup CPU quota).
+    No other cap: oversubscribing a cgroup quota makes the torch CPU path slower, not faster."""
+    total = os.cpu_count() or 1
+    n, why = total, "os.cpu_count()"
     try:
-        n = min(n, len(os.sched_getaffinity(0)))
+        aff = len(os.sched_getaffinity(0))
+        if aff < n:
+            n, why = aff, "sched_getaffinity"
     except AttributeError:
         pass
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
@@ -43,45 +89,61 @@ def usable_cores():
             txt = open(path).read().split()
             if path.endswith("cpu.max"):
                 if txt[0] != "max":
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+                    q = max(1, int(int(txt[0]) / int(txt[1])))
+                    if q < n:
+                        n, why = q, "cgroup cpu.max"
             else:
                 q = int(txt[0])
                 if q > 0:
                     per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                    n = min(n, max(1, q // per))
+                    if max(1, q // per) < n:
+                        n, why = max(1, q // per), "cgroup cfs quota"
         except (OSError, ValueError, IndexError):
             pass
-    return min(n, 16) if os.environ.get("T2S_BENCH_ALL_CORES") is None else n
+    return n, total, why
 
 
-def log(msg):
-    print("[bench] " + msg, file=sys.stderr, flush=True)
-
-
-def cpu_baseline(cfg, sd, sample_batch=2, n_samples=16000, reps=3):
-    """The oracle (oracle/waveglow_oracle.py, kind "port") on the host cores, bounded sample."""
+def cpu_baseline(cfg, sd, batch, n_samples, reps=5):
+    """the oracle (oracle/waveglow_oracle.py, kind "port": the reference's torch op sequence) on the
+    host cores, fp32, no_grad, the SAME 8 x 16000 batch shape as the GPU step, one same-shape warm-up call, median of 5."""
+    import torch
     from oracle import waveglow_oracle as O
-    cores = usable_cores()
+    from text2speech_amd import synth
+    cores, total, why = usable_cores()
     torch.set_num_threads(cores)
-    log("cpu baseline on %d threads" % cores)
-    mel, audio = synth.waveglow_inputs(sample_batch, n_samples, seed=31)
+    log("cpu baseline on %d threads (%s; host reports %d)" % (cores, why, total))
+    mel, audio = synth.waveglow_inputs(batch, n_samples, seed=31)
     times = []
     with torch.no_grad():
-        O.waveglow_forward(sd, cfg, mel[:1, :, :9], audio[:1, :2048])     # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        O.waveglow_forward(sd, cfg, mel, audio)                              # warm-up, same shape
+        log("cpu baseline warm-up %.2f s" % (time.perf_counter() - t0))
         for _ in range(reps):
             t0 = time.perf_counter()
             O.waveglow_forward(sd, cfg, mel, audio)
             times.append(time.perf_counter() - t0)
             log("cpu baseline rep %.2f s" % times[-1])
     t = sorted(times)[len(times) // 2]
-    return {"value": sample_batch * n_samples / t, "unit": "audio samples/s", "cores": cores, "kind": "port",
-            "sample": "oracle forward on batch %d x %d (1/%d of the GPU batch), median of %d, fp32 torch CPU ops"
-                      % (sample_batch, n_samples, 8 // sample_batch, reps)}
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": batch * n_samples / t, "unit": "audio samples/s", "cores": cores, "kind": "port",
+            "sample": "oracle forward on the full batch %d x %d, one same-shape warm-up then the median of %d calls "
+                      "(%.2f s each), fp32 torch CPU ops, %d threads = min(os.cpu_count()=%d, affinity, cgroup quota) [%s]"
+                      % (batch, n_samples, reps, t, cores, total, why),
+            "cpu_model": model, "host_cpu_count": total}
 
 
 def tacotron_metrics(dev):
     """Second half of BASELINE.json's metric: Tacotron-2 mel-frames/s (autoregressive B=1; teacher-forced eval forward
     at the configs[1] shape B=32, T_in=256, T_out=800) and the decoder step's weight stream against the HBM roofline."""
+    import torch
+    from text2speech_amd import synth
     from text2speech_amd.tacotron import Tacotron
     hp = dict(synth.TACOTRON_HPARAMS)
     m = Tacotron(hp, 80, num_speakers=2)
@@ -101,13 +163,14 @@ def tacotron_metrics(dev):
     dec = m.decoder
     A, D, E, P = dec.attention_rnn_dim, dec.decoder_rnn_dim, dec.encoder_embedding_dim, dec.prenet_dim
     lstm_bytes = 4.0 * (4 * A * (P + E + A) + 4 * D * (A + E + D))          # f32 LSTMCell weights streamed per step
-    out["inference_B1"] = {"mel_frames_per_s": n / dt, "us_per_step": dt / n * 1e6, "frames": n, "symbols": 64}
-    out["roofline"] = {"bound": "hbm", "kernel": "decoder step (2 x lstm_cell_kernel + attention + projection)",
-                       "achieved": lstm_bytes / (dt / n) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                       "frac": lstm_bytes / (dt / n) / 1e9 / 8000.0,
+    out["inference_B1"] = {"mel_frames_per_s": n / dt, "us_per_step": dt / n * 1e6, "frames": n, "symbols": 64,
+                           "decoder": getattr(m._eng(), "decoder_kind", "launch chain")}
+    out["roofline"] = {"bound": "hbm", "kernel": "decoder step (2 LSTM cells + attention + projection)",
+                       "achieved": lstm_bytes / (dt / n) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": lstm_bytes / (dt / n) / 1e9 / HBM_PEAK_GBS,
                        "algorithmic_bytes_per_step": lstm_bytes,
-                       "note": "71.3 MB of LSTMCell weights per step over the whole step time (5 dependent launches, "
-                               "latency-bound at B=1); the two cell kernels alone stream them at ~3.9 TB/s"}
+                       "note": "71.3 MB of f32 LSTMCell weights per decoder step (what the reference streams) over the whole "
+                               "step time, encoder + postnet included"}
     B, T_in, T_out = 32, 256, 800
     gen = torch.Generator().manual_seed(21)
     text = torch.randint(2, 80, (B, T_in), generator=gen).to(dev)
@@ -122,29 +185,94 @@ def tacotron_metrics(dev):
         m(inp)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 2
-    out["forward_B32_Tin256_Tout800"] = {"mel_frames_per_s": B * T_out / dt, "ms": dt * 1e3}
+    out["forward_B32_Tin256_Tout800"] = {"mel_frames_per_s": B * T_out / dt, "ms": dt * 1e3,
+                                         "achieved_TFLOPs": B * T_out * TACO_FWD_FLOP_PER_FRAME / dt / 1e12}
     return out
 
 
+def tacotron_train_metrics(dev, steps=4, warmup=2):
+    """BASELINE configs[1]: Tacotron-2 train step, B=32, T_in=256, T_out=800, teacher-forced: zero_grad -> forward (training
+    mode, device-drawn dropout) -> Tacotron2Loss -> hand-written backward -> FusedAdam (reference train.py:216-225)."""
+    import torch
+    from text2speech_amd import synth
+    from text2speech_amd.optim import FusedAdam
+    from text2speech_amd.tacotron import Tacotron, Tacotron2Loss
+    B, T_in, T_out = 32, 256, 800
+    m = Tacotron(dict(synth.TACOTRON_HPARAMS), 80, num_speakers=2)
+    m.load_state_dict(synth.tacotron_state())
+    m = m.to(dev).train()
+    opt = FusedAdam(list(m.parameters()), lr=1e-4, weight_decay=1e-6)           # train.py:187-189
+    gen = torch.Generator().manual_seed(21)
+    text = torch.randint(2, 80, (B, T_in), generator=gen).to(dev)
+    mel = torch.randn(B, 80, T_out, generator=gen).to(dev)
+    gate = torch.zeros(B, T_out, device=dev)
+    gate[:, -1] = 1
+    il = torch.full((B,), T_in, dtype=torch.long, device=dev)
+    ol = torch.full((B,), T_out, dtype=torch.long, device=dev)
+    inp = (text, il, mel, T_in, torch.zeros(B, device=dev), ol)
+    crit = Tacotron2Loss()
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        loss = crit(m(inp), (mel, gate))
+        loss.backward()
+        opt.step()
+        return loss
+
+    first = None
+    for _ in range(warmup):
+        l = step()
+        first = float(l) if first is None else first
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        l = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    flop = 3.0 * B * T_out * TACO_FWD_FLOP_PER_FRAME
+    return {"workload": "Tacotron-2 train step B=32, T_in=256, T_out=800 (BASELINE configs[1]), fixed shapes",
+            "ms_per_step": dt * 1e3, "mel_frames_per_s": B * T_out / dt, "steps": steps, "warmup": warmup,
+            "algorithmic_TFLOP_per_step": flop / 1e12, "achieved_TFLOPs": flop / dt / 1e12,
+            "dtype": "f32 (LSTM cells, attention: exact f32 MFMA / VALU) + bf16x3 (convolutions)",
+            "loss_first": first, "loss_last": float(l), "max_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}
+
+
+def run_steps(step, steps, warmup, dist, grad):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides."""
+    import torch
+    with torch.enable_grad() if grad else torch.no_grad():
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8)
-    ap.add_argument("--segment", type=int, default=16000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-tacotron", action="store_true", help="skip the Tacotron mel-frames/s block (N=1 only)")
-    ap.add_argument("--mode", choices=["forward", "train"], default="forward",
-                    help="forward: the headline metric (default); train: zero_grad+forward+loss+backward+Adam, "
-                         "data-parallel over RCCL when launched with N > 1 ranks (BASELINE configs[3])")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import torch
+    from text2speech_amd import _lib, synth
+    from text2speech_amd.glow import WaveGlow, WaveGlowLoss
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d; launch with torch.distributed.run --nproc-per-node %d "
+                         "(or run `python bench.py --gpus %d` without a launcher)" % (world, args.gpus, args.gpus, args.gpus))
     _lib.load()
     # T2S_BENCH_REHEARSE=gloo: functional rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks share
     # the visible devices, collectives over gloo).  The JSON line is tagged; it is not a measurement.
@@ -180,17 +308,16 @@ def main():
     model = model.to(dev).eval()
     mel, audio = synth.waveglow_inputs(args.batch, args.segment, seed=1234 + rank)
     mel, audio = mel.to(dev), audio.to(dev)
-
     eng = model._eng()
     log("rank %d: model built, starting warm-up" % rank)
-    if args.mode == "train":
-        from text2speech_amd.glow import WaveGlowLoss
+
+    def make_train_step():
         from text2speech_amd.optim import FusedAdam
         from text2speech_amd import distributed as D
         model.train()
         if dist is not None:
             D.apply_gradient_allreduce(model)
-        opt = FusedAdam(model.parameters(), lr=1e-4)
+        opt = FusedAdam(model.parameters(), lr=1e-4)           # waveglow/train.py:79
         crit = WaveGlowLoss(1.0)
 
         def step():
@@ -199,61 +326,62 @@ def main():
             loss.backward()
             opt.step()
             return loss
-    else:
-        def step():
-            with torch.no_grad():
-                model((mel, audio))
-    run_train_or_fwd = step
-    with torch.enable_grad() if args.mode == "train" else torch.no_grad():
-        for _ in range(args.warmup):
-            run_train_or_fwd()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        eng.gemm_events = [] if rank == 0 else None
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run_train_or_fwd()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    log("rank %d: %d steps in %.3f s" % (rank, args.steps, dt))
-    if dist is not None:
+        return step
+
+    def fwd_step():
+        model((mel, audio))
+
+    def max_over_ranks(dt):
+        if dist is None:
+            return dt
         tt = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        return float(tt.item())
 
+    step = make_train_step() if args.mode == "train" else fwd_step
+    # the gate GEMM's HIP events are recorded on the launch stream during the timed steps only
+    eng.gemm_events = None
+    with torch.enable_grad() if args.mode == "train" else torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+    torch.cuda.synchronize()
+    eng.gemm_events = [] if (rank == 0 and args.mode == "forward") else None
+    dt = max_over_ranks(run_steps(step, args.steps, 0, dist, args.mode == "train"))
+    evs = eng.gemm_events or []
+    eng.gemm_events = None
+    log("rank %d: %d steps in %.3f s" % (rank, args.steps, dt))
+
+    out = None
     if rank == 0:
-        evs = eng.gemm_events or []
-        eng.gemm_events = None
         wn = cfg["WN_config"]
         C, ks = wn["n_channels"], wn["kernel_size"]
         n_cond = cfg["n_mel_channels"] * cfg["n_group"]
         L = args.segment // cfg["n_group"]
         flops_per_launch = 2.0 * (2 * C) * (ks * C + n_cond) * args.batch * L
         roof = None
-        if evs and args.mode == "forward":
+        if evs:
             ms = [a.elapsed_time(b) for a, b in evs]
             avg_ms = sum(ms) / len(ms)
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
             # HBM-side bytes per launch of this kernel come from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-            # --pmc WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note): profiles/r01_pmc_traffic.json
-            traffic = None
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_v5.json")))
-                # the gate GEMM runs as two instantiations (shared-B tile for dilation <= 32, plain otherwise): launch-weighted mean
-                gk = [v for k, v in pm["kernels"].items() if k.startswith("_Z16conv_gemm_kernelILi0E")]
-                traffic = sum(v["traffic_bytes_per_launch"] * v["launches"] for v in gk) / sum(v["launches"] for v in gk)
-            except (OSError, KeyError, ValueError, ZeroDivisionError):
-                pass
+            # --pmc WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note in MI355X_MICROARCH.md)
+            traffic, tsrc = None, None
+            for name in (GEMM_PMC, "r01_pmc_traffic_v5.json"):
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    # the gate GEMM runs as two instantiations (shared-B tile for dilation <= 32, plain otherwise)
+                    gk = [v for k, v in pm["kernels"].items() if k.startswith("_Z16conv_gemm_kernelILi0E")]
+                    traffic = sum(v["traffic_bytes_per_launch"] * v["launches"] for v in gk) / sum(v["launches"] for v in gk)
+                    tsrc = name
+                    break
+                except (OSError, KeyError, ValueError, ZeroDivisionError):
+                    continue
             roof = {"bound": "mfma", "kernel": "conv_gemm_kernel<EPI_GATE> (in_layers+cond_layers+gate)",
                     "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
-                    "traffic_note": "bytes/launch at batch 8x16000 from profiles/r01_pmc_traffic_v5.json (separate --pmc passes, tools/pmc_traffic.py; launch-weighted over the two gate-GEMM instantiations); "
-                                    "compulsory bytes are 83 MB read + 33 MB written",
+                    "traffic_note": "bytes/launch at batch 8x16000 from profiles/%s (separate --pmc passes, tools/pmc_traffic.py; "
+                                    "launch-weighted over the two gate-GEMM instantiations); compulsory bytes are 83 MB read + "
+                                    "33 MB written" % tsrc,
                     "avg_launch_ms": avg_ms, "launches": len(ms), "algorithmic_flops_per_launch": flops_per_launch,
                     "note": "split-bf16: 3 bf16 MFMA products per algorithmic MAC, so frac <= 1/3 by construction"}
         total_samples = args.gpus * args.batch * args.segment * args.steps
@@ -270,18 +398,69 @@ def main():
                        "parallelism": "replicas, no collective" if args.mode == "forward"
                        else "dp%d, 13 bucketed RCCL all-reduces overlapped with backward" % args.gpus},
             "roofline": roof,
+            "achieved_TFLOPs_whole_step": total_samples * WG_FWD_FLOP_PER_SAMPLE * (3.0 if args.mode == "train" else 1.0) / dt / 1e12,
         }
+    # ---- data-parallel WaveGlow train step (BASELINE configs[3]) next to the forward figure, every rank takes part ----
+    train_block, train_key = None, None
+    if args.mode == "forward" and not args.no_train:
+        train_key = "waveglow_train" if world == 1 else "waveglow_train_dp"
+
+        def give_up():      # a collective that never completes must not cost the headline line: print it and leave
+            log("rank %d: train block exceeded 240 s: giving up on it" % rank)
+            if out is not None:
+                out[train_key] = {"error": "timeout after 240 s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        guard = threading.Timer(240.0, give_up)
+        guard.daemon = True
+        guard.start()
+        try:
+            tstep = make_train_step()
+            k_tr, w_tr = 6, 2
+            dtt = max_over_ranks(run_steps(tstep, k_tr, w_tr, dist, True))
+            n_samp = world * args.batch * args.segment
+            flop = 3.0 * args.batch * args.segment * WG_FWD_FLOP_PER_SAMPLE          # train step ~ 3 x forward
+            train_block = {"workload": "WaveGlow train step (zero_grad, forward with saves, WaveGlowLoss, hand-written backward, "
+                                       "FusedAdam), batch %d x %d per GPU, config.json defaults" % (args.batch, args.segment),
+                           "n_gpus": world, "ms_per_step": dtt / k_tr * 1e3, "audio_samples_per_s": n_samp * k_tr / dtt,
+                           "steps": k_tr, "warmup": w_tr, "algorithmic_TFLOP_per_step_per_gpu": flop / 1e12,
+                           "achieved_TFLOPs_per_gpu": flop / (dtt / k_tr) / 1e12,
+                           "frac_of_bf16_peak": flop / (dtt / k_tr) / 1e12 / BF16_DENSE_PEAK_TFLOPS,
+                           "parallelism": "single GPU" if world == 1 else
+                           "dp%d: 13 flat gradient buckets all-reduced (RCCL AVG) from inside the backward" % world}
+            gs = eng.grad_sync
+            if gs is not None:
+                train_block["allreduce_bytes_per_step"] = gs.bytes // max(1, gs.n_buckets) * 13
+        except Exception as e:      # noqa: BLE001  (the headline line must still be printed)
+            train_block = {"error": "%s: %s" % (type(e).__name__, e)}
+        guard.cancel()
+        tstep = None
+        model.eval()
+        model.zero_grad(set_to_none=True)
+
+    if rank == 0:
         if rehearse:
             out["rehearsal"] = "NOT A MEASUREMENT: %d ranks share %d GPU(s), collectives over %s" % (world, torch.cuda.device_count(), rehearse)
-        if args.gpus == 1 and args.mode == "forward" and not args.no_tacotron:
-            log("tacotron metrics")
+        if train_block is not None:
+            out[train_key] = train_block
+        if args.gpus == 1 and args.mode == "forward":
             del model, eng
             torch.cuda.empty_cache()
-            out["tacotron"] = tacotron_metrics(dev)
-        if args.gpus == 1 and not args.no_cpu_baseline and args.mode == "forward":
-            out["cpu_baseline"] = cpu_baseline(cfg, sd)
+            if not args.no_tacotron:
+                log("tacotron metrics")
+                out["tacotron"] = tacotron_metrics(dev)
+                if not args.no_train:
+                    log("tacotron train step")
+                    torch.cuda.empty_cache()
+                    try:
+                        out["tacotron_train"] = tacotron_train_metrics(dev)
+                    except Exception as e:      # noqa: BLE001
+                        out["tacotron_train"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(cfg, sd, args.batch, args.segment)
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -5,10 +5,10 @@ reference WaveGlow path.  Only ``tests/``, ``__graft_entry__.smoke()`` and
 ``bench.py``'s ``cpu_baseline`` leg may import this file; the product package
 ``text2speech_amd`` never does.
 
-Parity status: PINNED.  ``tools/gen_golden.py`` imports the reference
+Parity status: PINNED.  ``tools/gen_golden_waveglow.py`` imports the reference
 (`/root/reference/waveglow/glow.py`) in the build container, loads the same
-seeded weights (``text2speech_amd.synth``) and writes ``tests/golden/*.npz``;
-``tests/test_oracle_golden.py`` checks this restatement against those vectors.
+seeded weights (``text2speech_amd.synth``) and writes ``tests/golden/waveglow_*.npz``;
+``tests/test_oracle_waveglow_golden.py`` checks this restatement against those vectors.
 
 Each function cites the reference lines it restates.  It is written as pure
 functions over a ``state_dict`` (reference key names), not as a module tree.

@@ -65,3 +65,30 @@ def test_roundtrip_property():
         z, _, _ = O.waveglow_forward(sd, cfg, mel, audio)
     want = torch.cat([ne[1], ne[0], nf], 1)
     assert _rel(z, want) < 1e-5
+
+
+@pytest.mark.slow
+def test_grads_config_defaults_vs_reference(golden_dir):
+    """config.json defaults (512 channels), B=2 x 4096: loss and the gradient of EVERY parameter (sum and sum of squares)
+    plus strided samples of one tensor of every kind in flows 0, 5, 11 against the reference's own backward
+    (tests/golden/waveglow_full_grads.npz, tools/gen_golden_waveglow.py)."""
+    g = np.load(os.path.join(golden_dir, "waveglow_full_grads.npz"))
+    cfg = synth.WAVEGLOW_DEFAULT
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth.waveglow_state(cfg).items()}
+    mel, audio = synth.waveglow_inputs(2, 4096, seed=33)
+    out = O.waveglow_forward(sd, cfg, mel, audio)
+    loss = O.waveglow_loss(out)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    names = [str(n) for n in g["all_names"]]
+    assert len(names) == len(sd) == 938
+    for n, gs, gq in zip(names, g["all_gradsum"], g["all_gradsq"]):
+        gr = sd[n].grad.double()
+        assert abs(float((gr ** 2).sum()) - gq) <= 2e-4 * gq + 1e-12, n
+        assert abs(float(gr.sum()) - gs) <= 2e-3 * float(gr.abs().sum()) + 1e-9, n
+    for key in g.files:
+        if key.startswith("grad::"):
+            name = key[len("grad::"):]
+            flat = sd[name].grad.flatten()
+            step = max(1, flat.numel() // 4096)
+            assert _rel(flat[::step], g[key]) < 2e-4, name

@@ -110,16 +110,9 @@ def test_grads_vs_reference_golden(trained):
         assert _rel(flat[::step], g[key]) < 5e-3, name
 
 
-def test_batch12_step_vs_oracle():
-    """Batch 12 (> 8 items: the LSTM cells and the BPTT data gradients take the f32 matrix-core path, csrc/sbgemm.hip):
-    loss and every parameter gradient against CPU autograd through the oracle, seeded masks, ragged lengths."""
-    from oracle import tacotron_oracle as O
-    from text2speech_amd.tacotron import Tacotron
-    _lib.load()
-    B, T_in, T_out = 12, 22, 20       # T_in % 4 != 0: the in-loop d_memory accumulation (the deferred form needs % 4)
-    gen = torch.Generator().manual_seed(5)
-    in_len = torch.tensor([T_in - (i * 3) // 2 for i in range(B)])
-    out_len = torch.tensor([T_out - i for i in range(B)])
+def _ragged(B, T_in, T_out, gen, din=None, dout=None):
+    in_len = torch.tensor([T_in - (din(i) if din else i) for i in range(B)])
+    out_len = torch.tensor([T_out - (dout(i) if dout else i) for i in range(B)])
     text = torch.randint(2, 80, (B, T_in), generator=gen)
     mel_t = torch.randn(B, 80, T_out, generator=gen)
     gate_t = torch.zeros(B, T_out)
@@ -127,11 +120,33 @@ def test_batch12_step_vs_oracle():
         text[b, in_len[b]:] = 0
         mel_t[b, :, out_len[b]:] = 0
         gate_t[b, out_len[b] - 1:] = 1
+    return text, in_len, mel_t, gate_t, out_len
+
+
+def _seeded_masks(B, T_in, T_out, gen):
     bern = lambda *s: (torch.rand(*s, generator=gen) < 0.5).to(torch.uint8)
     bern9 = lambda *s: (torch.rand(*s, generator=gen) < 0.9).to(torch.uint8)
     tm = {"enc": [bern(B, 512, T_in) for _ in range(3)], "att": bern9(T_out, B, 1024), "dec": bern9(T_out, B, 1024),
           "post": [bern(B, 512, T_out) for _ in range(4)] + [bern(B, 80, T_out)]}
     pm = bern(T_out + 1, B, 2, 256)
+    masks = {"enc": [t.float() for t in tm["enc"]], "prenet": pm.float(), "att": tm["att"].float(), "dec": tm["dec"].float(),
+             "post": [t.float() for t in tm["post"]]}
+    return tm, pm, masks
+
+
+@pytest.mark.parametrize("B,T_in,T_out", [
+    (12, 22, 20),     # > 8 items: f32 matrix-core cells (csrc/sbgemm.hip); T_in % 4 != 0: in-loop d_memory accumulation
+    (32, 64, 64),     # BASELINE configs[1] batch (train.py:216-225): two 16-item groups per sbgemm workgroup, deferred d_memory
+])
+def test_step_vs_oracle(B, T_in, T_out):
+    """Loss, the four outputs and every parameter gradient against CPU autograd through the oracle, seeded masks, ragged
+    lengths."""
+    from oracle import tacotron_oracle as O
+    from text2speech_amd.tacotron import Tacotron
+    _lib.load()
+    gen = torch.Generator().manual_seed(5)
+    text, in_len, mel_t, gate_t, out_len = _ragged(B, T_in, T_out, gen, din=lambda i: (i * 3) // 2 if B == 12 else i)
+    tm, pm, masks = _seeded_masks(B, T_in, T_out, gen)
     sd = synth.tacotron_state()
     m = Tacotron(HP, 80, num_speakers=2)
     m.load_state_dict(sd, strict=True)
@@ -145,8 +160,6 @@ def test_batch12_step_vs_oracle():
     torch.cuda.synchronize()
     got = {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}
     sd_cpu = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
-    masks = {"enc": [t.float() for t in tm["enc"]], "prenet": pm.float(), "att": tm["att"].float(), "dec": tm["dec"].float(),
-             "post": [t.float() for t in tm["post"]]}
     oo = O.tacotron_forward(sd_cpu, HP, text, in_len, mel_t, out_len, masks, training=True)
     lo = O.tacotron_loss(oo, mel_t, gate_t)
     lo.backward()
@@ -162,6 +175,146 @@ def test_batch12_step_vs_oracle():
         worst.append((0.0 if diff < 2e-5 else _rel(got[n], v.grad), n))
     worst.sort(reverse=True)
     assert worst[0][0] < 5e-3, worst[:6]
+
+
+def test_three_adam_steps_vs_oracle_batch32():
+    """zero_grad -> forward -> Tacotron2Loss -> backward -> Adam (reference train.py:216-225; Adam lr / weight decay as
+    train.py:187-189) three times at B=32 on the GPU (FusedAdam) and through the oracle (torch.optim.Adam on CPU) with the
+    same injected masks: the loss of every step within 1e-3 rel, the weights after the third step within 1e-3 rel."""
+    from oracle import tacotron_oracle as O
+    from text2speech_amd.optim import FusedAdam
+    from text2speech_amd.tacotron import Tacotron, Tacotron2Loss
+    _lib.load()
+    B, T_in, T_out = 32, 48, 40
+    gen = torch.Generator().manual_seed(17)
+    text, in_len, mel_t, gate_t, out_len = _ragged(B, T_in, T_out, gen)
+    tm, pm, masks = _seeded_masks(B, T_in, T_out, gen)
+    sd = synth.tacotron_state()
+    m = Tacotron(HP, 80, num_speakers=2)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).train()
+    opt = FusedAdam(m.parameters(), lr=1e-3, weight_decay=1e-6)
+    crit = Tacotron2Loss()
+    x = (text.to(DEV), in_len.to(DEV), mel_t.to(DEV), int(in_len.max()), torch.zeros(B, device=DEV), out_len.to(DEV))
+    y = (mel_t.to(DEV), gate_t.to(DEV))
+    losses = []
+    for _ in range(3):
+        m.zero_grad(set_to_none=True)
+        loss = crit(m(x, prenet_masks=pm, train_masks=tm), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    # oracle side: same steps with stock torch on the host
+    sd_cpu = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    params = [v for v in sd_cpu.values() if torch.is_tensor(v) and v.requires_grad]
+    opt_o = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-6)
+    losses_o = []
+    for _ in range(3):
+        opt_o.zero_grad(set_to_none=True)
+        lo = O.tacotron_loss(O.tacotron_forward(sd_cpu, HP, text, in_len, mel_t, out_len, masks, training=True), mel_t, gate_t)
+        lo.backward()
+        opt_o.step()
+        losses_o.append(float(lo))
+    for a, b in zip(losses, losses_o):
+        assert abs(a - b) < 1e-3 * abs(b), (losses, losses_o)
+    assert losses[2] < losses[0]
+    worst = []
+    for n, p in m.named_parameters():
+        v = sd_cpu[n]
+        if v.requires_grad and v.grad is not None:
+            worst.append((_rel(p.detach(), v.detach()), n))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 1e-3, worst[:6]
+
+
+def test_full_size_config_step_properties():
+    """BASELINE configs[1] at full size (B=32, T_in=256, T_out=800, ragged as SURVEY.md 8d: input_lengths 256-4i,
+    output_lengths 800-12i; ~20 GB of saves, three-stream BPTT): every output and gradient finite, the same seeded step
+    twice gives bit-identical gradients (device-drawn masks reproduce under torch.manual_seed), and three FusedAdam steps
+    on the fixed batch lower the loss."""
+    from text2speech_amd.optim import FusedAdam
+    from text2speech_amd.tacotron import Tacotron, Tacotron2Loss
+    _lib.load()
+    B, T_in, T_out = 32, 256, 800
+    gen = torch.Generator().manual_seed(21)
+    text, in_len, mel_t, gate_t, out_len = _ragged(B, T_in, T_out, gen, din=lambda i: 4 * i, dout=lambda i: 12 * i)
+    x = (text.to(DEV), in_len.to(DEV), mel_t.to(DEV), int(in_len.max()), torch.zeros(B, device=DEV), out_len.to(DEV))
+    y = (mel_t.to(DEV), gate_t.to(DEV))
+    crit = Tacotron2Loss()
+
+    def one_step(seed):
+        m = Tacotron(HP, 80, num_speakers=2)
+        m.load_state_dict(synth.tacotron_state(), strict=True)
+        m = m.to(DEV).train()
+        torch.manual_seed(seed)
+        out = m(x)
+        loss = crit(out, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        return m, out, float(loss), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    m, out, loss_a, ga = one_step(3)
+    assert len(ga) == len([p for p in m.parameters()]) - 3      # speaker table + deep_linear are dead weights (tacotron.py:27-29)
+    for t in out:
+        assert bool(torch.isfinite(t).all())
+    for n, g_ in ga.items():
+        assert bool(torch.isfinite(g_).all()), n
+        assert float(g_.abs().max()) > 0 or "convolutions" in n, n
+    # padded positions are masked exactly as the reference's parse_output does (tacotron.py:67-76)
+    assert float(out[0][5, :, int(out_len[5]):].abs().max()) == 0.0 and float(out[2][5, int(out_len[5]):].min()) == 1e3
+    _, _, loss_b, gb = one_step(3)
+    assert loss_a == loss_b
+    for n in ga:
+        assert torch.equal(ga[n], gb[n]), n
+    _, _, loss_c, _ = one_step(4)
+    assert loss_c != loss_a          # a different seed draws different dropout masks
+    del ga, gb
+    opt = FusedAdam(m.parameters(), lr=1e-3, weight_decay=1e-6)
+    tm = None
+    losses = []
+    torch.manual_seed(11)
+    for _ in range(4):
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(11)          # fixed masks: the loss sequence is then a pure function of the weights
+        loss = crit(m(x), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(l == l and abs(l) < 1e4 for l in losses), losses
+    assert losses[-1] < losses[0], losses
+
+
+def test_dropout_masks_fresh_per_call_and_reproducible():
+    """Every training forward / inference draws NEW dropout masks (reference: F.dropout on the global RNG,
+    modules.py:21, tacotron.py:193,368,383) and torch.manual_seed reproduces them."""
+    from text2speech_amd.tacotron import Tacotron
+    _lib.load()
+    B, T_in, T_out = 3, 24, 16
+    gen = torch.Generator().manual_seed(2)
+    text, in_len, mel_t, gate_t, out_len = _ragged(B, T_in, T_out, gen)
+    m = Tacotron(HP, 80, num_speakers=2)
+    m.load_state_dict(synth.tacotron_state(), strict=True)
+    m = m.to(DEV).train()
+    x = (text.to(DEV), in_len.to(DEV), mel_t.to(DEV), int(in_len.max()), torch.zeros(B, device=DEV), out_len.to(DEV))
+    with torch.no_grad():
+        torch.manual_seed(77)
+        a = [t.clone() for t in m(x)]
+        b = [t.clone() for t in m(x)]
+        torch.manual_seed(77)
+        c = [t.clone() for t in m(x)]
+    assert not torch.equal(a[1], b[1]) and not torch.equal(a[0], b[0])
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and torch.equal(a[2], c[2])
+    m.eval()
+    m.decoder.gate_threshold, m.decoder.max_decoder_steps = 2.0, 12
+    ids = text[:1, :20].to(DEV)
+    torch.manual_seed(5)
+    i1 = m.inference(ids, None)[0].clone()
+    i2 = m.inference(ids, None)[0].clone()
+    torch.manual_seed(5)
+    i3 = m.inference(ids, None)[0].clone()
+    assert not torch.equal(i1, i2) and torch.equal(i1, i3)      # the always-on prenet dropout (modules.py:21)
 
 
 def test_tacotron2loss_matches_torch():

@@ -19,16 +19,14 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.fixture(scope="module")
-def trained():
+def _train_once(cfg, batch, n_samples, seed):
     """One forward+backward on the GPU and the same through the CPU oracle."""
     assert torch.cuda.is_available()
     _lib.load()
     from oracle import waveglow_oracle as O
     from text2speech_amd.glow import WaveGlow, WaveGlowLoss
-    cfg = synth.WAVEGLOW_SMALL
     sd = synth.waveglow_state(cfg)
-    mel, audio = synth.waveglow_inputs(2, 4096, seed=31)
+    mel, audio = synth.waveglow_inputs(batch, n_samples, seed=seed)
     m = WaveGlow(**cfg)
     m.load_state_dict(sd)
     m = m.to(DEV).train()
@@ -44,6 +42,69 @@ def trained():
     losso.backward()
     want = {k: v.grad for k, v in sd_cpu.items() if v.grad is not None}
     return dict(got=got, want=want, loss=float(loss), loss_o=float(losso), model=m, n_params=len(list(m.parameters())))
+
+
+@pytest.fixture(scope="module")
+def trained():
+    return _train_once(synth.WAVEGLOW_SMALL, 2, 4096, 31)
+
+
+@pytest.fixture(scope="module")
+def trained512():
+    """BASELINE configs[3] arithmetic: reference waveglow/config.json defaults (512 channels: 4 M tiles in the gate-backward
+    GEMM, 9 x 4-tile weight-gradient GEMMs with flattened split-K, 16 K-chunks in pack_transposed) on a short segment."""
+    return _train_once(synth.WAVEGLOW_DEFAULT, 2, 4096, 33)
+
+
+def test_config_defaults_512ch_loss_and_all_param_grads_vs_oracle(trained512):
+    t = trained512
+    assert abs(t["loss"] - t["loss_o"]) < 1e-4
+    got, want = t["got"], t["want"]
+    assert len(got) == t["n_params"] == 938, "a parameter received no gradient"
+    worst = []
+    for name, w in want.items():
+        assert name in got, name
+        assert got[name].shape == w.shape, name
+        worst.append((_rel(got[name], w), name))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 2e-3, worst[:8]
+    assert sorted(r for r, _ in worst)[len(worst) // 2] < 2e-4, worst[:8]
+
+
+def test_config_defaults_512ch_grads_vs_reference_golden(trained512, golden_dir):
+    """Against the gradients the REFERENCE produced at config.json defaults (tests/golden/waveglow_full_grads.npz): the loss,
+    the squared norm of every one of the 938 parameter gradients, and strided samples of one tensor of every kind in flows
+    0, 5 and 11."""
+    g = np.load(os.path.join(golden_dir, "waveglow_full_grads.npz"))
+    got = trained512["got"]
+    assert abs(trained512["loss"] - float(g["loss"])) < 1e-4
+    names = [str(n) for n in g["all_names"]]
+    assert sorted(names) == sorted(got)
+    for n, gq in zip(names, g["all_gradsq"]):
+        sq = float((got[n].double() ** 2).sum())
+        assert abs(sq - gq) <= 5e-3 * gq + 1e-12, (n, sq, gq)
+    n_samples = 0
+    for key in g.files:
+        if not key.startswith("grad::"):
+            continue
+        name = key[len("grad::"):]
+        flat = got[name].flatten()
+        step = max(1, flat.numel() // 4096)
+        assert _rel(flat[::step], g[key]) < 2e-3, name
+        n_samples += 1
+    assert n_samples >= 100
+
+
+def test_config_defaults_512ch_backward_is_bitwise_reproducible(trained512):
+    from text2speech_amd.glow import WaveGlowLoss
+    m = trained512["model"]
+    mel, audio = synth.waveglow_inputs(2, 4096, seed=33)
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        WaveGlowLoss(1.0)(m((mel.to(DEV), audio.to(DEV)))).backward()
+        torch.cuda.synchronize()
+        for n, p in m.named_parameters():
+            assert torch.equal(p.grad.cpu(), trained512["got"][n]), n
 
 
 def test_loss_and_all_param_grads_vs_oracle(trained):
@@ -90,6 +151,64 @@ def test_adam_step_matches_torch(trained):
     torch.cuda.synchronize()
     worst = max(_rel(p.detach(), r.detach()) for p, r in zip(m.parameters(), ref))
     assert worst < 1e-6, worst
+
+
+def test_adam_state_interop_and_cache_invalidation():
+    """(1) an optimizer state written by torch.optim.Adam (what the reference's checkpoints hold, waveglow/train.py:41-60)
+    loads into FusedAdam and continues with the right bias correction; (2) load_state_dict on an optimizer that has already
+    stepped re-targets the kernel's job table at the new moment buffers; (3) a step invalidates the packed-weight cache that
+    infer() keys on parameter versions, so infer() after step() uses the new weights."""
+    from text2speech_amd.glow import WaveGlow, WaveGlowLoss
+    from text2speech_amd.optim import FusedAdam
+    _lib.load()
+    cfg = synth.WAVEGLOW_SMALL
+    mel, audio = synth.waveglow_inputs(1, 2048, seed=3)
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synth.waveglow_state(cfg))
+    m = m.to(DEV).train()
+    WaveGlowLoss(1.0)(m((mel.to(DEV), audio.to(DEV)))).backward()
+    torch.cuda.synchronize()
+    params = list(m.parameters())
+    ref = [p.detach().clone().requires_grad_(True) for p in params]
+    for r, p in zip(ref, params):
+        r.grad = p.grad.detach().clone()
+    opt_ref = torch.optim.Adam(ref, lr=1e-3)
+    for _ in range(5):
+        opt_ref.step()
+    opt = FusedAdam(params, lr=1e-3)
+    opt.step()                                   # has stepped once: job table cached, moments allocated
+    with torch.no_grad():
+        for p, r in zip(params, ref):
+            p.copy_(r)
+    opt.load_state_dict(opt_ref.state_dict())    # torch.optim.Adam layout: per-parameter 'step' tensors
+    opt.step()
+    opt_ref.step()
+    torch.cuda.synchronize()
+    assert opt.param_groups[0]["step"] == 6
+    worst = max(_rel(p.detach(), r.detach()) for p, r in zip(params, ref))
+    assert worst < 1e-6, worst
+    for p, r in zip(params[:20], ref[:20]):      # the moments the kernel wrote are the loaded ones, advanced by one step
+        assert _rel(opt.state[p]["exp_avg"], opt_ref.state[r]["exp_avg"]) < 1e-6
+        assert _rel(opt.state[p]["exp_avg_sq"], opt_ref.state[r]["exp_avg_sq"]) < 1e-6
+    # and the state written here loads into torch.optim.Adam
+    back = torch.optim.Adam(ref, lr=1e-3)
+    back.load_state_dict(opt.state_dict())
+    assert int(back.state[ref[0]]["step"]) == 6
+    # (3) infer() after a step must see the stepped weights
+    m.eval()
+    gen = torch.Generator().manual_seed(1)
+    spect = torch.randn(1, 80, 6, generator=gen).to(DEV)
+    L = 6 * 256 // 8
+    noise = (torch.randn(1, 4, L, generator=gen), [torch.randn(1, 2, L, generator=gen) for _ in range(2)])
+    a0 = m.infer(spect, sigma=0.7, noise=noise).clone()
+    opt2 = FusedAdam(params, lr=1e-2)
+    opt2.step()
+    a1 = m.infer(spect, sigma=0.7, noise=noise).clone()
+    m2 = WaveGlow(**cfg)
+    m2.load_state_dict(m.state_dict())
+    a2 = m2.to(DEV).eval().infer(spect, sigma=0.7, noise=noise)
+    assert not torch.equal(a0, a1)
+    assert torch.equal(a1, a2), _rel(a1, a2)
 
 
 def test_bucketed_allreduce_inside_backward_nccl_world1():

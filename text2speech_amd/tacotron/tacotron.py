@@ -7,9 +7,10 @@ the same ``state_dict`` keys.  ``Encoder`` / ``Decoder`` / ``Atte
 of ``libt2s_hip.so`` (include/t2s_hip.h).  No CPU / eager fallback.
 
 Dropout: the prenet's dropout is always on in the reference (modules.py:21).  Masks can be injected
-(``prenet_masks=`` {0,1} bytes) for parity tests; otherwise they are drawn on the device.
-Training-mode forward (BatchNorm batch statistics, encoder / LSTM / postnet dropout, backward) is
-not built yet and raises.
+(``prenet_masks=`` {0,1} bytes) for parity tests; otherwise they are drawn on the device from a seed
+that is fresh for every call (``_TacoEngine.fresh_seed``, reproducible under ``torch.manual_seed``).
+Training mode (BatchNorm batch statistics, encoder / LSTM / postnet dropout) runs here; its backward
+is ``tacotron/autograd.py``.
 """
 import ctypes
 import sys
@@ -400,7 +401,16 @@ class _TacoEngine:
         return Oh, Ol
 
     # ------------------------------------------------------------------ whole-model paths
-    def inference(self, ids, prenet_masks=None, seed=0, chunk=64):
+    @staticmethod
+    def fresh_seed():
+        """A new dropout seed per call, drawn from torch's default generator: every forward / inference draws different
+        masks (reference: F.dropout draws from the global RNG each call, modules.py:21, tacotron.py:193,368,383) and
+        ``torch.manual_seed`` reproduces them.  Host-side draw: no device synchronisation."""
+        return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+    def inference(self, ids, prenet_masks=None, seed=None, chunk=64):
+        if seed is None:
+            seed = self.fresh_seed()
         m = self.m
         dec = m.decoder
         dev = ids.device
@@ -435,7 +445,9 @@ class _TacoEngine:
         mel_post = mel + self.postnet(mel)
         return [mel, mel_post, gate, align]
 
-    def forward(self, text, text_lengths, mels, output_lengths, prenet_masks=None, seed=0, train_masks=None, save=None):
+    def forward(self, text, text_lengths, mels, output_lengths, prenet_masks=None, seed=None, train_masks=None, save=None):
+        if seed is None:
+            seed = self.fresh_seed()
         m = self.m
         dec = m.decoder
         dev = text.device
@@ -522,8 +534,9 @@ class Tacotron(nn.Module):
     def forward(self, inputs, prenet_masks=None, train_masks=None):
         """Teacher-forced forward (reference tacotron.py:36-49).  In ``.train()`` mode BatchNorm uses batch statistics
         and every dropout is live (``train_masks`` = {'enc': [3 x [B,C,T_in]], 'att': [T,B,H], 'dec': [T,B,H],
-        'post': [5 x [B,C,T]]} of {0,1} injects the draws; otherwise they are drawn on the device).  The backward
-        pass is not built yet: calling this with autograd enabled on trainable parameters raises."""
+        'post': [5 x [B,C,T]]} of {0,1} injects the draws; otherwise they are drawn on the device from a fresh seed per
+        call, reproducible under ``torch.manual_seed``).  With autograd enabled on trainable parameters the call goes
+        through ``tacotron/autograd.py``: forward with saves + hand-written HIP backward."""
         text_inputs, text_lengths, mels, max_len, speaker_id, output_lengths = inputs
         self._check(text_inputs)
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):

@@ -42,7 +42,24 @@ def build_ref(cfg, sd):
     return m
 
 
-def run_forward(name, cfg, batch, n_samples, seed, store_z=True, grads=False):
+GRAD_KEYS_SMALL = ["WN.0.in_layers.0.weight_v", "WN.0.in_layers.0.weight_g", "WN.3.cond_layers.7.weight_v",
+                   "WN.11.res_skip_layers.2.weight_v", "WN.5.start.weight_g", "WN.7.end.weight",
+                   "convinv.2.conv.weight", "upsample.weight", "WN.11.in_layers.7.bias"]
+
+
+def grad_keys_full():
+    """config.json defaults (512 channels): one tensor of every kind in flows 0, 5 and 11, first / middle / last layer."""
+    keys = ["upsample.weight", "upsample.bias"]
+    for k in (0, 5, 11):
+        keys += [f"convinv.{k}.conv.weight", f"WN.{k}.start.weight_v", f"WN.{k}.start.weight_g", f"WN.{k}.start.bias",
+                 f"WN.{k}.end.weight", f"WN.{k}.end.bias"]
+        for i in (0, 3, 7):
+            for kind in ("in_layers", "cond_layers", "res_skip_layers"):
+                keys += [f"WN.{k}.{kind}.{i}.weight_v", f"WN.{k}.{kind}.{i}.weight_g", f"WN.{k}.{kind}.{i}.bias"]
+    return keys
+
+
+def run_forward(name, cfg, batch, n_samples, seed, store_z=True, grads=False, grad_keys=None, sample=32768, all_norms=False):
     sd = synth.waveglow_state(cfg)
     mel, audio = synth.waveglow_inputs(batch, n_samples, seed=seed)
     m = build_ref(cfg, sd)
@@ -54,14 +71,17 @@ def run_forward(name, cfg, batch, n_samples, seed, store_z=True, grads=False):
         loss.backward()
         named = dict(m.named_parameters())
         # torch >= 2 exposes weight_norm params under their original names
-        for key in ["WN.0.in_layers.0.weight_v", "WN.0.in_layers.0.weight_g", "WN.3.cond_layers.7.weight_v",
-                    "WN.11.res_skip_layers.2.weight_v", "WN.5.start.weight_g", "WN.7.end.weight",
-                    "convinv.2.conv.weight", "upsample.weight", "WN.11.in_layers.7.bias"]:
+        for key in (grad_keys or GRAD_KEYS_SMALL):
             gflat = named[key].grad.detach().flatten()
-            step = max(1, gflat.numel() // 32768)       # strided sample keeps fixtures small
+            step = max(1, gflat.numel() // sample)       # strided sample keeps fixtures small
             out["grad::" + key] = gflat[::step].contiguous().numpy()
             out["gradsum::" + key] = np.float64(gflat.double().sum().item())
             out["gradsq::" + key] = np.float64((gflat.double() ** 2).sum().item())
+        if all_norms:      # every parameter's gradient is pinned by its sum and sum of squares (two scalars per tensor)
+            names = sorted(named)
+            out["all_names"] = np.array(names)
+            out["all_gradsum"] = np.array([named[n].grad.double().sum().item() for n in names], dtype=np.float64)
+            out["all_gradsq"] = np.array([(named[n].grad.double() ** 2).sum().item() for n in names], dtype=np.float64)
         out["loss"] = np.float64(loss.item())
     else:
         with torch.no_grad():
@@ -115,5 +135,8 @@ if __name__ == "__main__":
     run_forward("waveglow_small_grads", synth.WAVEGLOW_SMALL, 2, 4096, seed=31, store_z=False, grads=True)
     run_infer("waveglow_small_infer_s0", synth.WAVEGLOW_SMALL, 2, 12, seed=41, sigma=0.0)
     run_infer("waveglow_small_infer_s0666", synth.WAVEGLOW_SMALL, 2, 12, seed=41, sigma=0.666)
+    # BASELINE configs[3] arithmetic (config.json defaults, 512 channels) on a short segment: loss + gradients
+    run_forward("waveglow_full_grads", synth.WAVEGLOW_DEFAULT, 2, 4096, seed=33, store_z=False, grads=True,
+                grad_keys=grad_keys_full(), sample=4096, all_norms=True)
     if args.full:
         run_forward("waveglow_full_fwd", synth.WAVEGLOW_DEFAULT, 8, 16000, seed=31)
