@@ -8,11 +8,20 @@
  *
  * Conventions
  *  - every pointer is a DEVICE pointer owned by the caller (PyTorch allocations);
- *    the library allocates nothing and keeps no global state;
- *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
- *    nothing synchronises;
+ *    the library allocates no device memory;
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, or
+ *    ordered before the point the call leaves it at, and nothing synchronises
+ *    with the host;
  *  - return value 0 = success; a negative T2S_E* code otherwise (never throws);
- *  - entry points are re-entrant (autograd calls backward from another thread).
+ *  - entry points are re-entrant and thread-safe (autograd calls backward from
+ *    another thread), and work on whichever device is current in the calling
+ *    thread.  Library-owned state, all of it per device and created on first use
+ *    on that device: (a) t2s_taco_bptt_steps keeps two helper streams + five events
+ *    per device behind a per-device mutex (it overlaps three dependent chains; on
+ *    every exit, error exits included, the caller's stream waits for both helpers);
+ *    (b) the GEMM launchers remember per device that they raised the kernel's
+ *    dynamic-LDS limit (an idempotent one-bit flag); (c) t2s_last_hip_error()
+ *    is per thread.  Nothing else persists between calls.
  *
  * "Planes": activations on the WN path are channel-last, split-bf16:
  *      x ~= float(hi) + float(lo),   plane[b][c/32][row][c%32] (bf16),

@@ -54,6 +54,24 @@ def _worker(rank, world, port, out):
         gs.reduce_async(flat)
         gs.finish()
         assert torch.allclose(flat, torch.full((1000,), 0.5))
+        # the shape the hand-written WaveGlow backward uses (glow_autograd._Bucket): several flat buckets shipped one after
+        # the other while later work is still being produced, gradients are VIEWS into the buckets, one finish() at the end
+        gs = D.GradSync()
+        buckets, views = [], []
+        for k in range(5):
+            flat = torch.empty(64 * (k + 1) + 8)
+            a = flat[:64 * (k + 1)].view(k + 1, 64)
+            b = flat[64 * (k + 1):]
+            a.fill_(float(rank + k))
+            b.fill_(float(10 * rank))
+            gs.reduce_async(flat)
+            buckets.append(flat)
+            views.append((a, b))
+        assert gs.n_buckets == 5 and len(gs.pending) == 5
+        gs.finish()
+        assert not gs.pending
+        for k, (a, b) in enumerate(views):
+            assert torch.allclose(a, torch.full_like(a, k + 0.5)) and torch.allclose(b, torch.full_like(b, 5.0))
         out.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         out.put((rank, repr(e)))

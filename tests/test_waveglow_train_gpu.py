@@ -180,7 +180,10 @@ def test_adam_state_interop_and_cache_invalidation():
     with torch.no_grad():
         for p, r in zip(params, ref):
             p.copy_(r)
-    opt.load_state_dict(opt_ref.state_dict())    # torch.optim.Adam layout: per-parameter 'step' tensors
+    import copy
+    # torch.optim.Adam layout: per-parameter 'step' tensors.  deepcopy: Optimizer.load_state_dict keeps tensors that already
+    # have the parameter's dtype and device BY REFERENCE, and the two optimizers must not share moment buffers here
+    opt.load_state_dict(copy.deepcopy(opt_ref.state_dict()))
     opt.step()
     opt_ref.step()
     torch.cuda.synchronize()
@@ -192,7 +195,7 @@ def test_adam_state_interop_and_cache_invalidation():
         assert _rel(opt.state[p]["exp_avg_sq"], opt_ref.state[r]["exp_avg_sq"]) < 1e-6
     # and the state written here loads into torch.optim.Adam
     back = torch.optim.Adam(ref, lr=1e-3)
-    back.load_state_dict(opt.state_dict())
+    back.load_state_dict(copy.deepcopy(opt.state_dict()))
     assert int(back.state[ref[0]]["step"]) == 6
     # (3) infer() after a step must see the stepped weights
     m.eval()

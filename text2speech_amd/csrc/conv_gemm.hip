@@ -616,13 +616,9 @@ template <int EPI, int MT, int WN = 4, bool BD = false, bool SH = false, bool EF
 static hipError_t launch_one(const ConvGemmArgs& a, hipStream_t stream) {
     const int nwg = a.n_mtiles * a.n_ttiles * a.B;
     constexpr size_t lds = SH ? 2 * (2 * MT * 64) + 4 * 320 * 64 : NS * (2 * MT * 64 + 2 * B_PLANE_BYTES);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_kernel<EPI, MT, WN, BD, SH, EF, NS>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_mask{0};        // per instantiation; bit d = raised on device d
+    const hipError_t e = t2s_raise_lds_limit((const void*)conv_gemm_kernel<EPI, MT, WN, BD, SH, EF, NS>, (int)lds, attr_mask);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((conv_gemm_kernel<EPI, MT, WN, BD, SH, EF, NS>), dim3(nwg), dim3(128 * WN), lds, stream, a);
     return hipGetLastError();
 }

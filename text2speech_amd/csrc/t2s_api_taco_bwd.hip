@@ -6,12 +6,41 @@
 
 #include <string.h>
 
+#include <mutex>
+
 extern "C" int t2s_internal_fail_hip(int e);
 #define T2S_CHECK_HIP(expr)                                          \
     do {                                                             \
         hipError_t _e = (expr);                                      \
         if (_e != hipSuccess) return t2s_internal_fail_hip((int)_e); \
     } while (0)
+
+// The one piece of library-owned state (documented in include/t2s_hip.h): the BPTT driver overlaps three dependent
+// chains on three streams.  The caller hands over ONE stream, so the two helpers and their events belong to the library:
+// one set per device, created on first use on THAT device, and a per-device mutex held while a call enqueues (two autograd
+// threads may call into the same device; the call only enqueues work, it never blocks on the GPU).
+namespace {
+struct BpttStreams {
+    std::mutex mu;
+    hipStream_t side = nullptr, side2 = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_energy = nullptr, ev_conv = nullptr, ev_join = nullptr;
+    bool ready = false;
+};
+constexpr int kMaxDevices = 64;
+BpttStreams g_bptt[kMaxDevices];
+
+hipError_t bptt_streams_init(BpttStreams& s) {      // caller holds s.mu; the current device is the one s belongs to
+    if (s.ready) return hipSuccess;
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking)) != hipSuccess) return e;
+    if ((e = hipStreamCreateWithFlags(&s.side2, hipStreamNonBlocking)) != hipSuccess) return e;
+    hipEvent_t* evs[] = {&s.ev_main, &s.ev_side, &s.ev_energy, &s.ev_conv, &s.ev_join};
+    for (hipEvent_t* ev : evs)
+        if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return e;
+    s.ready = true;
+    return hipSuccess;
+}
+}  // namespace
 
 extern "C" {
 
@@ -78,17 +107,26 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
     // signals one event per step; its ~27 us per step hide behind the ~78 us of the attention chain.
     // A third stream takes the last part of the attention backward (location-conv backward): it only feeds the NEXT step's
     // carries and the kernel gradient, so it runs beside this step's attention-cell backward and GEMM.
-    static hipStream_t side = nullptr, side2 = nullptr;
-    static hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_energy = nullptr, ev_conv = nullptr;
     static const bool two_streams = !getenv("T2S_BPTT_ONE_STREAM");
-    if (two_streams && !side) {
-        T2S_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-        T2S_CHECK_HIP(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
-        T2S_CHECK_HIP(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
-        T2S_CHECK_HIP(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
-        T2S_CHECK_HIP(hipEventCreateWithFlags(&ev_energy, hipEventDisableTiming));
-        T2S_CHECK_HIP(hipEventCreateWithFlags(&ev_conv, hipEventDisableTiming));
-    }
+    int device = 0;
+    T2S_CHECK_HIP(hipGetDevice(&device));
+    if (device < 0 || device >= kMaxDevices) return T2S_EINVAL;
+    BpttStreams& S = g_bptt[device];
+    std::unique_lock<std::mutex> lock(S.mu);
+    if (two_streams) T2S_CHECK_HIP(bptt_streams_init(S));
+    hipStream_t side = S.side, side2 = S.side2;
+    hipEvent_t ev_main = S.ev_main, ev_side = S.ev_side, ev_energy = S.ev_energy, ev_conv = S.ev_conv;
+    // Whatever happens below (including a failed launch), the caller's stream is made to wait for everything already
+    // enqueued on the two helper streams before this call returns: the caller may recycle the scratch buffers as soon as
+    // ITS stream has passed this point.
+    struct Join {
+        BpttStreams& S; hipStream_t stream; bool on;
+        ~Join() {
+            if (!on) return;
+            if (hipEventRecord(S.ev_join, S.side) == hipSuccess) (void)hipStreamWaitEvent(stream, S.ev_join, 0);
+            if (hipEventRecord(S.ev_join, S.side2) == hipSuccess) (void)hipStreamWaitEvent(stream, S.ev_join, 0);
+        }
+    } join{S, stream, two_streams};
     bool conv_pending = false;
     hipStream_t dstream = two_streams ? side : stream;
     if (two_streams) {                                   // everything enqueued so far (d_hc, the saves) precedes the side chain

@@ -53,3 +53,18 @@ static __device__ __forceinline__ float wave_sum(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+
+// Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once per device.
+// `mask` is one static word per kernel: bit d = done on device d.  Setting the attribute twice is harmless, so a relaxed
+// atomic is all the synchronisation two calling threads need.
+#include <atomic>
+static inline hipError_t t2s_raise_lds_limit(const void* fn, int bytes, std::atomic<unsigned long long>& mask) {
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (device & 63);
+    if (mask.load(std::memory_order_relaxed) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) mask.fetch_or(bit, std::memory_order_relaxed);
+    return e;
+}

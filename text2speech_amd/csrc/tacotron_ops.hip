@@ -560,12 +560,9 @@ hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream) {
     if (a.T > ATT_FUSED_MAXT || a.enc_dim > 512 || a.att_dim > 128 || a.loc_f > 32 || a.loc_ks > 63 || a.att_rnn > 1024)
         return hipErrorInvalidValue;
     const size_t lds = ((size_t)a.T * 33 + a.T) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)att_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_mask{0};
+    const hipError_t e = t2s_raise_lds_limit((const void*)att_fused_kernel, 96 * 1024, attr_mask);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(att_fused_kernel, dim3(a.B), dim3(1024), lds, stream, a);
     return hipGetLastError();
 }
