@@ -191,8 +191,8 @@ def test_adam_state_interop_and_cache_invalidation():
     worst = max(_rel(p.detach(), r.detach()) for p, r in zip(params, ref))
     assert worst < 1e-6, worst
     for p, r in zip(params[:20], ref[:20]):      # the moments the kernel wrote are the loaded ones, advanced by one step
-        assert _rel(opt.state[p]["exp_avg"], opt_ref.state[r]["exp_avg"]) < 1e-6
-        assert _rel(opt.state[p]["exp_avg_sq"], opt_ref.state[r]["exp_avg_sq"]) < 1e-6
+        assert _rel(opt.state[p]["exp_avg"], opt_ref.state[r]["exp_avg"]) < 1e-5
+        assert _rel(opt.state[p]["exp_avg_sq"], opt_ref.state[r]["exp_avg_sq"]) < 1e-5
     # and the state written here loads into torch.optim.Adam
     back = torch.optim.Adam(ref, lr=1e-3)
     back.load_state_dict(copy.deepcopy(opt.state_dict()))

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libt2s_hip.so")
-SOURCES = ["conv_gemm.hip", "waveglow_ops.hip", "tacotron_ops.hip", "sbgemm.hip", "train_ops.hip", "taco_bwd_ops.hip", "t2s_api_taco_bwd.hip", "t2s_api.hip", "t2s_api_taco.hip",
+SOURCES = ["conv_gemm.hip", "gate_gemm_pp.hip", "waveglow_ops.hip", "tacotron_ops.hip", "sbgemm.hip", "train_ops.hip", "taco_bwd_ops.hip", "t2s_api_taco_bwd.hip", "t2s_api.hip", "t2s_api_taco.hip",
            "t2s_api_train.hip", "audio_ops.hip", "t2s_api_audio.hip", "loss_ops.hip"]
 
 
@@ -34,6 +34,7 @@ def build(force=False, verbose=False):
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd[1:1] = os.environ.get("T2S_BUILD_DEFINES", "").split()      # e.g. -DT2S_GEMM_ABLATE for the timing-only ablations
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         r = subprocess.run(cmd, capture_output=True, text=True)

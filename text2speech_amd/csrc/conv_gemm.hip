@@ -636,6 +636,11 @@ hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a_in, int epi, hipStream_t s
         if (epi == EPI_GATE_BWD) return launch_one<EPI_GATE_BWD, 128>(a, stream);
         return hipErrorInvalidValue;
     }
+    // default gate GEMM: the ping-pong schedule (csrc/gate_gemm_pp.hip); T2S_GEMM_PP=0 falls back to the lockstep kernels below
+    static const int pp = getenv("T2S_GEMM_PP") ? atoi(getenv("T2S_GEMM_PP")) : 1;
+    if (epi == EPI_GATE && pp && a.ksplit <= 1 && a.k0 == 0 && a.kflat == 0 && a.nk == a.nk_x + a.sc && a.nk_x == a.taps * a.xc &&
+        a.a_bstride == 0 && (a.taps >> 1) * a.dil <= a.halo)
+        return t2s_launch_gate_gemm_pp(a, stream);
     static const int wn2 = getenv("T2S_GEMM_WN2") ? atoi(getenv("T2S_GEMM_WN2")) : 0;
     static const int bdir = getenv("T2S_GEMM_BD") ? atoi(getenv("T2S_GEMM_BD")) : 0;
     if (epi == EPI_GATE && wn2) return launch_one<EPI_GATE, 256, 2>(a, stream);

@@ -1,0 +1,449 @@
+// Gate GEMM of the WaveGlow WN layer, "ping-pong" schedule for gfx950 (MI355X).
+//
+// Same arithmetic, operands and epilogue as conv_gemm_kernel<EPI_GATE, 256> (csrc/conv_gemm.hip: in_layers[i](x) +
+// cond_layers[i](spect) as ONE split-bf16 GEMM with K = taps*C + C_cond, tanh * sigmoid gate and the folded WN.end in the
+// epilogue; reference glow.py:159-162,172-175) - what changes is how the K loop is scheduled on the CU:
+//
+//  * the two waves that share a SIMD no longer run the same program in lockstep.  The 8 waves form two groups
+//    (waves 0-3 / 4-7: one wave of each group on every SIMD).  A K-step is cut into four phases of
+//    {LDS fragment reads + DMA issue | s_barrier | 24 MFMAs | s_barrier}, and group 1 runs one barrier behind group 0, so in
+//    every barrier interval one wave of a SIMD feeds the matrix pipe while its partner reads LDS and issues the fill
+//    (MI355X_MICROARCH.md "Two waves per SIMD" items 5 and 9; cdna_hip_programming.md section 5, the 256^2 8-phase template).
+//  * the global -> LDS fill (global_load_lds_dwordx4) is issued one 16 KB half-tile per phase, five phases ahead of its first
+//    read, and is never drained inside the loop: a counted s_waitcnt vmcnt(6) leaves three half-tiles in flight across the
+//    raw s_barriers (no __syncthreads(): its fence would emit vmcnt(0)).
+//  * a wave's 128 x 64 output block is 64 rows from each 128-row half of the A tile and 32 columns from each 128-column half
+//    of the B tile, so every phase consumes exactly one (A half, B half) pair and each LDS half-tile is read in one phase only.
+//
+// LDS: 2 buffers x [A_hi 16 K | A_lo 16 K | B_hi 16 K | B_lo 16 K]; a half-tile = rows 128h .. 128h+127 of a (hi, lo) pair.
+// Per K-step ks (buffer ks & 1), phase p:
+//      p  reads (ds_read_b128)        MFMAs (x3 split-bf16 products)        stages (2 x global_load_lds per wave)
+//      0  A half 0 (8), B half 0 (4)  acc[0..3][0..1] += A0 . B0            B half 1 of K-step ks+1
+//      1  B half 1 (4)                acc[0..3][2..3] += A0 . B1            A half 1 of K-step ks+1
+//      2  A half 1 (8)                acc[4..7][2..3] += A1 . B1            A half 0 of K-step ks+2
+//      3  -                           acc[4..7][0..1] += A1 . B0            B half 0 of K-step ks+2
+// A stage issued in phase q is retired by the vmcnt(6) of phase q+3 (every wave waits for its own pieces, then the barrier),
+// and first read in phase q+5; a slot is re-staged no earlier than two phases after its last read (WAR), which also covers
+// the one-barrier lag of group 1.
+#include "t2s_common.h"
+#include "t2s_kernels.h"
+
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace {
+
+constexpr int PP_PLANE = 16384;          // one plane tile: 256 rows x 64 B
+constexpr int PP_HALF = 8192;            // 128 rows
+constexpr int PP_BUF = 4 * PP_PLANE;     // A_hi, A_lo, B_hi, B_lo
+
+__device__ __forceinline__ int pp_swz4(int rb) { return (0x78 >> (rb * 2)) & 3; }      // {0,2,3,1}[rb]
+
+__device__ __forceinline__ void pp_glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// B-operand source of one K-step: tap-major over the conv input (row offset (tap - taps/2) * dil), then the conditioning
+// planes.  All state is wave-uniform (scalar registers); the per-thread part of the address is inside the base pointers.
+struct BCursor {
+    long off;       // bytes from the X (or S) base
+    int kc, tap;
+    bool in_s;
+};
+
+}  // namespace
+
+// ABL: timing-only ablations of the main loop (results are wrong), instantiated only under -DT2S_GEMM_ABLATE and selected with
+// env T2S_DBG_GEMM: bit 0 = no DMA, bit 1 = no MFMA, bit 2 = no LDS fragment reads.
+#ifdef T2S_GEMM_STAMPS
+// Diagnostic build only (cdna_hip_programming.md section 7, in-kernel stamps): s_memtime / s_memrealtime of wave 0 of every
+// workgroup at four points, written to a buffer nothing else reads.  [wg][0..3] = shader-clock stamps (kernel entry, loop
+// entry, loop exit, kernel exit), [wg][4..5] = 100 MHz real-time stamps at entry / exit.
+__device__ unsigned long long t2s_pp_stamps[1024 * 8];
+#define PP_STAMP(i)                                                                                        \
+    if (tid == 0) t2s_pp_stamps[(blockIdx.x & 1023) * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#define PP_RSTAMP(i)                                                                                       \
+    if (tid == 0) t2s_pp_stamps[(blockIdx.x & 1023) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define PP_STAMP(i)
+#define PP_RSTAMP(i)
+#endif
+
+template <int ABL>
+__global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2;          // group: 0 = waves 0-3, 1 = waves 4-7 (SIMD partners are wave w and w + 4)
+    const int wc = wave & 3;
+    PP_STAMP(0)
+    PP_RSTAMP(4)
+
+    // ---- XCD-aware, bijective block remap (as conv_gemm_kernel) ----
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int mt = logical % a.n_mtiles;
+    const int tt_all = logical / a.n_mtiles;
+    const int b = tt_all / a.n_ttiles;
+    const int t0 = (tt_all % a.n_ttiles) * T2S_TILE_N;
+
+    // ---- DMA sources.  LDS slot p = tid (16 B each) of a half-plane: row = tid >> 2, k-chunk slot = tid & 3, which holds
+    // logical chunk (tid & 3) ^ s[(row >> 2) & 3] (the swizzle lives on the SOURCE address and on the read address) ----
+    const int thr_off = (tid >> 2) * 64 + (((tid & 3) ^ pp_swz4((tid >> 4) & 3)) * 16);
+    const size_t a_kstride = (size_t)a.Mpad * 64;
+    const size_t x_cstride = (size_t)a.Lp * 64;
+    const char* const A_hi = (const char*)a.A_hi + (size_t)mt * 256 * 64 + thr_off;
+    const char* const A_lo = (const char*)a.A_lo + (size_t)mt * 256 * 64 + thr_off;
+    const char* const X_hi = (const char*)a.X_hi + (((size_t)b * a.xc) * a.Lp + a.halo + t0) * 64 + thr_off;
+    const char* const X_lo = (const char*)a.X_lo + (((size_t)b * a.xc) * a.Lp + a.halo + t0) * 64 + thr_off;
+    const char* const S_hi = (const char*)a.S_hi + ((size_t)b * a.sc * a.Lp + a.halo + t0) * 64 + thr_off;
+    const char* const S_lo = (const char*)a.S_lo + ((size_t)b * a.sc * a.Lp + a.halo + t0) * 64 + thr_off;
+    char* const lds_wave = smem + wave * 1024;            // + lane * 16 is implicit in the DMA
+
+    const int nk = a.nk;
+    auto cursor_at = [&](int ks) {
+        BCursor c;
+        if (ks < a.nk_x) {
+            c.tap = ks / a.xc;
+            c.kc = ks - c.tap * a.xc;
+            c.in_s = false;
+            c.off = (long)c.kc * (long)x_cstride + (long)((c.tap - (a.taps >> 1)) * a.dil) * 64;
+        } else {
+            c.tap = a.taps;
+            c.kc = ks - a.nk_x;
+            c.in_s = true;
+            c.off = (long)c.kc * (long)x_cstride;
+        }
+        return c;
+    };
+    auto advance = [&](BCursor& c) {
+        c.kc += 1;
+        c.off += (long)x_cstride;
+        if (!c.in_s && c.kc == a.xc) {
+            c.kc = 0;
+            c.tap += 1;
+            if (c.tap == a.taps) {
+                c.in_s = true;
+                c.off = 0;
+            } else {
+                c.off = (long)((c.tap - (a.taps >> 1)) * a.dil) * 64;
+            }
+        }
+    };
+    auto stage_a = [&](int ks, int half) {
+        char* dst = lds_wave + (ks & 1) * PP_BUF + half * PP_HALF;
+        const size_t off = (size_t)ks * a_kstride + (size_t)half * PP_HALF;
+        pp_glds16(A_hi + off, dst);
+        pp_glds16(A_lo + off, dst + PP_PLANE);
+    };
+    auto stage_b = [&](int ks, const BCursor& c, int half) {
+        char* dst = lds_wave + (ks & 1) * PP_BUF + 2 * PP_PLANE + half * PP_HALF;
+        const long off = c.off + (long)half * PP_HALF;
+        pp_glds16((c.in_s ? S_hi : X_hi) + off, dst);
+        pp_glds16((c.in_s ? S_lo : X_lo) + off, dst + PP_PLANE);
+    };
+
+    // ---- per-lane fragment read offsets: row = lane & 15, logical k-chunk = lane >> 4 ----
+    const int frag_off = (lane & 15) * 64 + (((lane >> 4) ^ pp_swz4((lane >> 2) & 3)) * 16);
+    const int a_frag = wr * 4096 + frag_off;                       // + half * 8192 + mm * 1024 (+ PP_PLANE for lo)
+    const int b_frag = 2 * PP_PLANE + wc * 2048 + frag_off;        // + half * 8192 + nn * 1024 (+ PP_PLANE for lo)
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 afh[4], afl[4], b0h[2], b0l[2], b1h[2], b1l[2];
+
+    // ---- prologue: K-step 0 whole, A half 0 / B half 0 of K-step 1 (the steady-state lead) ----
+    BCursor c1 = cursor_at(0);          // becomes the cursor of K-step ks + 1
+    stage_a(0, 0);
+    stage_b(0, c1, 0);
+    stage_b(0, c1, 1);
+    stage_a(0, 1);
+    advance(c1);                        // K-step 1
+    BCursor c2 = c1;                    // cursor of K-step ks + 2
+    if (nk > 1) {
+        stage_a(1, 0);
+        stage_b(1, c1, 0);
+        advance(c2);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
+
+#define PP_MFMA(ACC, AH, AL, BH, BL)                                                 \
+    if (!(ABL & 2)) {                                                                \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL, BH, ACC, 0, 0, 0);         \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, BL, ACC, 0, 0, 0);         \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, BH, ACC, 0, 0, 0);         \
+    } else {                                                                         \
+        asm volatile("" ::"v"(AH), "v"(AL), "v"(BH), "v"(BL));                       \
+    }
+
+    // One phase = read segment, barrier, matrix segment, barrier.  `MAIN` K-steps issue a stage in every phase and wait
+    // with a counted vmcnt(6); the last two K-steps have nothing (or less) left to stage and drain with vmcnt(0).
+    auto kstep = [&](int ks, auto main_tag) {
+        constexpr bool MAIN = decltype(main_tag)::value;
+        const char* sb = smem + (ks & 1) * PP_BUF;
+        // ------------------------------------------------ phase 0: A half 0 x B half 0
+        if (!(ABL & 4) || !MAIN) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            b0h[n] = *(const bf16x8*)(sb + b_frag + n * 1024);
+            b0l[n] = *(const bf16x8*)(sb + b_frag + PP_PLANE + n * 1024);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            afh[m] = *(const bf16x8*)(sb + a_frag + m * 1024);
+            afl[m] = *(const bf16x8*)(sb + a_frag + PP_PLANE + m * 1024);
+        }
+        }
+        if ((MAIN && !(ABL & 1)) || (!MAIN && ks + 1 < nk)) stage_b(ks + 1, c1, 1);
+        if (MAIN && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { PP_MFMA(acc[m][n], afh[m], afl[m], b0h[n], b0l[n]) }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ------------------------------------------------ phase 1: A half 0 x B half 1
+        if (!(ABL & 4) || !MAIN) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            b1h[n] = *(const bf16x8*)(sb + b_frag + PP_HALF + n * 1024);
+            b1l[n] = *(const bf16x8*)(sb + b_frag + PP_HALF + PP_PLANE + n * 1024);
+        }
+        }
+        if ((MAIN && !(ABL & 1)) || (!MAIN && ks + 1 < nk)) stage_a(ks + 1, 1);
+        if (MAIN && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { PP_MFMA(acc[m][2 + n], afh[m], afl[m], b1h[n], b1l[n]) }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ------------------------------------------------ phase 2: A half 1 x B half 1
+        if (!(ABL & 4) || !MAIN) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            afh[m] = *(const bf16x8*)(sb + a_frag + PP_HALF + m * 1024);
+            afl[m] = *(const bf16x8*)(sb + a_frag + PP_HALF + PP_PLANE + m * 1024);
+        }
+        }
+        if ((MAIN && !(ABL & 1)) || (!MAIN && ks + 2 < nk)) stage_a(ks + 2, 0);
+        if (MAIN && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { PP_MFMA(acc[4 + m][2 + n], afh[m], afl[m], b1h[n], b1l[n]) }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ------------------------------------------------ phase 3: A half 1 x B half 0 (fragments still in registers)
+        if ((MAIN && !(ABL & 1)) || (!MAIN && ks + 2 < nk)) stage_b(ks + 2, c2, 0);
+        if (MAIN && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { PP_MFMA(acc[4 + m][n], afh[m], afl[m], b0h[n], b0l[n]) }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // cursors: c1 -> K-step ks + 2, c2 -> K-step ks + 3
+        c1 = c2;
+        advance(c2);
+    };
+
+    int ks = 0;
+    PP_STAMP(1)
+    for (; ks + 2 < nk; ++ks) kstep(ks, std::true_type{});
+    for (; ks < nk; ++ks) kstep(ks, std::false_type{});
+    if (wr == 0) __builtin_amdgcn_s_barrier();          // matches group 1's extra barrier in front of the loop
+    PP_STAMP(2)
+#undef PP_MFMA
+
+    // ---- epilogue (conv_gemm_kernel's EPI_GATE, with this kernel's row / column ownership).
+    // C/D map of mfma 16x16: col = lane & 15 (time), row = 4 * (lane >> 4) + reg (channel).
+    // m-tile m of this wave covers packed rows (m >> 2) * 128 + wr * 64 + (m & 3) * 16 of the M tile: m even = tanh rows,
+    // m odd = sigmoid rows of the same 16 channels (PERM_GATE groups of 32 packed rows).
+    // n-tile n covers tile columns (n >> 1) * 128 + wc * 32 + (n & 1) * 16.
+    const int tcol = lane & 15;
+    const int rq = (lane >> 4) * 4;
+    f32x4 facc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) facc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pair = 0; pair < 2; ++pair) {
+        u16x4 hv[2][4], lv[2][4];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int mp = pair * 2 + half;
+            const int prow = mt * 256 + pair * 128 + wr * 64 + half * 32 + rq;          // tanh rows prow..prow+3
+            // gate in exp2 / rcp form: E = e^(2x), F = e^(-y);  tanh(x) = (E - 1) / (E + 1),  sigmoid(y) = 1 / (1 + F).
+            // The bias is folded into the exponent (one fma per value); x is clamped at 10 (tanh(10) rounds to 1.0f) so that E
+            // stays finite; F = inf (y < -88) gives 1 / inf = 0, the correctly rounded limit.  v_exp_f32 / v_rcp_f32 are 1 ulp.
+            constexpr float L2E = 1.4426950408889634f;
+            const f32x4 bt0 = *(const f32x4*)(a.bias + prow);
+            const f32x4 bs0 = *(const f32x4*)(a.bias + prow + 16);
+            const f32x4 bt = bt0 * (2.0f * L2E), bs = bs0 * (-L2E);
+            const int ch = mt * 128 + pair * 64 + wr * 32 + half * 16 + rq;             // channels ch..ch+3
+            const bool chv = ch < a.C;
+            const size_t obase = (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int t = t0 + (n >> 1) * 128 + wc * 32 + (n & 1) * 16 + tcol;
+                u16x4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
+                if (chv && t < a.L) {
+                    const size_t o = obase + (size_t)t * 32;
+                    if (a.T_hi) {      // training: tanh and sigmoid are kept for the backward pass
+                        u16x4 thi, tlo, ghi, glo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float E = __builtin_amdgcn_exp2f(fminf(fmaf(acc[2 * mp][n][e], 2.0f * L2E, bt[e]), 20.0f * L2E));
+                            const float F = __builtin_amdgcn_exp2f(fmaf(acc[2 * mp + 1][n][e], -L2E, bs[e]));
+                            const float tv = (E - 1.0f) * __builtin_amdgcn_rcpf(E + 1.0f);
+                            const float gv = __builtin_amdgcn_rcpf(1.0f + F);
+                            u16 h, l;
+                            split_bf16(tv * gv, h, l);
+                            hi[e] = h;
+                            lo[e] = l;
+                            split_bf16(tv, h, l);
+                            thi[e] = h;
+                            tlo[e] = l;
+                            split_bf16(gv, h, l);
+                            ghi[e] = h;
+                            glo[e] = l;
+                        }
+                        *(u16x4*)(a.T_hi + o) = thi;
+                        *(u16x4*)(a.T_lo + o) = tlo;
+                        *(u16x4*)(a.G_hi + o) = ghi;
+                        *(u16x4*)(a.G_lo + o) = glo;
+                    } else {           // forward / infer: only the product is needed - one reciprocal for both
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float E = __builtin_amdgcn_exp2f(fminf(fmaf(acc[2 * mp][n][e], 2.0f * L2E, bt[e]), 20.0f * L2E));
+                            const float F = __builtin_amdgcn_exp2f(fmaf(acc[2 * mp + 1][n][e], -L2E, bs[e]));
+                            const float v = (E - 1.0f) * __builtin_amdgcn_rcpf((E + 1.0f) * (1.0f + F));
+                            u16 h, l;
+                            split_bf16(v, h, l);
+                            hi[e] = h;
+                            lo[e] = l;
+                        }
+                    }
+                    *(u16x4*)(a.O_hi + o) = hi;
+                    *(u16x4*)(a.O_lo + o) = lo;
+                }
+                hv[half][n] = hi;
+                lv[half][n] = lo;
+            }
+        }
+        if (a.fold_A) {
+            // fold_A blocks are indexed by the 32-channel block of the M tile (endfold_weights_kernel: block = c >> 5)
+            const u16* fa = a.fold_A + ((size_t)(mt * 4 + pair * 2 + wr) * 2 * 64 + lane) * 8;
+            const bf16x8 wh = *(const bf16x8*)fa;
+            const bf16x8 wl = *(const bf16x8*)(fa + 64 * 8);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+                const u16x8 bh8 = {hv[0][n][0], hv[0][n][1], hv[0][n][2], hv[0][n][3],
+                                   hv[1][n][0], hv[1][n][1], hv[1][n][2], hv[1][n][3]};
+                const u16x8 bl8 = {lv[0][n][0], lv[0][n][1], lv[0][n][2], lv[0][n][3],
+                                   lv[1][n][0], lv[1][n][1], lv[1][n][2], lv[1][n][3]};
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, bh8);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, bl8);
+                facc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, bh, facc[n], 0, 0, 0);
+                facc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bl, facc[n], 0, 0, 0);
+                facc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bh, facc[n], 0, 0, 0);
+            }
+        }
+    }
+    if (a.fold_A && lane < 32) {     // D rows j = 4 * (lane >> 4) + reg < 8, col = time
+        const int slot = mt * 2 + wr;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int t = t0 + (n >> 1) * 128 + wc * 32 + (n & 1) * 16 + tcol;
+            if (t >= a.L) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float* dst = a.fold_acc + ((((size_t)slot * a.B + b) * 8 + rq + e) * a.L + t);
+                *dst = a.fold_init ? facc[n][e] : *dst + facc[n][e];
+            }
+        }
+    }
+#ifdef T2S_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    PP_STAMP(3)
+    PP_RSTAMP(5)
+}
+
+template <int ABL>
+static hipError_t launch_pp(const ConvGemmArgs& a, hipStream_t stream) {
+    const int nwg = a.n_mtiles * a.n_ttiles * a.B;
+    constexpr int lds = 2 * PP_BUF;
+    static std::atomic<unsigned long long> attr_mask{0};
+    const hipError_t e = t2s_raise_lds_limit((const void*)gate_gemm_pp_kernel<ABL>, lds, attr_mask);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(gate_gemm_pp_kernel<ABL>, dim3(nwg), dim3(512), lds, stream, a);
+    return hipGetLastError();
+}
+
+#ifdef T2S_GEMM_STAMPS
+extern "C" int t2s_debug_read_pp_stamps(unsigned long long* host_out, int n_words) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(t2s_pp_stamps), sizeof(unsigned long long) * n_words);
+}
+#endif
+
+hipError_t t2s_launch_gate_gemm_pp(const ConvGemmArgs& a, hipStream_t stream) {
+#ifdef T2S_GEMM_ABLATE
+    static const int dbg = getenv("T2S_DBG_GEMM") ? atoi(getenv("T2S_DBG_GEMM")) : 0;
+    switch (dbg & 7) {
+        case 1: return launch_pp<1>(a, stream);
+        case 2: return launch_pp<2>(a, stream);
+        case 3: return launch_pp<3>(a, stream);
+        case 4: return launch_pp<4>(a, stream);
+        case 5: return launch_pp<5>(a, stream);
+        case 6: return launch_pp<6>(a, stream);
+        case 7: return launch_pp<7>(a, stream);
+        default: break;
+    }
+#endif
+    return launch_pp<0>(a, stream);
+}

@@ -54,6 +54,8 @@ struct ConvGemmArgs {
 };
 
 hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a, int epi, hipStream_t stream, int mt_rows = 256);
+// EPI_GATE, 256 x 256 tile, plain K order (nk = taps * xc + sc): the ping-pong schedule of csrc/gate_gemm_pp.hip
+hipError_t t2s_launch_gate_gemm_pp(const ConvGemmArgs& a, hipStream_t stream);
 
 struct PackArgs {
     const float* v;        // [O][Cin][Kt]
