@@ -1,7 +1,10 @@
 """Bit-exact symbol indexing (north star; SURVEY.md section 4 known answers, 8f N2).  CPU only."""
+import json
+import os
 import unicodedata
 
 import numpy as np
+import pytest
 
 from text2speech_amd import text as T
 
@@ -37,8 +40,53 @@ def test_punctuation_unknowns_and_roundtrip():
     seq = T.text_to_sequence(s)
     assert seq[-1] == 1 and 73 in seq and 69 in seq and 79 in seq
     assert T.sequence_to_text(seq, skip_eos_and_pad=True, combine_jamo=True) == s
-    # characters outside the table are dropped, as the reference's _should_keep_symbol does
-    assert T.text_to_sequence("가A1나").tolist() == T.text_to_sequence("가나").tolist()
+    # Latin letters and digits are spelled out by normalize() (reference text/korean.py:151,163-177) ...
+    assert T.text_to_sequence("가A1나").tolist() == T.text_to_sequence("가에이일나").tolist()
+    # ... and characters that are still outside the table afterwards are dropped, as the reference's _should_keep_symbol does
+    assert T.text_to_sequence("가#나@").tolist() == T.text_to_sequence("가나").tolist()
     assert T.text_to_sequence("").tolist() == [1]
     # ids feed the model directly
     assert int(seq.max()) < 80 and int(seq.min()) >= 1
+
+
+def _golden():
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "text_normalize.json")
+    return json.load(open(p, encoding="utf-8"))
+
+
+def test_normalize_bit_exact_vs_reference_outputs():
+    """normalize() against the reference's own outputs (tools/gen_golden_text.py imports text/korean.py of the reference):
+    the reference's demo inputs (korean.py:335-341) plus digits / separators / signs / decimals, count words, units, English
+    words and abbreviations, the phrase table, parenthesised day notes and Hanja."""
+    from text2speech_amd.text.korean import normalize
+    g = _golden()
+    assert len(g["cases"]) >= 100
+    for c in g["cases"]:
+        assert normalize(c["text"]) == c["normalized"], c["text"]
+
+
+def test_ids_follow_the_normalized_text_bit_exact():
+    """text_to_sequence(raw) == ids of the jamo decomposition of the REFERENCE's normalized string (decomposition pinned by
+    test_every_syllable_against_unicode_nfd and the known answers above)."""
+    g = _golden()
+    n_changed = 0
+    for c in g["cases"]:
+        want = [T._symbol_to_id[t] for t in T.hangul_to_jamo(c["normalized"]) if T._should_keep_symbol(t)] + [1]
+        got = T.text_to_sequence(c["text"])
+        assert got.dtype == np.int32 and got.tolist() == want, c["text"]
+        n_changed += c["text"].strip() != c["normalized"]
+    assert n_changed > 80          # the fixture is about inputs that normalisation rewrites
+    # spot values worked by hand from the reference's demo (korean.py:337-340)
+    assert T.text_to_sequence("60.3%").tolist() == T.text_to_sequence("육십쩜 삼퍼센트").tolist()
+    # a count word selects native numerals digit by digit (the reference's rule, korean.py:279-283): 3,600마리 -> 세천여섯백마리
+    assert T.text_to_sequence("오늘(13일) 3,600마리 강아지가").tolist() == T.text_to_sequence("오늘 세천여섯백마리 강아지가").tolist()
+
+
+def test_normalize_reference_quirks_are_kept():
+    from text2speech_amd.text.korean import normalize
+    assert normalize("0개") == "영"                      # the count word after a zero is lost (korean.py:264-265)
+    assert normalize("12.5개") == "열두개"                # a decimal part in front of a count word is dropped (group 1 only)
+    with pytest.raises(ValueError):
+        normalize("+5")                                  # int('+') in the reference's digit loop
+    # unpinned corner (nltk punkt absent upstream here): single-sentence quotes are re-quoted with ASCII apostrophes
+    assert normalize('"저돌"(猪突) 입니다.') == "'저돌' 입니다."

@@ -7,15 +7,16 @@ vowel 0x1161 + (s%588)//28, tail 0x11A7 + s%28).  Pinned by the reference's own 
 (text/__init__.py:41, text/cleaners.py:29, text/symbols.py:19-28) and cross-checked against
 ``unicodedata.normalize('NFD', ...)``.
 
-Not restated: the dictionary / regex driven ``normalize()`` (numbers, English words, quotes ->
-Korean words, text/korean.py:163-341) — "parity unpinned" (SURVEY.md 8c): the reference holds no expected
-outputs for it.  ``text_to_sequence`` therefore expects text that normalisation would leave unchanged
-(Hangul, spaces and the punctuation in the table); anything else is dropped exactly as the reference's
-``_should_keep_symbol`` drops unknown symbols.
+``tokenize`` runs ``normalize()`` first, as the reference does (text/korean.py:151): numbers, units, English words and
+abbreviations, quotes -> Korean words (``text/korean.py`` of this package, pinned by the reference's own outputs in
+tests/golden/text_normalize.json).  Symbols that are not in the table after that are dropped exactly as the reference's
+``_should_keep_symbol`` drops them.
 """
 import re
 
 import numpy as np
+
+from .korean import normalize
 
 PAD = "_"
 EOS = "~"
@@ -68,8 +69,8 @@ def jamo_to_hangul(tokens):
 
 
 def tokenize(text, as_id=False):
-    """Reference text/korean.py:149-160 without ``normalize``: jamo tokens + EOS."""
-    tokens = hangul_to_jamo(text.strip())
+    """Reference text/korean.py:149-160: normalize, then jamo tokens + EOS."""
+    tokens = hangul_to_jamo(normalize(text))
     if as_id:
         return [_symbol_to_id[t] for t in tokens] + [_symbol_to_id[EOS]]
     return tokens + [EOS]
