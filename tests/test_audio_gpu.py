@@ -111,3 +111,33 @@ def test_griffin_lim_vs_oracle():
     mg, _ = st.transform(got)
     mw, _ = A.stft_transform(want, fwd)
     assert _rel(mg, mw) < 5e-3
+
+
+def test_denoiser_and_griffin_lim_vs_reference_golden(golden_dir):
+    """HIP Denoiser / griffin_lim against what the REFERENCE's own classes produced (tests/golden/audio_denoise_gl.npz):
+    the bias spectrum of the small vocoder, two denoised clips (strength 0.1 and 1.0) and a 6-iteration Griffin-Lim signal
+    from the reference's captured initial phase."""
+    import os
+    import numpy as np
+    import text2speech_amd.glow as glow
+    from text2speech_amd.audio import STFT, Denoiser, griffin_lim
+    _lib.load()
+    g = np.load(os.path.join(golden_dir, "audio_denoise_gl.npz"))
+    cfg = synth.WAVEGLOW_SMALL
+    m = glow.WaveGlow(**cfg)
+    m.load_state_dict(synth.waveglow_state(cfg), strict=True)
+    m = m.to(DEV).eval()
+    dn = Denoiser(m).to(DEV)
+    assert _rel(dn.bias_spec, g["bias_spec"]) < 1e-3
+    gen = torch.Generator().manual_seed(44)
+    clip = torch.rand(2, 4096, generator=gen) * 0.6 - 0.3
+    for key, strength in (("denoised_s01", 0.1), ("denoised_s10", 1.0)):
+        got = dn(clip.to(DEV), strength=strength)
+        assert tuple(got.shape) == g[key].shape
+        assert _rel(got, g[key]) < 1e-3, key
+    st = STFT(1024, 256, 1024).to(DEV)
+    sig = griffin_lim(torch.from_numpy(g["gl_mag"]).to(DEV), st, n_iters=6, angles=torch.from_numpy(g["gl_angles"]).to(DEV))
+    assert tuple(sig.shape) == g["gl_signal"].shape
+    assert _rel(sig, g["gl_signal"]) < 2e-2                 # the iteration amplifies rounding differences
+    mg, _ = st.transform(sig)
+    assert _rel(mg, st.transform(torch.from_numpy(g["gl_signal"]).to(DEV))[0]) < 5e-3

@@ -90,3 +90,34 @@ def test_product_filterbank_and_bases_match_oracle_on_cpu():
         st.transform(torch.zeros(1, 4096))            # host tensor: there is no CPU path
     with pytest.raises(RuntimeError):
         ts.mel_spectrogram(torch.zeros(1, 4096))
+
+
+def test_denoiser_and_griffin_lim_vs_reference(golden_dir):
+    """The reference's own Denoiser (waveglow/denoiser.py:7-40) and griffin_lim (utils/audio_processing.py:51-67) outputs
+    (tests/golden/audio_denoise_gl.npz, tools/gen_golden_audio.py) against the oracle's restatements, with the bias spectrum
+    derived through the WaveGlow oracle exactly as Denoiser.__init__ derives it (zero mel [1, 80, 88], sigma = 0)."""
+    from oracle import waveglow_oracle as O
+    from text2speech_amd import synth
+    g = np.load(os.path.join(golden_dir, "audio_denoise_gl.npz"))
+    cfg = synth.WAVEGLOW_SMALL
+    sd = synth.waveglow_state(cfg)
+    fwd, inv = A.stft_basis(1024, 256, 1024)
+    L = 88 * 256 // cfg["n_group"]
+    with torch.no_grad():
+        bias_audio = O.waveglow_infer(sd, cfg, torch.zeros(1, 80, 88), torch.zeros(1, 4, L),
+                                      [torch.zeros(1, 2, L) for _ in range(2)], sigma=0.0)
+        bias = A.stft_transform(bias_audio, fwd)[0][:, :, 0][:, :, None]
+    assert bias.shape == g["bias_spec"].shape
+    assert _rel(bias, g["bias_spec"]) < 1e-5
+    gen = torch.Generator().manual_seed(44)
+    clip = torch.rand(2, 4096, generator=gen) * 0.6 - 0.3
+    for key, strength in (("denoised_s01", 0.1), ("denoised_s10", 1.0)):
+        out = A.denoise(clip, torch.from_numpy(g["bias_spec"]), fwd, inv, strength=strength)
+        assert out.shape == g[key].shape
+        assert _rel(out, g[key]) < 1e-4, key
+    # the clamp at zero is active at strength 1.0: the two outputs differ by more than a scale
+    assert _rel(g["denoised_s10"], g["denoised_s01"]) > 1e-2
+    # griffin_lim from the reference's captured initial phase
+    sig = A.griffin_lim(torch.from_numpy(g["gl_mag"]), torch.from_numpy(g["gl_angles"]), fwd, inv, n_iters=6)
+    assert sig.shape == g["gl_signal"].shape
+    assert _rel(sig, g["gl_signal"]) < 2e-3

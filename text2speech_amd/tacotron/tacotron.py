@@ -547,7 +547,7 @@ class Tacotron(nn.Module):
         with torch.no_grad():
             out = self._eng().forward(text_inputs, text_lengths.data, mels, output_lengths.data, prenet_masks,
                                       train_masks=train_masks)
-        return self.parse_output(out, output_lengths.data)
+        return self._as_module_dtype(self.parse_output(out, output_lengths.data))
 
     def inference(self, inputs, speaker_id=None, prenet_masks=None):
         """Autoregressive decode (reference tacotron.py:51-65)."""
@@ -556,7 +556,15 @@ class Tacotron(nn.Module):
             raise NotImplementedError("Tacotron.inference is an eval-mode path (reference inference.py:61); call .eval()")
         with torch.no_grad():
             out = self._eng().inference(inputs, prenet_masks)
-        return self.parse_output(out)
+        return self._as_module_dtype(self.parse_output(out))
+
+    def _as_module_dtype(self, outputs):
+        """After ``model.half()`` (reference inference.py:61) the reference's outputs are half tensors; the kernels here
+        compute in f32 from the (half-rounded) weights and the results are cast on the way out."""
+        dt = self.embedding.weight.dtype
+        if dt in (torch.float16, torch.bfloat16):
+            return [o.to(dt) if torch.is_floating_point(o) else o for o in outputs]
+        return outputs
 
     def parse_output(self, outputs, output_lengths=None):
         """Reference tacotron.py:67-76: zero mel / 1e3 gate beyond each output length."""

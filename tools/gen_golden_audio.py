@@ -77,6 +77,54 @@ def main():
             out["c_inv_basis"] = st.inverse_basis.numpy()
     np.savez_compressed(os.path.join(OUT, "audio_stft.npz"), **out)
     print("wrote audio_stft.npz", {k: v.shape for k, v in out.items()})
+    denoiser_and_griffin_lim()
+
+
+def denoiser_and_griffin_lim():
+    """The reference's Denoiser (waveglow/denoiser.py:7-40) on the reference's WaveGlow with this repo's seeded small
+    weights, and the reference's griffin_lim (utils/audio_processing.py:51-67) -> tests/golden/audio_denoise_gl.npz.
+
+    Further shims, device placement / RNG capture only: torch.nn.Module.cuda is a no-op (denoiser.py:15 moves its STFT to the
+    GPU), torch.cuda.FloatTensor = torch.FloatTensor for WaveGlow.infer's noise constructors (sigma = 0 here, so the draws
+    are multiplied by zero), and griffin_lim's numpy draw of the initial phase is replayed from a seeded numpy RNG so that
+    the same angles can be handed to the oracle / the HIP path."""
+    from text2speech_amd import synth
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.FloatTensor = torch.FloatTensor
+    sys.path.insert(0, "/root/reference/waveglow")
+    import glow as ref_glow          # noqa: E402  (the reference)
+    import denoiser as ref_denoiser  # noqa: E402  (the reference)
+    from utils.audio_processing import griffin_lim as ref_griffin_lim  # noqa: E402
+
+    cfg = synth.WAVEGLOW_SMALL
+    torch.manual_seed(0)
+    wg = ref_glow.WaveGlow(**cfg)
+    wg.load_state_dict(synth.waveglow_state(cfg), strict=True)
+    wg.eval()
+    out = {}
+    den = ref_denoiser.Denoiser(wg)                    # mode='zeros': bias spectrum of the vocoder at a zero mel
+    out["bias_spec"] = den.bias_spec.numpy()           # [1, 513, 1]
+    gen = torch.Generator().manual_seed(44)
+    clip = torch.rand(2, 4096, generator=gen) * 0.6 - 0.3
+    with torch.no_grad():
+        out["denoised_s01"] = den(clip, strength=0.1).numpy()
+        out["denoised_s10"] = den(clip, strength=1.0).numpy()      # strong enough for the clamp at zero to bite
+    # griffin_lim: magnitudes of a seeded clip, 6 iterations, the reference's own initial-phase draw captured
+    st = STFT(filter_length=1024, hop_length=256, win_length=1024)
+    sig = torch.rand(1, 6000, generator=gen) * 1.2 - 0.6
+    with torch.no_grad():
+        mag, _ = st.transform(sig)
+    np.random.seed(1234)
+    angles = np.angle(np.exp(2j * np.pi * np.random.rand(*mag.size()))).astype(np.float32)
+    np.random.seed(1234)                               # the call below draws the same numbers
+    with torch.no_grad():
+        rec = ref_griffin_lim(mag, st, n_iters=6)
+    out["gl_mag"] = mag.numpy()
+    out["gl_angles"] = angles
+    out["gl_signal"] = rec.numpy()
+    np.savez_compressed(os.path.join(OUT, "audio_denoise_gl.npz"), **out)
+    print("wrote audio_denoise_gl.npz", {k: v.shape for k, v in out.items()},
+          "bias max %.4f" % float(np.abs(out["bias_spec"]).max()))
 
 
 if __name__ == "__main__":
