@@ -235,7 +235,8 @@ typedef struct t2s_taco_decoder {
     float att_drop_scale, dec_drop_scale;
     float *att_h0, *att_h1, *att_c, *dec_h0, *dec_h1, *dec_c;   /* ping-pong h (step parity), c in place */
     float *att_w, *att_wcum, *ctx, *q, *energies, *pre1, *pre2; /* [B][T_in] x3, [B][enc], [B][att_dim], ... */
-    float *q_part;                       /* [att_rnn/4][B][att_dim] partial queries (small-batch fused attention) or NULL */
+    float *q_part;                       /* [att_rnn/2][B][att_dim] scratch: per-workgroup partial queries written by the attention
+                                          * cell and summed by the fused attention kernel (B <= 8), or NULL (W_query . h there) */
     float *mel_gate_out;                 /* [B][n_mel+1][T_cap] (autoregressive), row n_mel = gate logit */
     float *align_out;                    /* [B][T_cap][T_in] */
     float *hc_all;                       /* teacher forced: [T][B][dec+enc] */

@@ -140,6 +140,11 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         const bool fused_att = B <= 8 && T <= 512 && d->w_loc_denseT && d->att_dim <= 128;
         if (d->att_gates_all) { ca.gates_out = d->att_gates_all + (size_t)s * B * 4 * A; ca.c_out = d->att_c_all + (size_t)s * B * A; }
         if (d->att_h_all) { ca.h_copy = d->att_h_all + (size_t)s * B * A; ca.s_copy = A; }
+        // small batch: the attention cell's workgroups emit partial queries (their own hidden units' columns of W_query), so
+        // the fused attention kernel sums 128 KB of partials instead of pulling the 512 KB of W_query through one CU
+        const bool q_parts = fused_att && d->q_part != nullptr;
+        const int units = ca.gates_out ? 2 : 4;             // hidden units per workgroup of lstm_cell_kernel (training / eval)
+        if (q_parts) { ca.w_q = d->w_query; ca.q_part = d->q_part; ca.q_dim = d->att_dim; }
         T2S_CHECK_HIP(t2s_launch_lstm_cell(ca, stream));
         // 2.-4. attention: query, location-sensitive energies, softmax, context, cumulative weights
         AttArgs aa;
@@ -153,6 +158,7 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         aa.w_query = d->w_query; aa.h_att = ah_out; aa.w_loc_denseT = d->w_loc_denseT; aa.att_rnn = A;
         if (d->q_all) aa.q_save = d->q_all + (size_t)s * B * d->att_dim;
         if (d->wcum_all) aa.wcum_save = d->wcum_all + (size_t)s * B * T;
+        if (q_parts) { aa.q_part = d->q_part; aa.n_part = A / units; }
         if (fused_att) {
             // small batch: one fused launch per step (one workgroup per batch element)
             T2S_CHECK_HIP(t2s_launch_att_fused(aa, stream));

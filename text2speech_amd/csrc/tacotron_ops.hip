@@ -20,29 +20,31 @@ static __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.
 
 // ------------------------------------------------------------------------------------------------
 // Input vector of a GEMV = concatenation of up to three segments (e.g. [prenet_out | context | h]).
-struct XSeg {
-    const float* p[3];
-    int n[3];
-    long stride[3];      // per-item stride (floats)
-};
-
-// per-lane float4 slot v covers k = (v*64 + lane)*4 .. +3 of the concatenated vector
+// per-lane float4 slot v covers k = (v*64 + lane)*4 .. +3 of the concatenated vector.
+//
+// The segment pointers / sizes / strides are passed as plain scalars (they stay in SGPRs) and chosen with selects.  They must
+// NOT sit in a struct or array that is indexed or address-selected at run time: hipcc then keeps that object in memory,
+// promotes it to LDS, and addresses the promoted copy through the flat work-item id, which it derives from the AQL dispatch
+// packet - a scalar load from HOST memory over PCIe in the middle of the kernel (measured at B = 1: 5-11 us of the 12.9 us
+// the 337 x 1536 projection GEMV took; .amdhsa_user_sgpr_dispatch_ptr in the kernel descriptor is the tell-tale).
 template <int NV4>
 struct LaneMap {
     const float* xp[NV4];
     long xs[NV4];
     bool valid[NV4];
-    __device__ void init(const XSeg& s, int lane) {
-        const int K = s.n[0] + s.n[1] + s.n[2];
+    __device__ __forceinline__ void init(const float* p0, const float* p1, const float* p2, int n0, int n1, int n2, long s0,
+                                         long s1, long s2, int lane) {
+        const int K = n0 + n1 + n2;
 #pragma unroll
         for (int v = 0; v < NV4; ++v) {
-            int k = (v * 64 + lane) * 4;
+            const int k = (v * 64 + lane) * 4;
             valid[v] = k < K;
-            int seg = 0;
-            if (k >= s.n[0]) { k -= s.n[0]; seg = 1; if (k >= s.n[1]) { k -= s.n[1]; seg = 2; } }
-            if (!valid[v]) { seg = 0; k = 0; }
-            xp[v] = s.p[seg] + k;
-            xs[v] = s.stride[seg];
+            const bool in0 = k < n0, in1 = !in0 && (k - n0) < n1;
+            const float* base = in0 ? p0 : (in1 ? p1 : p2);
+            const long stride = in0 ? s0 : (in1 ? s1 : s2);
+            const int kk = in0 ? k : (in1 ? k - n0 : k - n0 - n1);
+            xp[v] = valid[v] ? base + kk : p0;
+            xs[v] = valid[v] ? stride : s0;
         }
     }
 };
@@ -51,40 +53,90 @@ struct LaneMap {
 template <int NV4>
 static __device__ __forceinline__ void load_row(f32x4 (&w)[NV4], const float* W1, int ld1, int k1, const float* W2,
                                                 int ld2, int k2, int row, int lane) {
+    // Every load is issued unconditionally from an in-range address and masked afterwards: a load under a per-slot runtime
+    // condition makes hipcc branch around it and wait vmcnt(0) per slot - NV4 dependent memory round trips instead of one
+    // (cdna_hip_programming.md section 5, ".s-level traps" (c); measured here: 12.6 us -> a few us for the 337 x 1536 GEMV).
+    const float* p[NV4];
+    bool ok[NV4];
 #pragma unroll
     for (int v = 0; v < NV4; ++v) {
         const int k = (v * 64 + lane) * 4;
-        if (k < k1) w[v] = *(const f32x4*)(W1 + (size_t)row * ld1 + k);
-        else if (k < k1 + k2) w[v] = *(const f32x4*)(W2 + (size_t)row * ld2 + (k - k1));
-        else w[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ok[v] = k < k1 + k2;
+        const bool in2 = k >= k1 && k2 > 0;
+        p[v] = in2 ? W2 + (size_t)row * ld2 + (ok[v] ? k - k1 : 0) : W1 + (size_t)row * ld1 + (k < k1 ? k : 0);
     }
+#pragma unroll
+    for (int v = 0; v < NV4; ++v) w[v] = *(const f32x4*)p[v];
+#pragma unroll
+    for (int v = 0; v < NV4; ++v)
+        if (!ok[v]) w[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
 // ------------------------------------------------------------------------------------------------
 // y[item][row] = act(bias + W[row] . x[item]) * mask   — one wave per output row, weights in registers.
 // Restates every small Linear on the decoder path: query_layer (tacotron.py:137), linear_projection +
 // gate_layer (:387-392), Prenet layers (modules.py:19-22), memory_layer (tacotron.py:306).
+#ifdef T2S_CLOCK_PROBE
+// Diagnostic build only: (kernel id, s_memtime, s_memrealtime) at entry and exit of workgroup 0 of the decoder-chain kernels,
+// in a ring nothing else reads (tools/decode_probe.py).  Tells the in-kernel clock and the body time of each launch.
+__device__ unsigned long long t2s_probe_buf[1 << 16][12];
+__device__ unsigned int t2s_probe_idx;
+extern "C" int t2s_debug_read_probe(unsigned long long* host_out, unsigned int* n) {
+    hipError_t e = hipMemcpyFromSymbol(n, HIP_SYMBOL(t2s_probe_idx), sizeof(unsigned int));
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(t2s_probe_buf), sizeof(unsigned long long) * 12 * (1 << 16));
+}
+#define PROBE_BEGIN(ID)                                                                        \
+    unsigned int probe_i = 0;                                                                  \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                              \
+        probe_i = atomicAdd(&t2s_probe_idx, 1u) & 0xffff;                                      \
+        t2s_probe_buf[probe_i][0] = (ID);                                                      \
+        t2s_probe_buf[probe_i][1] = __builtin_amdgcn_s_memtime();                              \
+        t2s_probe_buf[probe_i][2] = __builtin_amdgcn_s_memrealtime();                          \
+    }
+#define PROBE_END()                                                                            \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                              \
+        t2s_probe_buf[probe_i][3] = __builtin_amdgcn_s_memtime();                              \
+        t2s_probe_buf[probe_i][4] = __builtin_amdgcn_s_memrealtime();                          \
+    }
+#define PROBE_MID(J)                                                                           \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                              \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                            \
+        t2s_probe_buf[probe_i][5 + (J)] = __builtin_amdgcn_s_memrealtime();                    \
+    }
+#else
+#define PROBE_BEGIN(ID)
+#define PROBE_END()
+#define PROBE_MID(J)
+#endif
+
 template <int NV4>
 __global__ __launch_bounds__(256) void gemv_rows_kernel(const GemvArgs a) {
+    PROBE_BEGIN(100 + NV4)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.rows) return;
+    if (row >= a.rows) return;          // (never workgroup 0 / thread 0: the probe above always reaches its end)
     f32x4 w[NV4];
     load_row<NV4>(w, a.W1, a.ld1, a.k1, a.W2, a.ld2, a.k2, row, lane);
-    XSeg s = {{a.x1, a.x2, a.x3}, {a.n1, a.n2, a.n3}, {a.sx1, a.sx2, a.sx3}};
+    PROBE_MID(0)
     LaneMap<NV4> lm;
-    lm.init(s, lane);
+    lm.init(a.x1, a.x2, a.x3, a.n1, a.n2, a.n3, a.sx1, a.sx2, a.sx3, lane);
+    PROBE_MID(3)
     const float bias = (a.bias1 ? a.bias1[row] : 0.f) + (a.bias2 ? a.bias2[row] : 0.f);
+    PROBE_MID(4)
     for (int it = blockIdx.y; it < a.items; it += gridDim.y) {
         float acc = 0.f;
+        f32x4 x[NV4];
+#pragma unroll
+        for (int v = 0; v < NV4; ++v) x[v] = *(const f32x4*)(lm.xp[v] + (size_t)it * lm.xs[v]);    // all in flight together
+        PROBE_MID(1)
 #pragma unroll
         for (int v = 0; v < NV4; ++v) {
-            if (lm.valid[v]) {
-                const f32x4 x = *(const f32x4*)(lm.xp[v] + (size_t)it * lm.xs[v]);
-                acc += w[v][0] * x[0] + w[v][1] * x[1] + w[v][2] * x[2] + w[v][3] * x[3];
-            }
+            if (!lm.valid[v]) x[v] = (f32x4){0.f, 0.f, 0.f, 0.f};        // a select, not a branch: the weights there are 0 too
+            acc += w[v][0] * x[v][0] + w[v][1] * x[v][1] + w[v][2] * x[v][2] + w[v][3] * x[v][3];
         }
         acc = wave_sum(acc);
+        PROBE_MID(2)
         if (lane == 0) {
             float y = acc + bias;
             if (a.split_row > 0 && row >= a.split_row) {
@@ -101,6 +153,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const GemvArgs a) {
             }
         }
     }
+    PROBE_END()
 }
 
 hipError_t t2s_launch_gemv(const GemvArgs& a, hipStream_t stream) {
@@ -134,12 +187,21 @@ hipError_t t2s_launch_gemv(const GemvArgs& a, hipStream_t stream) {
 // UNITS = hidden units per workgroup (4 -> 1024 threads, 2 -> 512 threads); SAVE = keep gates / cell state (training)
 template <int NVW, int UNITS, bool SAVE>
 __global__ __launch_bounds__(UNITS * 256) void lstm_cell_kernel(const LstmCellArgs a) {
+    PROBE_BEGIN(200 + NVW)
     __shared__ float s_part[UNITS][4][4][64];        // [unit][kq][gate][item]
+    __shared__ float s_h[UNITS][64];                 // new h of this workgroup's units (for the partial attention query)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int ul = wave >> 2, kq = wave & 3;
     const int u = blockIdx.x * UNITS + ul;           // H % UNITS == 0 is checked by the caller
     const int K1 = a.n1 + a.n2, K = K1 + a.H;
+    // Everything the tail of the kernel needs from memory is requested now, next to the weight rows, so the pointwise update
+    // and the partial query do not add dependent round trips behind the reduction: the gate biases, the cell state of the
+    // first item chunk, and this workgroup's UNITS columns of W_query.
+    __shared__ float s_bsum[UNITS][4];
+    __shared__ float s_wq[UNITS][128];
+    float c_pre = 0.f;
+    if (kq == 0 && lane < a.B) c_pre = a.c[(size_t)lane * a.H + u];
     f32x4 w[4][NVW];
     const float* xp[NVW];
     long xs[NVW];
@@ -149,31 +211,42 @@ __global__ __launch_bounds__(UNITS * 256) void lstm_cell_kernel(const LstmCellAr
         const int v = kq + 4 * j;
         int k = (v * 64 + lane) * 4;
         valid[j] = k < K;
+        // unconditional loads from clamped addresses, masked afterwards (no branch + vmcnt(0) per slot: see load_row)
+        const int kc = valid[j] ? k : 0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const size_t row = (size_t)g * a.H + u;
-            if (!valid[j]) w[g][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            else if (k < K1) w[g][j] = *(const f32x4*)(a.W_ih + row * K1 + k);
-            else w[g][j] = *(const f32x4*)(a.W_hh + row * a.H + (k - K1));
+            const float* wp = kc < K1 ? a.W_ih + row * K1 + kc : a.W_hh + row * a.H + (kc - K1);
+            w[g][j] = *(const f32x4*)wp;
         }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (!valid[j]) w[g][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (!valid[j]) { xp[j] = a.x1; xs[j] = 0; }
         else if (k < a.n1) { xp[j] = a.x1 + k; xs[j] = a.sx1; }
         else if (k < K1) { xp[j] = a.x2 + (k - a.n1); xs[j] = a.sx2; }
         else { xp[j] = a.h_in + (k - K1); xs[j] = a.H; }
+    }
+    // (behind the weight-row loads in issue order: their wait covers these too)
+    if (kq == 0 && lane < 4) s_bsum[ul][lane] = a.b_ih[lane * a.H + u] + a.b_hh[lane * a.H + u];
+    if (a.q_part && (int)threadIdx.x < a.q_dim && a.q_dim <= 128) {
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) s_wq[i][threadIdx.x] = a.w_q[(size_t)threadIdx.x * a.H + blockIdx.x * UNITS + i];
     }
     for (int b0 = 0; b0 < a.B; b0 += 64) {
         const int bn = min(64, a.B - b0);
         for (int bb = 0; bb < bn; ++bb) {
             const int it = b0 + bb;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            f32x4 xv[NVW];
+#pragma unroll
+            for (int j = 0; j < NVW; ++j) xv[j] = *(const f32x4*)(xp[j] + (size_t)it * xs[j]);
 #pragma unroll
             for (int j = 0; j < NVW; ++j) {
-                if (valid[j]) {
-                    const f32x4 x = *(const f32x4*)(xp[j] + (size_t)it * xs[j]);
+                const f32x4 x = valid[j] ? xv[j] : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        acc[g] += w[g][j][0] * x[0] + w[g][j][1] * x[1] + w[g][j][2] * x[2] + w[g][j][3] * x[3];
-                }
+                for (int g = 0; g < 4; ++g)
+                    acc[g] += w[g][j][0] * x[0] + w[g][j][1] * x[1] + w[g][j][2] * x[2] + w[g][j][3] * x[3];
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -188,9 +261,9 @@ __global__ __launch_bounds__(UNITS * 256) void lstm_cell_kernel(const LstmCellAr
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 gsum[g] = (s_part[ul][0][g][lane] + s_part[ul][1][g][lane]) + (s_part[ul][2][g][lane] + s_part[ul][3][g][lane]) +
-                          (a.b_ih[g * a.H + u] + a.b_hh[g * a.H + u]);
+                          s_bsum[ul][g];
             const size_t idx = (size_t)it * a.H + u;
-            const float c = a.c[idx];
+            const float c = b0 == 0 ? c_pre : a.c[idx];
             const float c2 = sigmoid_acc(gsum[1]) * c + sigmoid_acc(gsum[0]) * tanhf(gsum[2]);
             float h2 = sigmoid_acc(gsum[3]) * tanhf(c2);
             a.c[idx] = c2;
@@ -203,9 +276,21 @@ __global__ __launch_bounds__(UNITS * 256) void lstm_cell_kernel(const LstmCellAr
             if (a.drop_mask) h2 = a.drop_mask[idx] ? h2 * a.drop_scale : 0.f;
             a.h_out[idx] = h2;
             if (a.h_copy) a.h_copy[(size_t)it * a.s_copy + u] = h2;
+            s_h[ul][lane] = h2;
         }
         __syncthreads();
+        // partial attention query of this workgroup's units (tacotron.py:137 query_layer, summed over workgroups by
+        // att_fused_kernel): q_part[wg][item][a] = sum_u W_query[a][u] * h[item][u]
+        if (a.q_part && (int)threadIdx.x < a.q_dim && a.q_dim <= 128) {
+            for (int bb = 0; bb < bn; ++bb) {
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < UNITS; ++i) q += s_wq[i][threadIdx.x] * s_h[i][bb];
+                a.q_part[((size_t)blockIdx.x * a.B + b0 + bb) * a.q_dim + threadIdx.x] = q;
+            }
+        }
     }
+    PROBE_END()
 }
 
 hipError_t t2s_launch_lstm_cell(const LstmCellArgs& a, hipStream_t stream) {
@@ -389,6 +474,7 @@ hipError_t t2s_launch_att_softmax_ctx(const AttArgs& a, hipStream_t stream) {
 // autoregressive step; the split kernels above remain for large batches, where they fill the chip.
 #define ATT_FUSED_MAXT 512
 __global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
+    PROBE_BEGIN(300)
     extern __shared__ float s_dyn[];                 // [T][33] location features, then [T] energies
     __shared__ float s_q[128];
     __shared__ float s_qp[8][128];
@@ -402,19 +488,43 @@ __global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
     const int T = a.T, AD = a.att_dim, KS = a.loc_ks, F = a.loc_f, pad = KS >> 1, A = a.att_rnn;
     float* s_f = s_dyn;                               // [T][33]
     float* s_e = s_dyn + (size_t)T * 33;              // [T]
-    // ---- every independent global load is issued first, so one memory latency covers them all ----
-    for (int i = tid; i < F * 2 * KS; i += 1024) s_k[i] = a.w_loc_conv[i];
-    for (int i = tid; i < 2 * (T + KS - 1); i += 1024) {
-        const int c = i / (T + KS - 1), j = i - c * (T + KS - 1);
-        const int t = j - pad;
-        const float* src = c ? a.w_cum : a.w_prev;
-        s_cat[c][j] = (t >= 0 && t < T) ? src[(size_t)b * T + t] : 0.f;
+    // ---- every independent global load is issued first and TOGETHER: fixed trip counts and clamped addresses, so the
+    // compiler emits one batch of loads and one wait instead of a load -> wait -> LDS store round trip per loop iteration
+    // (this kernel is a chain of memory round trips at B = 1; it was 19 of them, ~23 us) ----
+    {
+        const int nK = F * 2 * KS, nC = 2 * (T + KS - 1), TK = T + KS - 1;
+        float rk[4], rd[4], rc[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                          // nK <= 32 * 2 * 63 = 4032, s_d is 4096
+            const int i = tid + j * 1024;
+            rk[j] = a.w_loc_conv[i < nK ? i : 0];
+            const int f = i >> 7, ai = i & 127;
+            rd[j] = a.w_loc_denseT[(f < F && ai < AD) ? f * AD + ai : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                          // nC <= 2 * (512 + 62) = 1148
+            const int i = tid + j * 1024;
+            const int c = i >= TK ? 1 : 0, jj = i - c * TK, t = jj - pad;
+            const bool in = i < nC && t >= 0 && t < T;
+            rc[j] = (c ? a.w_cum : a.w_prev)[(size_t)b * T + (in ? t : 0)];
+            if (!in) rc[j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + j * 1024;
+            if (i < nK) s_k[i] = rk[j];
+            const int f = i >> 7, ai = i & 127;
+            s_d[i] = (f < F && ai < AD) ? rd[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + j * 1024;
+            if (i < nC) s_cat[i >= TK ? 1 : 0][i >= TK ? i - TK : i] = rc[j];
+        }
     }
-    for (int i = tid; i < 32 * 128; i += 1024) {          // dense location weights [f][a] in LDS (registers are
-        const int f = i >> 7, ai = i & 127;                 // capped at 128 per lane by the 1024-thread workgroup)
-        s_d[i] = (f < F && ai < AD) ? a.w_loc_denseT[f * AD + ai] : 0.f;
-    }
-    const float v0 = lane < AD ? a.w_v[lane] : 0.f, v1 = lane + 64 < AD ? a.w_v[lane + 64] : 0.f;
+    const float v0 = a.w_v[lane < AD ? lane : 0] * (lane < AD ? 1.f : 0.f);
+    const float v1 = a.w_v[lane + 64 < AD ? lane + 64 : 0] * (lane + 64 < AD ? 1.f : 0.f);
+    PROBE_MID(0)
     // ---- query: sum of the per-workgroup partials the attention LSTM cell just wrote, or W_q h_att ----
     if (a.q_part) {
         const int ai = tid & 127, part = tid >> 7;            // 8 slices of the partial list per output
@@ -422,6 +532,13 @@ __global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
         if (ai < AD) {
             float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             int w = part;
+            for (; w + 120 < a.n_part; w += 128) {         // 16 independent loads in flight (256 partials: two round trips)
+                float pv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) pv[u] = a.q_part[((size_t)(w + 8 * u) * a.B + b) * AD + ai];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a8[u & 7] += pv[u];
+            }
             for (; w + 56 < a.n_part; w += 64) {           // 8 independent loads in flight
 #pragma unroll
                 for (int u = 0; u < 8; ++u) a8[u] += a.q_part[((size_t)(w + 8 * u) * a.B + b) * AD + ai];
@@ -438,24 +555,28 @@ __global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
             s_q[tid] = q;
         }
     } else {
+        // loads are unconditional from clamped addresses and masked afterwards (no branch + vmcnt(0) per load: see load_row)
         f32x4 x[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int k = (v * 64 + lane) * 4;
-            x[v] = k < A ? *(const f32x4*)(a.h_att + (size_t)b * A + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            x[v] = *(const f32x4*)(a.h_att + (size_t)b * A + (k < A ? k : 0));
         }
-        for (int r0 = wave * 4; r0 < AD; r0 += 64) {
-            f32x4 w[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int v = 0; v < 4; ++v)
+            if ((v * 64 + lane) * 4 >= A) x[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int r0 = wave * 2; r0 < AD; r0 += 32) {       // (fallback path: the decode driver hands over partial queries)
+            f32x4 w[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int k = (v * 64 + lane) * 4;
-                    w[i][v] = (k < A && r0 + i < AD) ? *(const f32x4*)(a.w_query + (size_t)(r0 + i) * A + k)
-                                                     : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const int rr = r0 + i < AD ? r0 + i : AD - 1;
+                    w[i][v] = *(const f32x4*)(a.w_query + (size_t)rr * A + (k < A ? k : 0));      // x is 0 where k >= A
                 }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 2; ++i) {
                 float acc = 0.f;
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
@@ -466,6 +587,7 @@ __global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
         }
     }
     __syncthreads();
+    PROBE_MID(1)
     if (a.q_save && tid < AD) a.q_save[(size_t)b * AD + tid] = s_q[tid];
     // ---- location features f[t][:] = conv1d([w ; w_cum]) ----
     for (int i = tid; i < T * F; i += 1024) {
@@ -477,28 +599,41 @@ __global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
         s_f[t * 33 + f] = acc;
     }
     __syncthreads();
+    PROBE_MID(2)
     // ---- energies: attention_dim on lanes (2 per lane), one wave per time step ----
     {
         const float q0 = lane < AD ? s_q[lane] : 0.f, q1 = lane + 64 < AD ? s_q[lane + 64] : 0.f;
         const int len = a.lengths ? a.lengths[b] : T;
-        for (int t = wave; t < T; t += 16) {
-            const float* pm = a.pmem + ((size_t)b * T + t) * AD;
-            const float pm0 = lane < AD ? pm[lane] : 0.f, pm1 = lane + 64 < AD ? pm[lane + 64] : 0.f;
-            float p0 = q0, p1 = q1;
+        for (int tb = wave; tb < T; tb += 64) {             // four time steps per wave per round: their loads go out together
+            float pm0[4], pm1[4];
 #pragma unroll
-            for (int f = 0; f < 32; ++f) {
-                const float ff = s_f[t * 33 + f];
-                p0 += s_d[f * 128 + lane] * ff;
-                p1 += s_d[f * 128 + 64 + lane] * ff;
+            for (int r = 0; r < 4; ++r) {
+                const int t = tb + 16 * r;
+                const float* pm = a.pmem + ((size_t)b * T + (t < T ? t : 0)) * AD;
+                pm0[r] = pm[lane < AD ? lane : 0];
+                pm1[r] = pm[lane + 64 < AD ? lane + 64 : 0];
             }
-            float e = 0.f;
-            if (lane < AD) e += v0 * tanhf(p0 + pm0);
-            if (lane + 64 < AD) e += v1 * tanhf(p1 + pm1);
-            e = wave_sum(e);
-            if (lane == 0) s_e[t] = t < len ? e : -INFINITY;
+#pragma unroll 1
+            for (int r = 0; r < 4; ++r) {
+                const int t = tb + 16 * r;
+                if (t >= T) break;
+                float p0 = q0, p1 = q1;
+#pragma unroll
+                for (int f = 0; f < 32; ++f) {
+                    const float ff = s_f[t * 33 + f];
+                    p0 += s_d[f * 128 + lane] * ff;
+                    p1 += s_d[f * 128 + 64 + lane] * ff;
+                }
+                float e = 0.f;
+                if (lane < AD) e += v0 * tanhf(p0 + pm0[r]);
+                if (lane + 64 < AD) e += v1 * tanhf(p1 + pm1[r]);
+                e = wave_sum(e);
+                if (lane == 0) s_e[t] = t < len ? e : -INFINITY;
+            }
         }
     }
     __syncthreads();
+    PROBE_MID(3)
     // ---- softmax over T ----
     float m = -INFINITY;
     for (int t = tid; t < T; t += 1024) m = fmaxf(m, s_e[t]);
@@ -525,12 +660,13 @@ __global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
         const float w = s_e[t] * inv;
         s_e[t] = w;
         a.w_prev[(size_t)b * T + t] = w;
-        const float wc = a.w_cum[(size_t)b * T + t] + w;
+        const float wc = s_cat[1][t + pad] + w;                 // the cumulative weights were staged in LDS at entry
         a.w_cum[(size_t)b * T + t] = wc;
         if (a.wcum_save) a.wcum_save[(size_t)b * T + t] = wc;
         if (a.align_out) a.align_out[(size_t)b * a.s_align_b + t] = w;
     }
     __syncthreads();
+    PROBE_MID(4)
     // ---- context = weights . memory : two threads per channel, each half of the time range ----
     {
         const int c = tid & 511, half = tid >> 9;
@@ -540,7 +676,14 @@ __global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
             const float* mem = a.memory + (size_t)b * T * a.enc_dim + c;
             float a4[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             int t = tb;
-            for (; t + 8 <= te; t += 8) {         // 8 independent loads in flight per thread
+            for (; t + 16 <= te; t += 16) {       // 16 independent loads in flight per thread (T = 64: two round trips)
+                float mv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) mv[u] = mem[(size_t)(t + u) * a.enc_dim];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a4[u & 7] += s_e[t + u] * mv[u];
+            }
+            for (; t + 8 <= te; t += 8) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) a4[u] += s_e[t + u] * mem[(size_t)(t + u) * a.enc_dim];
             }
@@ -555,6 +698,7 @@ __global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
         a.ctx[(size_t)b * a.enc_dim + tid] = v;
         if (a.ctx_copy) a.ctx_copy[(size_t)b * a.s_ctx_copy + tid] = v;
     }
+    PROBE_END()
 }
 hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream) {
     if (a.T > ATT_FUSED_MAXT || a.enc_dim > 512 || a.att_dim > 128 || a.loc_f > 32 || a.loc_ks > 63 || a.att_rnn > 1024)

@@ -287,7 +287,7 @@ class _TacoEngine:
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
         S = dict(att_h0=z(B, A), att_h1=z(B, A), att_c=z(B, A), dec_h0=z(B, D), dec_h1=z(B, D), dec_c=z(B, D),
                  att_w=z(B, T_in), att_wcum=z(B, T_in), ctx=z(B, E), q=z(B, ad), energies=z(B, T_in),
-                 pre1=z(B, Pd), pre2=z(B, Pd), q_part=z(A // 4, B, ad), align_out=z(B, T_cap, T_in))
+                 pre1=z(B, Pd), pre2=z(B, Pd), q_part=z(A // 2, B, ad), align_out=z(B, T_cap, T_in))
         pmem = torch.empty(B, T_in, ad, dtype=torch.float32, device=dev)
         self._gemv(P["w_mem"], memory, ad, B * T_in, E, pmem)
         S["pmem"], S["memory"] = pmem, memory
