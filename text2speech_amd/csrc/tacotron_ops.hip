@@ -700,9 +700,290 @@ __global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
     }
     PROBE_END()
 }
+
+// ------------------------------------------------------------------------------------------------
+// Small-batch attention, matrix-core form (the default for F = 32 location filters, attention_dim = 128).
+// Same operator as att_fused_kernel; the two GEMM-shaped pieces run on the exact-f32 matrix cores
+// (v_mfma_f32_16x16x4_f32: f32 operands, f32 accumulate) instead of LDS-bound VALU loops:
+//   location features  F[t][f]  = sum_{c,j} cat[c][t + j] * K[f][c][j]       (tacotron.py:96-107 location_conv)
+//       = [T x 2*KS] (sliding windows of [w ; w_cum], read straight out of LDS as the A operand) x [2*KS x 32]
+//   pre-activation     P[t][a]  = sum_f F[t][f] * D[a][f]                       (location_dense)
+//       = [T x 32] x [32 x 128], epilogue  e[t] = sum_a v[a] * tanh(P + q[a] + pmem[t][a])   (tacotron.py:137-143)
+// At B = 1, T = 64 the VALU form spent 5.1 us in the convolution and 8.0 us in the energies (124 and 96 ds_read_b32 per
+// output and wave: LDS-bound in ONE CU); here both are a few dozen MFMAs per wave.
+// LDS operand layouts are padded so that the b32 fragment reads are bank-conflict free: K as [k][48], D as [f][144].
+__global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a) {
+    PROBE_BEGIN(301)
+    extern __shared__ float s_dyn[];                 // s_f [Tp][33] | s_e [Tp] | s_ep [8][Tp] | s_kb [KP][48]
+    __shared__ float s_q[128];
+    __shared__ float s_v[128];
+    __shared__ float s_qp[8][128];
+    __shared__ float s_d[32 * 144];
+    __shared__ float s_cat[2][ATT_FUSED_MAXT + 16 + 64];
+    __shared__ float red[16];
+    __shared__ float s_ctx[2][512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int T = a.T, KS = a.loc_ks, pad = KS >> 1, A = a.att_rnn;
+    constexpr int AD = 128, F = 32;
+    const int Tp = (T + 15) & ~15, K2 = 2 * KS, KP = (K2 + 3) & ~3, TKp = Tp + KS - 1;
+    float* s_f = s_dyn;
+    float* s_e = s_f + (size_t)Tp * 33;
+    float* s_ep = s_e + Tp;
+    float* s_kb = s_ep + 8 * Tp;
+    const int lr = lane & 15, lq = lane >> 4;
+    // ---- every independent global load first, in one batch (fixed trip counts, clamped addresses) ----
+    float pm[2][4];
+    {
+        const int nK = F * K2;
+        float rk[4], rd[4], rc[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                          // nK <= 32 * 2 * 63 = 4032; D is 32 x 128 = 4096
+            const int i = tid + j * 1024;
+            rk[j] = a.w_loc_conv[i < nK ? i : 0];
+            rd[j] = a.w_loc_denseT[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                          // 2 * TKp <= 2 * (512 + 62) = 1148
+            const int i = tid + j * 1024;
+            const int c = i >= TKp ? 1 : 0, t = i - c * TKp - pad;
+            const bool in = i < 2 * TKp && t >= 0 && t < T;
+            rc[j] = (c ? a.w_cum : a.w_prev)[(size_t)b * T + (in ? t : 0)];
+            if (!in) rc[j] = 0.f;
+        }
+        const float vv = tid < AD ? a.w_v[tid] : 0.f;
+        // processed memory of this wave's first two stage-2 tiles (tile id = wave, wave + 16: t-tile id >> 3, a-tile id & 7)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = wave + 16 * i, tt = id >> 3, at = id & 7;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 16 * tt + 4 * lq + r;
+                pm[i][r] = a.pmem[((size_t)b * T + (t < T ? t : 0)) * AD + 16 * at + lr];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + j * 1024;
+            if (i < nK) {
+                const int f = i / K2, k = i - f * K2;          // K[f][c][j] -> B operand [k = c*KS + j][f]
+                s_kb[k * 48 + f] = rk[j];
+            }
+            s_d[(i >> 7) * 144 + (i & 127)] = rd[j];
+        }
+        if (tid < (KP - K2) * F) s_kb[(K2 + tid / F) * 48 + (tid % F)] = 0.f;      // zero rows that pad K to a multiple of 4
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + j * 1024;
+            if (i < 2 * TKp) s_cat[i >= TKp ? 1 : 0][i >= TKp ? i - TKp : i] = rc[j];
+        }
+        if (tid < AD) s_v[tid] = vv;
+    }
+    PROBE_MID(0)
+    // ---- query: sum of the per-workgroup partials the attention LSTM cell just wrote, or W_q h_att ----
+    if (a.q_part) {
+        const int ai = tid & 127, part = tid >> 7;            // 8 slices of the partial list per output
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int w = part;
+        for (; w + 120 < a.n_part; w += 128) {                // 16 independent loads in flight (256 partials: two round trips)
+            float pv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) pv[u] = a.q_part[((size_t)(w + 8 * u) * a.B + b) * AD + ai];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a8[u & 7] += pv[u];
+        }
+        for (; w < a.n_part; w += 8) a8[0] += a.q_part[((size_t)w * a.B + b) * AD + ai];
+        s_qp[part][ai] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+        __syncthreads();
+        if (tid < AD) {
+            float q = 0.f;
+#pragma unroll
+            for (int p8 = 0; p8 < 8; ++p8) q += s_qp[p8][tid];
+            s_q[tid] = q;
+        }
+    } else {
+        f32x4 x[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int k = (v * 64 + lane) * 4;
+            x[v] = *(const f32x4*)(a.h_att + (size_t)b * A + (k < A ? k : 0));
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if ((v * 64 + lane) * 4 >= A) x[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int r0 = wave * 2; r0 < AD; r0 += 32) {
+            f32x4 w[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int k = (v * 64 + lane) * 4;
+                    w[i][v] = *(const f32x4*)(a.w_query + (size_t)(r0 + i) * A + (k < A ? k : 0));
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float acc = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    acc += w[i][v][0] * x[v][0] + w[i][v][1] * x[v][1] + w[i][v][2] * x[v][2] + w[i][v][3] * x[v][3];
+                acc = wave_sum(acc);
+                if (lane == 0) s_q[r0 + i] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    PROBE_MID(1)
+    if (a.q_save && tid < AD) a.q_save[(size_t)b * AD + tid] = s_q[tid];
+    // ---- stage 1: location features on the matrix cores.  A[t][k] = cat[c][t + j] (k = c*KS + j), B[k][f] = K[f][c][j] ----
+    {
+        const int n_tiles = (Tp >> 4) * 2;
+        for (int id = wave; id < n_tiles; id += 16) {
+            const int tt = id >> 1, ft = id & 1;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < KP; ks += 4) {
+                const int k = ks + lq;
+                const int kc = k < K2 ? k : 0;                  // (B rows >= 2*KS are zero)
+                const int c = kc >= KS ? 1 : 0, j = kc - c * KS;
+                const float av = s_cat[c][16 * tt + lr + j];
+                const float bv = s_kb[k * 48 + 16 * ft + lr];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_f[(16 * tt + 4 * lq + r) * 33 + 16 * ft + lr] = acc[r];
+        }
+    }
+    __syncthreads();
+    PROBE_MID(2)
+    // ---- stage 2: P = F . D^T on the matrix cores, energies in the epilogue ----
+    {
+        const int n_tiles = (Tp >> 4) * 8;
+        int it = 0;
+        for (int id = wave; id < n_tiles; id += 16, ++it) {
+            const int tt = id >> 3, at = id & 7;
+            float pmv[4];
+            if (it < 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pmv[r] = it == 0 ? pm[0][r] : pm[1][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = 16 * tt + 4 * lq + r;
+                    pmv[r] = a.pmem[((size_t)b * T + (t < T ? t : 0)) * AD + 16 * at + lr];
+                }
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < F; ks += 4) {
+                const float av = s_f[(16 * tt + lr) * 33 + ks + lq];
+                const float bv = s_d[(ks + lq) * 144 + 16 * at + lr];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+            const float qa = s_q[16 * at + lr], va = s_v[16 * at + lr];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // tanh(x) = 1 - 2 / (e^(2x) + 1): v_exp_f32 / v_rcp_f32 (1 ulp each), saturates cleanly
+                const float x = acc[r] + qa + pmv[r];
+                float e = va * (1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f));
+                e += __shfl_xor(e, 1, 64);
+                e += __shfl_xor(e, 2, 64);
+                e += __shfl_xor(e, 4, 64);
+                e += __shfl_xor(e, 8, 64);
+                if (lr == 0) s_ep[at * Tp + 16 * tt + 4 * lq + r] = e;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int len = a.lengths ? a.lengths[b] : T;
+        for (int t = tid; t < T; t += 1024) {
+            float e = 0.f;
+#pragma unroll
+            for (int at = 0; at < 8; ++at) e += s_ep[at * Tp + t];      // fixed order: bitwise reproducible
+            s_e[t] = t < len ? e : -INFINITY;
+        }
+    }
+    __syncthreads();
+    PROBE_MID(3)
+    // ---- softmax over T ----
+    float m = -INFINITY;
+    for (int t = tid; t < T; t += 1024) m = fmaxf(m, s_e[t]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = red[0];
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    __syncthreads();
+    float sum = 0.f;
+    for (int t = tid; t < T; t += 1024) {
+        const float p = expf(s_e[t] - m);
+        s_e[t] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    float tot = 0.f;
+    for (int i = 0; i < 16; ++i) tot += red[i];
+    const float inv = 1.0f / tot;
+    for (int t = tid; t < T; t += 1024) {
+        const float w = s_e[t] * inv;
+        s_e[t] = w;
+        a.w_prev[(size_t)b * T + t] = w;
+        const float wc = s_cat[1][t + pad] + w;                 // the cumulative weights were staged in LDS at entry
+        a.w_cum[(size_t)b * T + t] = wc;
+        if (a.wcum_save) a.wcum_save[(size_t)b * T + t] = wc;
+        if (a.align_out) a.align_out[(size_t)b * a.s_align_b + t] = w;
+    }
+    __syncthreads();
+    PROBE_MID(4)
+    // ---- context = weights . memory : two threads per channel, each half of the time range ----
+    {
+        const int c = tid & 511, half = tid >> 9;
+        float acc = 0.f;
+        if (c < a.enc_dim) {
+            const int tb = half ? (T + 1) / 2 : 0, te = half ? T : (T + 1) / 2;
+            const float* mem = a.memory + (size_t)b * T * a.enc_dim + c;
+            float a4[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int t = tb;
+            for (; t + 16 <= te; t += 16) {       // 16 independent loads in flight per thread (T = 64: two round trips)
+                float mv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) mv[u] = mem[(size_t)(t + u) * a.enc_dim];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a4[u & 7] += s_e[t + u] * mv[u];
+            }
+            for (; t + 8 <= te; t += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a4[u] += s_e[t + u] * mem[(size_t)(t + u) * a.enc_dim];
+            }
+            for (; t < te; ++t) a4[0] += s_e[t] * mem[(size_t)t * a.enc_dim];
+            acc = ((a4[0] + a4[1]) + (a4[2] + a4[3])) + ((a4[4] + a4[5]) + (a4[6] + a4[7]));
+        }
+        s_ctx[half][c] = acc;
+    }
+    __syncthreads();
+    if (tid < a.enc_dim && tid < 512) {
+        const float v = s_ctx[0][tid] + s_ctx[1][tid];
+        a.ctx[(size_t)b * a.enc_dim + tid] = v;
+        if (a.ctx_copy) a.ctx_copy[(size_t)b * a.s_ctx_copy + tid] = v;
+    }
+    PROBE_END()
+}
+
 hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream) {
     if (a.T > ATT_FUSED_MAXT || a.enc_dim > 512 || a.att_dim > 128 || a.loc_f > 32 || a.loc_ks > 63 || a.att_rnn > 1024)
         return hipErrorInvalidValue;
+    static const bool no_mfma = getenv("T2S_ATT_VALU") != nullptr;       // A/B switch: the VALU form
+    if (a.loc_f == 32 && a.att_dim == 128 && !no_mfma) {
+        const int Tp = (a.T + 15) & ~15, KP = (2 * a.loc_ks + 3) & ~3;
+        const size_t lds = ((size_t)Tp * 33 + Tp + 8 * Tp + (size_t)KP * 48) * sizeof(float);
+        static std::atomic<unsigned long long> attr_mask2{0};
+        const hipError_t e2 = t2s_raise_lds_limit((const void*)att_fused_mfma_kernel, 120 * 1024, attr_mask2);
+        if (e2 != hipSuccess) return e2;
+        hipLaunchKernelGGL(att_fused_mfma_kernel, dim3(a.B), dim3(1024), lds, stream, a);
+        return hipGetLastError();
+    }
     const size_t lds = ((size_t)a.T * 33 + a.T) * sizeof(float);
     static std::atomic<unsigned long long> attr_mask{0};
     const hipError_t e = t2s_raise_lds_limit((const void*)att_fused_kernel, 96 * 1024, attr_mask);
