@@ -701,6 +701,15 @@ __global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
     PROBE_END()
 }
 
+// value of lane (l + n) mod 16 within the same 16-lane row (DPP row_ror:n), n in {1, 2, 4, 8}
+template <int N>
+static __device__ __forceinline__ float row16_ror_c(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+static __device__ __forceinline__ float row16_ror(float v, int n) {
+    return n == 8 ? row16_ror_c<8>(v) : n == 4 ? row16_ror_c<4>(v) : n == 2 ? row16_ror_c<2>(v) : row16_ror_c<1>(v);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Small-batch attention, matrix-core form (the default for F = 32 location filters, attention_dim = 128).
 // Same operator as att_fused_kernel; the two GEMM-shaped pieces run on the exact-f32 matrix cores
@@ -714,21 +723,20 @@ __global__ __launch_bounds__(1024) void att_fused_kernel(const AttArgs a) {
 // LDS operand layouts are padded so that the b32 fragment reads are bank-conflict free: K as [k][48], D as [f][144].
 __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a) {
     PROBE_BEGIN(301)
-    extern __shared__ float s_dyn[];                 // s_f [Tp][33] | s_e [Tp] | s_ep [8][Tp] | s_kb [KP][48]
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // s_f [max(Tp*33, 4096)] | s_e [Tp] | s_ep [8][Tp] | s_kb [KP][48]
     __shared__ float s_q[128];
     __shared__ float s_v[128];
-    __shared__ float s_qp[8][128];
     __shared__ float s_d[32 * 144];
     __shared__ float s_cat[2][ATT_FUSED_MAXT + 16 + 64];
     __shared__ float red[16];
-    __shared__ float s_ctx[2][512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int T = a.T, KS = a.loc_ks, pad = KS >> 1, A = a.att_rnn;
     constexpr int AD = 128, F = 32;
     const int Tp = (T + 15) & ~15, K2 = 2 * KS, KP = (K2 + 3) & ~3, TKp = Tp + KS - 1;
+    const int nF = Tp * 33 > 4096 ? Tp * 33 : 4096;   // s_f doubles as [32][128] / [8][512] reduction scratch
     float* s_f = s_dyn;
-    float* s_e = s_f + (size_t)Tp * 33;
+    float* s_e = s_f + nF;
     float* s_ep = s_e + Tp;
     float* s_kb = s_ep + 8 * Tp;
     const int lr = lane & 15, lq = lane >> 4;
@@ -781,24 +789,28 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a) {
     }
     PROBE_MID(0)
     // ---- query: sum of the per-workgroup partials the attention LSTM cell just wrote, or W_q h_att ----
-    if (a.q_part) {
-        const int ai = tid & 127, part = tid >> 7;            // 8 slices of the partial list per output
-        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int w = part;
-        for (; w + 120 < a.n_part; w += 128) {                // 16 independent loads in flight (256 partials: two round trips)
-            float pv[16];
+    if (a.q_part && (a.n_part & 31) == 0 && a.n_part <= 512) {
+        // thread = (slice of the partial list, four consecutive outputs): n_part / 32 float4 loads each, all in flight at once
+        // (one memory round trip for the 128 KB of partials), then a 32-way sum through LDS in a fixed order
+        const int aq = tid & 31, part = tid >> 5;
+        const int per = a.n_part >> 5;                        // 8 for 256 partials, 16 for 512 (training: 2 units per workgroup)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* qp = a.q_part + ((size_t)part * per * a.B + b) * AD + 4 * aq;
+        const size_t qs = (size_t)a.B * AD;
+        for (int u0 = 0; u0 < per; u0 += 8) {                  // exactly `per` loads per thread, eight in flight at a time
+            f32x4 pv[8];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) pv[u] = a.q_part[((size_t)(w + 8 * u) * a.B + b) * AD + ai];
+            for (int u = 0; u < 8; ++u) pv[u] = *(const f32x4*)(qp + (size_t)(u0 + u) * qs);
 #pragma unroll
-            for (int u = 0; u < 16; ++u) a8[u & 7] += pv[u];
+            for (int u = 0; u < 8; ++u) acc += pv[u];
         }
-        for (; w < a.n_part; w += 8) a8[0] += a.q_part[((size_t)w * a.B + b) * AD + ai];
-        s_qp[part][ai] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+        float* s_q32 = s_f;                                   // [32][128] scratch (s_f is not live yet; Tp * 33 >= 16 * 33... see below)
+        *(f32x4*)(s_q32 + part * 128 + 4 * aq) = acc;
         __syncthreads();
         if (tid < AD) {
             float q = 0.f;
 #pragma unroll
-            for (int p8 = 0; p8 < 8; ++p8) q += s_qp[p8][tid];
+            for (int p8 = 0; p8 < 32; ++p8) q += s_q32[p8 * 128 + tid];
             s_q[tid] = q;
         }
     } else {
@@ -840,13 +852,19 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a) {
         for (int id = wave; id < n_tiles; id += 16) {
             const int tt = id >> 1, ft = id & 1;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int ks = 0; ks < KP; ks += 4) {
-                const int k = ks + lq;
-                const int kc = k < K2 ? k : 0;                  // (B rows >= 2*KS are zero)
-                const int c = kc >= KS ? 1 : 0, j = kc - c * KS;
-                const float av = s_cat[c][16 * tt + lr + j];
-                const float bv = s_kb[k * 48 + 16 * ft + lr];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            for (int ks0 = 0; ks0 < KP; ks0 += 64) {           // fragments of up to 16 k-steps are read first, then the MFMA chain runs
+                float av[16], bv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int k = ks0 + 4 * u + lq;
+                    const int kc = k < K2 ? k : 0;              // (B rows >= 2*KS are zero)
+                    const int c = kc >= KS ? 1 : 0, j = kc - c * KS;
+                    av[u] = s_cat[c][16 * tt + lr + j];
+                    bv[u] = s_kb[(k < KP ? k : 0) * 48 + 16 * ft + lr];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (ks0 + 4 * u < KP) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) s_f[(16 * tt + 4 * lq + r) * 33 + 16 * ft + lr] = acc[r];
@@ -872,24 +890,32 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a) {
                 }
             }
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            float av[8], bv[8];
 #pragma unroll
-            for (int ks = 0; ks < F; ks += 4) {
-                const float av = s_f[(16 * tt + lr) * 33 + ks + lq];
-                const float bv = s_d[(ks + lq) * 144 + 16 * at + lr];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            for (int u = 0; u < 8; ++u) {
+                av[u] = s_f[(16 * tt + lr) * 33 + 4 * u + lq];
+                bv[u] = s_d[(4 * u + lq) * 144 + 16 * at + lr];
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
             const float qa = s_q[16 * at + lr], va = s_v[16 * at + lr];
+            float ev[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // tanh(x) = 1 - 2 / (e^(2x) + 1): v_exp_f32 / v_rcp_f32 (1 ulp each), saturates cleanly
                 const float x = acc[r] + qa + pmv[r];
-                float e = va * (1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f));
-                e += __shfl_xor(e, 1, 64);
-                e += __shfl_xor(e, 2, 64);
-                e += __shfl_xor(e, 4, 64);
-                e += __shfl_xor(e, 8, 64);
-                if (lr == 0) s_ep[at * Tp + 16 * tt + 4 * lq + r] = e;
+                ev[r] = va * (1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f));
             }
+            // sum over the 16 lanes that hold the 16 attention channels of this tile: DPP row rotations (one VALU
+            // instruction each, no LDS round trip as ds_bpermute-based shuffles would need), four independent chains
+#pragma unroll
+            for (int sh = 8; sh >= 1; sh >>= 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ev[r] += row16_ror(ev[r], sh);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (lr == 0) s_ep[at * Tp + 16 * tt + 4 * lq + r] = ev[r];
         }
     }
     __syncthreads();
@@ -937,34 +963,34 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a) {
     }
     __syncthreads();
     PROBE_MID(4)
-    // ---- context = weights . memory : two threads per channel, each half of the time range ----
+    // ---- context = weights . memory.  thread = (four consecutive channels, one of eight time slices): float4 loads, up to 16
+    // of them in flight per thread (T <= 128: ONE memory round trip for the whole [T x enc_dim] block), then an 8-way sum
+    // through LDS in a fixed order ----
     {
-        const int c = tid & 511, half = tid >> 9;
-        float acc = 0.f;
-        if (c < a.enc_dim) {
-            const int tb = half ? (T + 1) / 2 : 0, te = half ? T : (T + 1) / 2;
-            const float* mem = a.memory + (size_t)b * T * a.enc_dim + c;
-            float a4[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int cq = tid & 127, sl = tid >> 7;               // enc_dim <= 512 = 128 float4
+        const int per = (T + 7) >> 3;                          // time steps per slice
+        const int tb = sl * per, te = min(T, tb + per);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (4 * cq < a.enc_dim) {
+            const float* mem = a.memory + (size_t)b * T * a.enc_dim + 4 * cq;
             int t = tb;
-            for (; t + 16 <= te; t += 16) {       // 16 independent loads in flight per thread (T = 64: two round trips)
-                float mv[16];
+            for (; t + 8 <= te; t += 8) {                       // eight float4 loads in flight per thread, no duplicates
+                f32x4 mv[8];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) mv[u] = mem[(size_t)(t + u) * a.enc_dim];
+                for (int u = 0; u < 8; ++u) mv[u] = *(const f32x4*)(mem + (size_t)(t + u) * a.enc_dim);
 #pragma unroll
-                for (int u = 0; u < 16; ++u) a4[u & 7] += s_e[t + u] * mv[u];
+                for (int u = 0; u < 8; ++u) acc += mv[u] * s_e[t + u];
             }
-            for (; t + 8 <= te; t += 8) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) a4[u] += s_e[t + u] * mem[(size_t)(t + u) * a.enc_dim];
-            }
-            for (; t < te; ++t) a4[0] += s_e[t] * mem[(size_t)t * a.enc_dim];
-            acc = ((a4[0] + a4[1]) + (a4[2] + a4[3])) + ((a4[4] + a4[5]) + (a4[6] + a4[7]));
+            for (; t < te; ++t) acc += *(const f32x4*)(mem + (size_t)t * a.enc_dim) * s_e[t];
         }
-        s_ctx[half][c] = acc;
+        float* s_c8 = s_f;                                      // [8][512] scratch (the location features are dead by now)
+        *(f32x4*)(s_c8 + sl * 512 + 4 * cq) = acc;
     }
     __syncthreads();
     if (tid < a.enc_dim && tid < 512) {
-        const float v = s_ctx[0][tid] + s_ctx[1][tid];
+        float v = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) v += s_f[sl * 512 + tid];
         a.ctx[(size_t)b * a.enc_dim + tid] = v;
         if (a.ctx_copy) a.ctx_copy[(size_t)b * a.s_ctx_copy + tid] = v;
     }
@@ -977,7 +1003,8 @@ hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream) {
     static const bool no_mfma = getenv("T2S_ATT_VALU") != nullptr;       // A/B switch: the VALU form
     if (a.loc_f == 32 && a.att_dim == 128 && !no_mfma) {
         const int Tp = (a.T + 15) & ~15, KP = (2 * a.loc_ks + 3) & ~3;
-        const size_t lds = ((size_t)Tp * 33 + Tp + 8 * Tp + (size_t)KP * 48) * sizeof(float);
+        const size_t nF = (size_t)Tp * 33 > 4096 ? (size_t)Tp * 33 : 4096;
+        const size_t lds = (nF + Tp + 8 * Tp + (size_t)KP * 48) * sizeof(float);
         static std::atomic<unsigned long long> attr_mask2{0};
         const hipError_t e2 = t2s_raise_lds_limit((const void*)att_fused_mfma_kernel, 120 * 1024, attr_mask2);
         if (e2 != hipSuccess) return e2;
