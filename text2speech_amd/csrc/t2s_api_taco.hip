@@ -3,6 +3,7 @@
 #include "t2s_kernels.h"
 #include "tacotron_ops.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 extern "C" int t2s_internal_fail_hip(int e);   // defined in t2s_api.hip (records the HIP error text)
@@ -137,12 +138,15 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         ca.n1 = P; ca.sx1 = P; ca.x2 = d->ctx; ca.n2 = E; ca.sx2 = E;
         ca.h_in = ah_in; ca.h_out = ah_out; ca.c = d->att_c; ca.B = B; ca.H = A;
         if (d->att_drop) { ca.drop_mask = d->att_drop + (size_t)s * B * A; ca.drop_scale = d->att_drop_scale; }
-        const bool fused_att = B <= 8 && T <= 512 && d->w_loc_denseT && d->att_dim <= 128;
+        // one fused attention launch per step (one workgroup per batch element) up to this batch; beyond it the three-kernel
+        // form (query GEMV, energies, softmax + context) fills the chip better (measured at B = 32, T_in = 256: no difference)
+        static const int fused_max_b = getenv("T2S_ATT_FUSED_MAXB") ? atoi(getenv("T2S_ATT_FUSED_MAXB")) : 8;
+        const bool fused_att = B <= fused_max_b && T <= 512 && d->w_loc_denseT && d->att_dim <= 128;
         if (d->att_gates_all) { ca.gates_out = d->att_gates_all + (size_t)s * B * 4 * A; ca.c_out = d->att_c_all + (size_t)s * B * A; }
         if (d->att_h_all) { ca.h_copy = d->att_h_all + (size_t)s * B * A; ca.s_copy = A; }
         // small batch: the attention cell's workgroups emit partial queries (their own hidden units' columns of W_query), so
         // the fused attention kernel sums 128 KB of partials instead of pulling the 512 KB of W_query through one CU
-        const bool q_parts = fused_att && d->q_part != nullptr;
+        const bool q_parts = fused_att && B <= 8 && d->q_part != nullptr;      // (9+ items: the cells run on sbgemm.hip, no partials)
         const int units = ca.gates_out ? 2 : 4;             // hidden units per workgroup of lstm_cell_kernel (training / eval)
         if (q_parts) { ca.w_q = d->w_query; ca.q_part = d->q_part; ca.q_dim = d->att_dim; }
         T2S_CHECK_HIP(t2s_launch_lstm_cell(ca, stream));
