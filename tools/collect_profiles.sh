@@ -1,22 +1,26 @@
 #!/bin/bash
-# Reproduce the evidence under profiles/ on a 1-GPU MI355X box (run from the repo root; ~4 GPU-minutes).
-# rocprofv3 7.2 writes a rocpd SQLite database; tools/rocpd_stats.py and tools/pmc_traffic.py turn it into the tables /
-# JSON that profiles/r01_summary.md quotes.  Counters are collected in their own passes (no trace domains next to --pmc).
-set -euo pipefail
+# Reproduce the evidence under profiles/ on a 1-GPU MI355X box (run from the repo root; ~6 GPU-minutes).
+# rocprofv3 7.2 writes a rocpd SQLite database; tools/rocpd_stats.py, tools/pmc_traffic.py and tools/pmc_counters.py turn
+# it into the tables / JSON that profiles/r02_summary.md quotes.  Counters are collected in their own passes (no trace
+# domains next to --pmc).  The program after `--` is always python3 itself (never env / bash -c: MI355X pool rule).
+set -uo pipefail
 R=$(pwd)
 OUT=$(realpath -m "${1:-$R/gpurun_out/collect}")
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-tacotron"
-rocprofv3 --kernel-trace --stats -d "$OUT/fwd" -o fw -- $B --steps 5 --warmup 1 > "$OUT/fwd_under_rocprof.json"
-rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o f -- $B --steps 2 --warmup 1 > /dev/null
-rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o w -- $B --steps 2 --warmup 1 > /dev/null
-rocprofv3 --kernel-trace --stats -d "$OUT/train" -o wt -- python3 $R/bench.py --mode train --steps 3 --warmup 1 > "$OUT/train_under_rocprof.json"
-rocprofv3 --kernel-trace --stats -d "$OUT/taco_train" -o tt -- python3 $R/tools/bench_tacotron_train.py > "$OUT/taco_train_under_rocprof.json"
+B="python3 $R/bench.py --no-cpu-baseline --no-tacotron --no-train"
+rocprofv3 --kernel-trace --stats -d "$OUT/fwd" -o fw -- $B --steps 5 --warmup 1 > "$OUT/fwd_under_rocprof.json" 2> "$OUT/fwd.err"
+rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o f -- $B --steps 2 --warmup 1 > /dev/null 2> "$OUT/pmc_f.err"
+rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o w -- $B --steps 2 --warmup 1 > /dev/null 2> "$OUT/pmc_w.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/train" -o wt -- python3 $R/bench.py --mode train --steps 3 --warmup 1 --no-train > "$OUT/train_under_rocprof.json" 2> "$OUT/train.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/taco_inf" -o ti -- python3 $R/tools/bench_tacotron.py > "$OUT/taco_inf_under_rocprof.json" 2> "$OUT/taco_inf.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/taco_train" -o tt -- python3 $R/tools/bench_tacotron_train.py > "$OUT/taco_train_under_rocprof.json" 2> "$OUT/taco_train.err"
 cd "$R"
-python3 bench.py > "$OUT/bench.json"
 python3 tools/rocpd_stats.py "$OUT/fwd/fw_results.db" 6 16 > "$OUT/fwd_kernels.md"
 python3 tools/rocpd_stats.py "$OUT/train/wt_results.db" 4 16 > "$OUT/train_kernels.md"
+python3 tools/rocpd_stats.py "$OUT/taco_inf/ti_results.db" 1 14 > "$OUT/taco_inf_kernels.md"
 python3 tools/rocpd_stats.py "$OUT/taco_train/tt_results.db" 4 16 > "$OUT/taco_train_kernels.md"
 python3 tools/pmc_traffic.py "$OUT/pmc_fetch/f_results.db" "$OUT/pmc_write/w_results.db" > "$OUT/pmc_traffic.json"
+rm -rf "$OUT"/fwd "$OUT"/train "$OUT"/taco_inf "$OUT"/taco_train "$OUT"/pmc_fetch "$OUT"/pmc_write     # databases are large
+python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "wrote $OUT"
