@@ -298,6 +298,21 @@ int t2s_wgrad_gemm_flat(const void* A_hi, const void* A_lo, const void* X_hi, co
                         float* out, int B, int M, int N, int Mpad, int Npad, int n_tchunks, int k0, int k1, int nsplit,
                         void* stream);
 
+/* The same contraction straight from CHANNEL-LAST planes (no time-major copies): the transpose happens in the LDS read
+ * (ds_read_b64_tr_b16).  Operands are lists of 32-channel chunks, 8 per 256-row tile (pad with a chunk of zeros):
+ *   hi / lo  = device pointers to plane row 0 of that chunk for batch entry 0 (a dilated tap is a row offset folded into the
+ *              pointer: the autograd of in_layers[i], glow.py:134-139, needs x shifted by (tap - 1) * dilation);
+ *   bstride  = u16 elements between batch entries (0 for constants such as the all-ones bias chunk).
+ * out = [nsplit][M][N] f32 slabs over K-blocks [k0, k1) of 32 plane rows of each of the B batch entries, as t2s_wgrad_gemm_flat.
+ * Both tables live in device memory ([n_tiles * 8] entries).  Replaces 7 t2s_plane_transpose launches per WN layer. */
+typedef struct t2s_wgrad_chunk {
+    const void* hi;
+    const void* lo;
+    long bstride;
+} t2s_wgrad_chunk;
+int t2s_wgrad_cl(const t2s_wgrad_chunk* a_chunks, int n_a_chunks, const t2s_wgrad_chunk* b_chunks, int n_b_chunks, float* out,
+                 int B, int M, int N, int k0, int k1, int nsplit, void* stream);
+
 int t2s_plane_transpose(const void* src_hi, const void* src_lo, int B, int src_chunks, int n_chunks, int Lp, int shift,
                         void* dst_hi, void* dst_lo, int Npad, int n_off, void* stream);
 int t2s_tm_ones_row(void* dst_hi, void* dst_lo, int B, int Lp, int halo, int L, int Npad, int n_row, void* stream);

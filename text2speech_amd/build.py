@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libt2s_hip.so")
-SOURCES = ["conv_gemm.hip", "gate_gemm_pp.hip", "waveglow_ops.hip", "tacotron_ops.hip", "sbgemm.hip", "train_ops.hip", "taco_bwd_ops.hip", "t2s_api_taco_bwd.hip", "t2s_api.hip", "t2s_api_taco.hip",
+SOURCES = ["conv_gemm.hip", "gate_gemm_pp.hip", "wgrad_cl.hip", "waveglow_ops.hip", "tacotron_ops.hip", "sbgemm.hip", "train_ops.hip", "taco_bwd_ops.hip", "t2s_api_taco_bwd.hip", "t2s_api.hip", "t2s_api_taco.hip",
            "t2s_api_train.hip", "audio_ops.hip", "t2s_api_audio.hip", "loss_ops.hip"]
 
 

@@ -179,6 +179,21 @@ int t2s_wgrad_gemm_flat(const void* A_hi, const void* A_lo, const void* X_hi, co
     return T2S_OK;
 }
 
+int t2s_wgrad_cl(const t2s_wgrad_chunk* a_chunks, int n_a_chunks, const t2s_wgrad_chunk* b_chunks, int n_b_chunks, float* out,
+                 int B, int M, int N, int k0, int k1, int nsplit, void* stream) {
+    static_assert(sizeof(t2s_wgrad_chunk) == sizeof(WgradChunk), "t2s_wgrad_chunk layout");
+    if (!a_chunks || !b_chunks || !out || B <= 0 || M <= 0 || N <= 0 || k0 < 0 || k0 >= k1 || nsplit < 1) return T2S_EINVAL;
+    const int n_mtiles = cdiv(M, 256), n_ntiles = cdiv(N, 256);
+    if (n_a_chunks != n_mtiles * 8 || n_b_chunks != n_ntiles * 8 || nsplit > B * (k1 - k0)) return T2S_EINVAL;
+    WgradClArgs a;
+    a.a_chunks = (const WgradChunk*)a_chunks; a.b_chunks = (const WgradChunk*)b_chunks; a.P = out;
+    a.M = M; a.N = N; a.n_mtiles = n_mtiles; a.n_ntiles = n_ntiles; a.B = B; a.k0 = k0; a.k1 = k1;
+    a.nslab = nsplit; a.kchunk = cdiv(B * (k1 - k0), nsplit);
+    if ((long)a.kchunk * (nsplit - 1) >= (long)B * (k1 - k0)) return T2S_EINVAL;      // every slab must own >= 1 K-block
+    T2S_CHECK_HIP(t2s_launch_wgrad_cl(a, (hipStream_t)stream));
+    return T2S_OK;
+}
+
 int t2s_plane_transpose(const void* src_hi, const void* src_lo, int B, int src_chunks, int n_chunks, int Lp, int shift,
                         void* dst_hi, void* dst_lo, int Npad, int n_off, void* stream) {
     if (!planes_ok(src_hi, src_lo) || !planes_ok(dst_hi, dst_lo) || B <= 0 || n_chunks <= 0 || n_chunks > src_chunks ||

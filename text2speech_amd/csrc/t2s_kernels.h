@@ -57,6 +57,22 @@ hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a, int epi, hipStream_t stre
 // EPI_GATE, 256 x 256 tile, plain K order (nk = taps * xc + sc): the ping-pong schedule of csrc/gate_gemm_pp.hip
 hipError_t t2s_launch_gate_gemm_pp(const ConvGemmArgs& a, hipStream_t stream);
 
+// csrc/wgrad_cl.hip: weight-gradient GEMM straight from channel-last planes (transposed LDS reads)
+struct WgradChunk {            // one 32-channel chunk of an operand; mirrors t2s_wgrad_chunk in include/t2s_hip.h
+    const u16* hi;             // row 0 of this chunk for batch entry 0 (chunk index and any tap shift folded in)
+    const u16* lo;
+    long bstride;              // u16 elements between batch entries (0: the same rows for every batch entry)
+};
+struct WgradClArgs {
+    const WgradChunk* a_chunks;    // [n_mtiles * 8]  M side (output rows)
+    const WgradChunk* b_chunks;    // [n_ntiles * 8]  N side (output columns)
+    float* P;                      // [nslab][M][N]
+    int M, N, n_mtiles, n_ntiles;
+    int B, k0, k1;                 // K-blocks of 32 plane rows [k0, k1) of every batch entry
+    int nslab, kchunk;             // slab s covers flattened (batch, block) steps [s * kchunk, (s + 1) * kchunk)
+};
+hipError_t t2s_launch_wgrad_cl(const WgradClArgs& a, hipStream_t stream);
+
 struct PackArgs {
     const float* v;        // [O][Cin][Kt]
     const float* g;        // [O] weight-norm gain, or null for a plain weight

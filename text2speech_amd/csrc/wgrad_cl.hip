@@ -1,0 +1,182 @@
+// Weight-gradient GEMM straight from channel-last planes (gfx950 / MI355X).
+//
+//   P[slab][m][n] = sum over (batch b, time t) in the slab of  A[b][m][t] * B[b][n][t]
+//
+// i.e. the contraction index of the MFMA is TIME, while every activation / gradient tensor of the WaveGlow path is stored
+// channel-last (plane[b][c/32][row][c%32], row = halo + t, split-bf16 hi / lo).  Round 1 fed this GEMM from "time-major"
+// copies made by plane_transpose_kernel: 7 transposes per WN layer (661 launches, 11-19 ms of a 96 ms training step), three of
+// them only to materialise the dilated taps as shifted copies.  Here the operands are DMA'd as they are - for a 32-step
+// K-block, the 32 rows x 64 B of one 32-channel chunk are ONE contiguous 2 KB piece, and a dilated tap is a row offset on the
+// source address - and the transpose happens in the LDS read: gfx950's ds_read_b64_tr_b16 hands each 16-lane group a 4-row x
+// 16-column block of 16-bit elements column-major, which is exactly the k-contiguous fragment v_mfma_f32_16x16x32_bf16 wants
+// (cdna_hip_programming.md T10).  Two such reads (rows 8g..8g+3 and 8g+4..8g+7 for lane group g) make one bf16x8 operand.
+//
+// Operands are described per 32-channel CHUNK (WgradChunk: hi / lo pointers to row 0 of that chunk for batch 0, with any tap
+// shift folded in, and the element stride between batch entries), so one GEMM can take its M rows from two plane sets
+// ([d_x ; d_skip]) and its N rows from five ([x tap -1 | x tap 0 | x tap +1 | spect | ones]) without any gather pass.
+// Tables are padded to 8 chunks per 256-row tile with a zero chunk; the bias column is a chunk whose channel 0 is 1.
+//
+// Tile: 256 (M) x 256 (N) per 512-thread workgroup, 8 waves as 2 (M) x 4 (N), 128 x 64 per wave, split-bf16 products
+// a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, f32 accumulate; K-step = 32 time steps; two LDS stages of [A_hi | A_lo | B_hi | B_lo] x 16 KB
+// filled by global_load_lds_dwordx4.  LDS image of a plane tile: [chunk (8)][t (32)][64 B]; the two 32-byte halves of a row
+// are swapped on rows with bit 3 set (on the DMA source address and on the read address), which makes the transposed reads of
+// a 32-lane half (two 4-row blocks 8 rows apart) hit disjoint banks.
+// Split-K over (batch, time block) flattened; every slab writes its own f32 partial (reduced by wn_backward_kernel).
+#include "t2s_common.h"
+#include "t2s_kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+constexpr int WG_PLANE = 16384;          // one plane tile: 8 chunks x 32 rows x 64 B
+constexpr int WG_STAGE = 4 * WG_PLANE;   // A_hi, A_lo, B_hi, B_lo
+
+__device__ __forceinline__ void wg_glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// one k-contiguous MFMA operand (16 rows x 32 time steps) out of a channel-last LDS image: two transposed 8-byte reads
+__device__ __forceinline__ bf16x8 tr_frag(const char* lds_addr) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_addr));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_addr + 4 * 64));      // rows + 4
+    const s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(512) void wgrad_cl_kernel(const WgradClArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // XCD-aware bijective remap, M tiles fastest (they share the B tiles of one slab in that XCD's L2)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int mt = logical % a.n_mtiles;
+    const int rest = logical / a.n_mtiles;
+    const int nt = rest % a.n_ntiles;
+    const int slab = rest / a.n_ntiles;
+    const int kper = a.k1 - a.k0;
+    const int kf0 = slab * a.kchunk;
+    int nk = min(a.kchunk, a.B * kper - kf0);
+    if (nk < 0) nk = 0;
+
+    // ---- DMA sources: call j (0, 1) of a plane tile covers chunks 4j .. 4j+3; this thread's piece: chunk 4j + (tid >> 7),
+    // row (tid >> 2) & 31, LDS 16-byte slot tid & 3, which holds the logical slot with the 32-byte half swapped on rows 8..15,
+    // 24..31 (the same involution is applied to the read address) ----
+    const int row = (tid >> 2) & 31, slot = tid & 3;
+    const int lslot = (((slot >> 1) ^ ((row >> 3) & 1)) << 1) | (slot & 1);
+    const long thr_el = (long)row * 32 + lslot * 8;                      // u16 elements inside a chunk's K-block
+    const u16 *ah[2], *al[2], *bh[2], *bl[2];
+    long abs_[2], bbs_[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const WgradChunk ca = a.a_chunks[mt * 8 + 4 * j + (tid >> 7)];
+        const WgradChunk cb = a.b_chunks[nt * 8 + 4 * j + (tid >> 7)];
+        ah[j] = ca.hi + thr_el; al[j] = ca.lo + thr_el; abs_[j] = ca.bstride;
+        bh[j] = cb.hi + thr_el; bl[j] = cb.lo + thr_el; bbs_[j] = cb.bstride;
+    }
+    char* const lds_wave = smem + wave * 1024;                            // + lane * 16 is implicit in the DMA
+    int nbb = kf0 / kper, nkk = a.k0 + kf0 - nbb * kper;                  // (batch entry, K-block) of the next step to issue
+    auto issue = [&](int ks, int buf) {
+        (void)ks;
+        const int bb = nbb, kk = nkk;
+        if (++nkk == a.k1) { nkk = a.k0; ++nbb; }
+        const long roff = (long)kk * 32 * 32;                            // 32 rows x 32 channels per K-block
+        char* dst = lds_wave + buf * WG_STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wg_glds16(ah[j] + bb * abs_[j] + roff, dst + j * 8192);
+            wg_glds16(al[j] + bb * abs_[j] + roff, dst + WG_PLANE + j * 8192);
+            wg_glds16(bh[j] + bb * bbs_[j] + roff, dst + 2 * WG_PLANE + j * 8192);
+            wg_glds16(bl[j] + bb * bbs_[j] + roff, dst + 3 * WG_PLANE + j * 8192);
+        }
+    };
+
+    // ---- transposed fragment addresses.  Lane group g = lane >> 4 owns k = 8g .. 8g+7; inside the group lane 4q + p supplies
+    // the address of block row q, columns 4p .. 4p+3 (8 bytes).  16-channel half `c16` of the chunk sits in the 32-byte half
+    // c16 ^ (g & 1) of the row (rows 8g .. 8g+7 all have (row >> 3) & 1 == g & 1). ----
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int tr_base = (8 * g + qq) * 64 + pp * 8;
+    const int half0 = (0 ^ (g & 1)) * 32, half1 = (1 ^ (g & 1)) * 32;
+    // A m-tile mi (0..7) of this wave: chunk wr*4 + (mi >> 1), channel half mi & 1;  B n-tile ni (0..3): chunk wc*2 + (ni >> 1)
+    const int a_frag = wr * 4 * 2048 + tr_base;
+    const int b_frag = 2 * WG_PLANE + wc * 2 * 2048 + tr_base;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const char* sb = smem + (ks & 1) * WG_STAGE;
+        if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
+        bf16x8 fbh[4], fbl[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int off = b_frag + (n >> 1) * 2048 + ((n & 1) ? half1 : half0);
+            fbh[n] = tr_frag(sb + off);
+            fbl[n] = tr_frag(sb + off + WG_PLANE);
+        }
+        // the A fragments of m-tile m + 1 are fetched while m's 12 MFMAs issue
+        bf16x8 fah = tr_frag(sb + a_frag + half0);
+        bf16x8 fal = tr_frag(sb + a_frag + half0 + WG_PLANE);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            bf16x8 fah_n = fah, fal_n = fal;
+            if (m + 1 < 8) {
+                const int off = a_frag + ((m + 1) >> 1) * 2048 + (((m + 1) & 1) ? half1 : half0);
+                fah_n = tr_frag(sb + off);
+                fal_n = tr_frag(sb + off + WG_PLANE);
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal, fbh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah, fbl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah, fbh[n], acc[m][n], 0, 0, 0);
+            fah = fah_n;
+            fal = fal_n;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D map of mfma 16x16: col = lane & 15 (n), row = 4 * (lane >> 4) + reg (m) ----
+    float* P = a.P + (size_t)slab * a.M * a.N;
+    const int ncol = lane & 15, mrow = (lane >> 4) * 4;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int mm = mt * 256 + wr * 128 + m * 16 + mrow;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int nn = nt * 256 + wc * 64 + n * 16 + ncol;
+            if (nn >= a.N) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (mm + e < a.M) P[(size_t)(mm + e) * a.N + nn] = acc[m][n][e];
+        }
+    }
+}
+
+hipError_t t2s_launch_wgrad_cl(const WgradClArgs& a, hipStream_t stream) {
+    const int nwg = a.n_mtiles * a.n_ntiles * a.nslab;
+    constexpr int lds = 2 * WG_STAGE;
+    static std::atomic<unsigned long long> attr_mask{0};
+    const hipError_t e = t2s_raise_lds_limit((const void*)wgrad_cl_kernel, lds, attr_mask);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(wgrad_cl_kernel, dim3(nwg), dim3(512), lds, stream, a);
+    return hipGetLastError();
+}

@@ -91,8 +91,49 @@ def _alloc_train(eng, B, L, dev):
     st.A_cT = (_bf(2 * C // 32, st.Ms, 32, dev=dev), _bf(2 * C // 32, st.Ms, 32, dev=dev))
     st.zero_bias = torch.zeros(max(st.M2pad, st.Ms, 1024), dtype=torch.float32, device=dev)
     st.sw_scratch = torch.empty(_lib.load().t2s_small_wgrad_scratch(B, xc), dtype=torch.float32, device=dev)
+    # channel-last weight-gradient GEMM (t2s_wgrad_cl): constant chunks and the per-layer operand tables (built on first use)
+    st.cl_ok = C % 32 == 0 and g["n_cond"] % 32 == 0 and not os.environ.get("T2S_WGRAD_TM")
+    st.zero_plane = _bf(Lp, 32, dev=dev)
+    st.ones_plane = _bf(Lp, 32, dev=dev)
+    st.ones_plane[g["halo"]:g["halo"] + L, 0] = 1.0
+    st.cl_tables = {}
     eng.ws[key] = st
     return st
+
+
+def _chunk_rows(pair, n_chunks, shift=0):
+    """t2s_wgrad_chunk rows of the first n_chunks 32-channel chunks of a (hi, lo) plane pair [B, chunks, Lp, 32], rows shifted by
+    `shift` (a dilated tap)."""
+    hi, lo = pair
+    Bc, nch, Lp, _ = hi.shape
+    return [[hi.data_ptr() + 2 * (c * Lp + shift) * 32, lo.data_ptr() + 2 * (c * Lp + shift) * 32, nch * Lp * 32]
+            for c in range(n_chunks)]
+
+
+def _chunk_table(ts, rows, dev):
+    """Pad to 8 chunks per 256-row tile with the zero chunk; int64 [n][3] in device memory."""
+    z = [ts.zero_plane.data_ptr(), ts.zero_plane.data_ptr(), 0]
+    rows = rows + [z] * (-len(rows) % 8)
+    return torch.tensor(rows, dtype=torch.int64).to(dev)
+
+
+def _cl_tables(ts, key, lay_sv, last, xc, sc, ks, d, dev):
+    """Operand tables of the two weight-gradient GEMMs of one WN layer (the buffers they point at are allocated once per shape,
+    so the tables are built once)."""
+    t = ts.cl_tables.get(key)
+    if t is not None:
+        return t
+    ones = [[ts.ones_plane.data_ptr(), ts.zero_plane.data_ptr(), 0]]
+    a1 = ([] if last else _chunk_rows(ts.DX, xc)) + _chunk_rows(ts.DS, xc)            # [d_x ; d_skip]
+    b1 = _chunk_rows(lay_sv["A"], xc) + ones                                            # [acts | 1]
+    a2 = _chunk_rows(ts.DP, 2 * xc)                                                     # d_pre (tanh half, sigmoid half)
+    b2 = []
+    for tap in range(ks):
+        b2 += _chunk_rows(lay_sv["X"], xc, (tap - ks // 2) * d)                         # x shifted by the dilated tap
+    b2 += _chunk_rows(ts.S_planes, sc) + ones                                           # [ .. | spect | 1]
+    t = tuple(_chunk_table(ts, r, dev) for r in (a1, b1, a2, b2))
+    ts.cl_tables[key] = t
+    return t
 
 
 def forward_train(eng, mel, audio):
@@ -183,11 +224,13 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
     st2 = _lib.c_vp(side_s.cuda_stream)
     side_s.wait_stream(main_s)
     ev_dx_ready, ev_tdp_done = None, None
-    # conditioning rows + the ones row of the in/cond weight-gradient GEMM are the same for every layer
-    _lib.call("t2s_plane_transpose", _ptr(ts.S_planes[0]), _ptr(ts.S_planes[1]), B, sc, sc, Lp, 0, _ptr(ts.TM_x[0]),
-              _ptr(ts.TM_x[1]), ts.N2pad, ks * C, st2)
-    _lib.call("t2s_tm_ones_row", _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), B, Lp, halo, L, ts.N2pad, ts.N2 - 1, st2)
-    _lib.call("t2s_tm_ones_row", _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]), B, Lp, halo, L, ts.N1pad, C, st2)
+    cl = ts.cl_ok       # weight-gradient GEMMs straight from the channel-last planes (no time-major copies)
+    if not cl:
+        # conditioning rows + the ones row of the in/cond weight-gradient GEMM are the same for every layer
+        _lib.call("t2s_plane_transpose", _ptr(ts.S_planes[0]), _ptr(ts.S_planes[1]), B, sc, sc, Lp, 0, _ptr(ts.TM_x[0]),
+                  _ptr(ts.TM_x[1]), ts.N2pad, ks * C, st2)
+        _lib.call("t2s_tm_ones_row", _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), B, Lp, halo, L, ts.N2pad, ts.N2 - 1, st2)
+        _lib.call("t2s_tm_ones_row", _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]), B, Lp, halo, L, ts.N1pad, C, st2)
     dsp_init = 1
     keep = []
 
@@ -293,30 +336,43 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             ev_dp.record(main_s)
             # 2. dW_rs = [dx ; dS] . acts^T  (+ bias column)                                                 [side]
             side_s.wait_event(ev_in)
-            if not last:
-                _lib.call("t2s_plane_transpose", _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, xc, xc, Lp, 0, _ptr(ts.TM_drs[0]),
-                          _ptr(ts.TM_drs[1]), Mrs, 0, st2)
-            _lib.call("t2s_plane_transpose", _ptr(ts.DS[0]), _ptr(ts.DS[1]), B, xc, xc, Lp, 0, _ptr(ts.TM_drs[0]),
-                      _ptr(ts.TM_drs[1]), Mrs, 0 if last else C, st2)
-            ev_tdrs = torch.cuda.Event()        # DX / DS have been read: the chain may update DX in place
-            ev_tdrs.record(side_s)
-            _lib.call("t2s_plane_transpose", _ptr(sv["A"][0]), _ptr(sv["A"][1]), B, xc, xc, Lp, 0, _ptr(ts.TM_act[0]),
-                      _ptr(ts.TM_act[1]), ts.N1pad, 0, st2)
-            _lib.call("t2s_wgrad_gemm_flat", _ptr(ts.TM_drs[0]), _ptr(ts.TM_drs[1]), _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]), _ptr(zb),
-                      _ptr(ts.P1), B, rows2, ts.N1, Mrs, ts.N1pad, nt, ts.k0, ts.k1, ts.ks1, st2)
+            d = 2 ** i
+            if cl:
+                ta1, tb1, ta2, tb2 = _cl_tables(ts, (k, i), sv, last, xc, sc, ks, d, dev)
+                _lib.call("t2s_wgrad_cl", _ptr(ta1), ta1.size(0), _ptr(tb1), tb1.size(0), _ptr(ts.P1), B, rows2, ts.N1,
+                          ts.k0, ts.k1, ts.ks1, st2)
+                ev_tdrs = torch.cuda.Event()        # DX / DS have been read: the chain may update DX in place
+                ev_tdrs.record(side_s)
+            else:
+                if not last:
+                    _lib.call("t2s_plane_transpose", _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, xc, xc, Lp, 0, _ptr(ts.TM_drs[0]),
+                              _ptr(ts.TM_drs[1]), Mrs, 0, st2)
+                _lib.call("t2s_plane_transpose", _ptr(ts.DS[0]), _ptr(ts.DS[1]), B, xc, xc, Lp, 0, _ptr(ts.TM_drs[0]),
+                          _ptr(ts.TM_drs[1]), Mrs, 0 if last else C, st2)
+                ev_tdrs = torch.cuda.Event()        # DX / DS have been read: the chain may update DX in place
+                ev_tdrs.record(side_s)
+                _lib.call("t2s_plane_transpose", _ptr(sv["A"][0]), _ptr(sv["A"][1]), B, xc, xc, Lp, 0, _ptr(ts.TM_act[0]),
+                          _ptr(ts.TM_act[1]), ts.N1pad, 0, st2)
+                _lib.call("t2s_wgrad_gemm_flat", _ptr(ts.TM_drs[0]), _ptr(ts.TM_drs[1]), _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]),
+                          _ptr(zb), _ptr(ts.P1), B, rows2, ts.N1, Mrs, ts.N1pad, nt, ts.k0, ts.k1, ts.ks1, st2)
             wn_grads(conv_rs, ts.P1, ts.ks1, rows2, ts.N1, 0, 0, C, rows2, C, 1, stream=st2)
             # 3. dW_in, dW_cond = d_pre . [x taps | spect | 1]^T                                             [side]
             side_s.wait_event(ev_dp)
-            _lib.call("t2s_plane_transpose", _ptr(ts.DP[0]), _ptr(ts.DP[1]), B, 2 * xc, 2 * xc, Lp, 0, _ptr(ts.TM_dp[0]),
-                      _ptr(ts.TM_dp[1]), ts.M2pad, 0, st2)
-            ev_tdp_done = torch.cuda.Event()
-            ev_tdp_done.record(side_s)
-            d = 2 ** i
-            for tap in range(ks):
-                _lib.call("t2s_plane_transpose", _ptr(sv["X"][0]), _ptr(sv["X"][1]), B, xc, xc, Lp, (tap - ks // 2) * d,
-                          _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), ts.N2pad, tap * C, st2)
-            _lib.call("t2s_wgrad_gemm_flat", _ptr(ts.TM_dp[0]), _ptr(ts.TM_dp[1]), _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), _ptr(zb),
-                      _ptr(ts.P2), B, 2 * C, ts.N2, ts.M2pad, ts.N2pad, nt, ts.k0, ts.k1, ts.ks2, st2)
+            if cl:
+                _lib.call("t2s_wgrad_cl", _ptr(ta2), ta2.size(0), _ptr(tb2), tb2.size(0), _ptr(ts.P2), B, 2 * C, ts.N2,
+                          ts.k0, ts.k1, ts.ks2, st2)
+                ev_tdp_done = torch.cuda.Event()    # d_pre has been read: the next layer's gate backward may overwrite DP
+                ev_tdp_done.record(side_s)
+            else:
+                _lib.call("t2s_plane_transpose", _ptr(ts.DP[0]), _ptr(ts.DP[1]), B, 2 * xc, 2 * xc, Lp, 0, _ptr(ts.TM_dp[0]),
+                          _ptr(ts.TM_dp[1]), ts.M2pad, 0, st2)
+                ev_tdp_done = torch.cuda.Event()
+                ev_tdp_done.record(side_s)
+                for tap in range(ks):
+                    _lib.call("t2s_plane_transpose", _ptr(sv["X"][0]), _ptr(sv["X"][1]), B, xc, xc, Lp, (tap - ks // 2) * d,
+                              _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), ts.N2pad, tap * C, st2)
+                _lib.call("t2s_wgrad_gemm_flat", _ptr(ts.TM_dp[0]), _ptr(ts.TM_dp[1]), _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]),
+                          _ptr(zb), _ptr(ts.P2), B, 2 * C, ts.N2, ts.M2pad, ts.N2pad, nt, ts.k0, ts.k1, ts.ks2, st2)
             wn_grads(conv_in, ts.P2, ts.ks2, 2 * C, ts.N2, 0, C, ts.N2 - 1, 2 * C, C, ks, stream=st2)
             wn_grads(conv_c, ts.P2, ts.ks2, 2 * C, ts.N2, ks * C, 0, ts.N2 - 1, 2 * C, n_cond, 1, stream=st2)
             # 4. dx (+)= W_in^T (*) d_pre ;  d_spect += W_cond^T d_pre                                       [main]
