@@ -153,7 +153,7 @@ class _Engine:
         return g
 
     # ------------------------------------------------------------------ weights
-    def pack_weights(self, device, force=True):
+    def pack_weights(self, device, force=True, flow_events=None):
         m = self.m
         key = tuple(p._version for p in m.parameters()) + (str(device),)
         if not force and self.packed is not None and self.packed_key == key:
@@ -207,18 +207,21 @@ class _Engine:
                 specs.append((t[6], t[7], t[8], None, ly["A2h"], ly["A2l"], ly["b2"], t[6].size(0), C, 1, 0, 0, ly["Mpad2"], 0,
                               g["Cpad"], ly["s_rs"]))
         ptr_key = tuple(0 if t is None else t.data_ptr() for t in srcs)
+        jpf = 3 * nl                                   # jobs per flow: (in, cond, res_skip) x layers
         if self.packed.get("job_key") != ptr_key:
-            rows, row_start = [], 0
+            rows, flow_rows, row_start = [], [], 0
             dp = lambda t: 0 if t is None else t.data_ptr()
-            for (v, gg, b1, b2, Ah, Al, bo, O, Cin, Kt, perm, Cg, Mpad, koff, Cin_pad, so) in specs:
+            for n, (v, gg, b1, b2, Ah, Al, bo, O, Cin, Kt, perm, Cg, Mpad, koff, Cin_pad, so) in enumerate(specs):
+                if n % jpf == 0 and n:                  # row_start restarts per flow: every flow's jobs are a table of their own
+                    flow_rows.append(row_start)
+                    row_start = 0
                 rows.append([dp(v), dp(gg), dp(b1), dp(b2), dp(Ah), dp(Al), dp(bo), row_start,
                              O, Cin, Kt, perm, Cg, Mpad, koff, Cin_pad, 0, 0, dp(so)])
                 row_start += -(-O // 16)          # the table kernel packs 16 rows per workgroup
+            flow_rows.append(row_start)
             self.packed["jobs"] = torch.tensor(rows, dtype=torch.int64).to(device)
-            self.packed["n_jobs"], self.packed["total_rows"] = len(rows), row_start
+            self.packed["flow_rows"] = flow_rows
             self.packed["job_key"] = ptr_key
-        _lib.call("t2s_pack_conv_weight_table", _lib.ptr(self.packed["jobs"]), self.packed["n_jobs"],
-                  self.packed["total_rows"], st)
         # WN.end folded into the skip path: (W_end . W_skip_i)^T per layer, from the scales the pack just wrote
         fsrc = []
         for k in range(m.n_flows):
@@ -238,16 +241,27 @@ class _Engine:
                              br.data_ptr() + 4 * r0, ly["fold_A"].data_ptr(), bes.data_ptr() + 4 * 8 * i, nj, C])
             self.packed["fold_jobs"] = torch.tensor(rows, dtype=torch.int64).to(device)
             self.packed["fold_key"] = fkey
-        _lib.call("t2s_wg_endfold_weights", _lib.ptr(self.packed["fold_jobs"]), len(fsrc), C, st)
-        keep = srcs + [t for tup in fsrc for t in tup[:3]]
+        # One table-driven launch per flow packs its 3 * n_layers convolutions (weight-norm + split + permute), one more
+        # builds its folded WN.end matrices, a third its `start` weights.  With `flow_events` (the no-grad forward) the per-flow
+        # work is enqueued on the caller's current stream - a side stream there - and an event per flow lets the main stream
+        # start flow k as soon as ITS weights are packed: the pack is HBM-bound (2.1 GB per forward), the GEMMs are not.
+        jobs_ptr, fold_ptr = self.packed["jobs"].data_ptr(), self.packed["fold_jobs"].data_ptr()
+        starts = []
         for k in range(m.n_flows):
             wn = m.WN[k]
             fl = self.packed["flows"][k]
+            _lib.call("t2s_pack_conv_weight_table", _lib.c_vp(jobs_ptr + k * jpf * 19 * 8), jpf, self.packed["flow_rows"][k], st)
+            _lib.call("t2s_wg_endfold_weights", _lib.c_vp(fold_ptr + k * nl * 8 * 8), nl, C, st)
             v, gg = _vg(wn.start)
             v, gg = _f32c(v), (None if gg is None else _f32c(gg))
-            keep += [v, gg]
+            starts += [v, gg]
             _lib.call("t2s_weightnorm_small", _lib.ptr(v), _lib.ptr(gg), C, fl["n_half"], _lib.ptr(fl["w_start"]), st)
             fl["w_inv"] = None
+            if flow_events is not None:
+                ev = torch.cuda.Event()
+                ev.record()
+                flow_events.append(ev)
+        keep = srcs + [t for tup in fsrc for t in tup[:3]] + starts
         self.packed_key = key
         self._keep = keep
         return self.packed
@@ -389,10 +403,21 @@ class _Engine:
                 _lib.call("t2s_small_logdet_inv_batch_host", ctypes.c_void_p(jobs.data_ptr()), m.n_flows, float(B * L), st2)
             else:
                 _lib.call("t2s_small_logdet_inv_batch", _lib.ptr(jobs), m.n_flows, float(B * L), st2)
-        self.pack_weights(dev, force=True)
+        # The per-forward weight pack (weight_norm recompute + split + permute, HBM-bound: 1.07 GB in, 1.07 GB out) runs flow by
+        # flow on a third stream; the main stream waits for flow k's event only, so all but the first flow's share of the pack
+        # hides under the GEMMs of the flows before it.
+        pack_s = self.pack_stream if getattr(self, "pack_stream", None) is not None else torch.cuda.Stream(device=dev)
+        self.pack_stream = pack_s
+        if os.environ.get("T2S_NO_SIDE_STREAM") or os.environ.get("T2S_PACK_OVERLAP") == "0":
+            pack_s = main                   # A/B switch: the whole pack in front of flow 0 on the caller's stream (round 1)
+        pack_events = []
+        pack_s.wait_stream(main)
+        with torch.cuda.stream(pack_s):
+            self.pack_weights(dev, force=True, flow_events=pack_events)
         main.wait_stream(side)
         st = _lib.current_stream()
         for k in range(m.n_flows):
+            main.wait_event(pack_events[k])
             c_off, n_rem, n_half = self._flow_geom(k)
             Wk = Ws[k]
             _lib.call("t2s_wg_convinv", _lib.ptr(z), _lib.ptr(Wk), B, G, c_off, n_rem, L, st)
