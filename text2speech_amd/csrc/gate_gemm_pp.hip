@@ -306,23 +306,49 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
     // n-tile n covers tile columns (n >> 1) * 128 + wc * 32 + (n & 1) * 16.
     const int tcol = lane & 15;
     const int rq = (lane >> 4) * 4;
+    // Everything the epilogue reads from memory is requested here in one batch (the fragment registers are free now): the 16
+    // bias vectors, the folded-WN.end weights and - for layers after the first - the running fold sums this wave adds to.  One
+    // memory round trip instead of a dependent one in front of each (pair, half) block and a read-modify-write at the very end.
+    f32x4 bt_all[4], bs_all[4];
+#pragma unroll
+    for (int mp = 0; mp < 4; ++mp) {
+        const int prow = mt * 256 + (mp >> 1) * 128 + wr * 64 + (mp & 1) * 32 + rq;
+        bt_all[mp] = *(const f32x4*)(a.bias + prow);
+        bs_all[mp] = *(const f32x4*)(a.bias + prow + 16);
+    }
+    bf16x8 fw_h[2] = {}, fw_l[2] = {};
+    if (a.fold_A) {
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {
+            const u16* fa = a.fold_A + ((size_t)(mt * 4 + pair * 2 + wr) * 2 * 64 + lane) * 8;
+            fw_h[pair] = *(const bf16x8*)fa;
+            fw_l[pair] = *(const bf16x8*)(fa + 64 * 8);
+        }
+    }
     f32x4 facc[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) facc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.fold_A && !a.fold_init && lane < 32) {       // start from the running sums: the final store needs no load then
+        const int slot = mt * 2 + wr;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int t = t0 + (n >> 1) * 128 + wc * 32 + (n & 1) * 16 + tcol;
+            const int tc = t < a.L ? t : 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) facc[n][e] = a.fold_acc[(((size_t)slot * a.B + b) * 8 + rq + e) * a.L + tc];
+        }
+    }
 #pragma unroll
     for (int pair = 0; pair < 2; ++pair) {
         u16x4 hv[2][4], lv[2][4];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int mp = pair * 2 + half;
-            const int prow = mt * 256 + pair * 128 + wr * 64 + half * 32 + rq;          // tanh rows prow..prow+3
             // gate in exp2 / rcp form: E = e^(2x), F = e^(-y);  tanh(x) = (E - 1) / (E + 1),  sigmoid(y) = 1 / (1 + F).
             // The bias is folded into the exponent (one fma per value); x is clamped at 10 (tanh(10) rounds to 1.0f) so that E
             // stays finite; F = inf (y < -88) gives 1 / inf = 0, the correctly rounded limit.  v_exp_f32 / v_rcp_f32 are 1 ulp.
             constexpr float L2E = 1.4426950408889634f;
-            const f32x4 bt0 = *(const f32x4*)(a.bias + prow);
-            const f32x4 bs0 = *(const f32x4*)(a.bias + prow + 16);
-            const f32x4 bt = bt0 * (2.0f * L2E), bs = bs0 * (-L2E);
+            const f32x4 bt = bt_all[mp] * (2.0f * L2E), bs = bs_all[mp] * (-L2E);
             const int ch = mt * 128 + pair * 64 + wr * 32 + half * 16 + rq;             // channels ch..ch+3
             const bool chv = ch < a.C;
             const size_t obase = (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
@@ -376,9 +402,7 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
         }
         if (a.fold_A) {
             // fold_A blocks are indexed by the 32-channel block of the M tile (endfold_weights_kernel: block = c >> 5)
-            const u16* fa = a.fold_A + ((size_t)(mt * 4 + pair * 2 + wr) * 2 * 64 + lane) * 8;
-            const bf16x8 wh = *(const bf16x8*)fa;
-            const bf16x8 wl = *(const bf16x8*)(fa + 64 * 8);
+            const bf16x8 wh = fw_h[pair], wl = fw_l[pair];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
@@ -402,8 +426,7 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
             if (t >= a.L) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float* dst = a.fold_acc + ((((size_t)slot * a.B + b) * 8 + rq + e) * a.L + t);
-                *dst = a.fold_init ? facc[n][e] : *dst + facc[n][e];
+                a.fold_acc[(((size_t)slot * a.B + b) * 8 + rq + e) * a.L + t] = facc[n][e];
             }
         }
     }
