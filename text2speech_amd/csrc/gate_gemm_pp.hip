@@ -38,6 +38,19 @@ constexpr int PP_PLANE = 16384;          // one plane tile: 256 rows x 64 B
 constexpr int PP_HALF = 8192;            // 128 rows
 constexpr int PP_BUF = 4 * PP_PLANE;     // A_hi, A_lo, B_hi, B_lo
 
+// 8-byte plane store.  Measured negative (profiles/r02_summary.md): making these stores write-through (sc1, -DT2S_PP_SC1_STORES:
+// the bytes leave the XCD's L2 during the epilogue instead of at the end-of-kernel release) costs 1.4 % on the gate GEMM and
+// 1.1 % on the forward - 8-byte sc1 stores run at 0.54-0.70 x the 16-byte rate and the residual GEMM that follows no longer
+// finds the gate outputs in L2.  Plain stores are the default.
+__device__ __forceinline__ void pp_store8(u16* dst, u16x4 v) {
+#ifdef T2S_PP_SC1_STORES
+    __hip_atomic_store((unsigned long long*)dst, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *(u16x4*)dst = v;
+#endif
+}
+
 __device__ __forceinline__ int pp_swz4(int rb) { return (0x78 >> (rb * 2)) & 3; }      // {0,2,3,1}[rb]
 
 __device__ __forceinline__ void pp_glds16(const void* gsrc, void* lds_dst) {
@@ -377,10 +390,10 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
                             ghi[e] = h;
                             glo[e] = l;
                         }
-                        *(u16x4*)(a.T_hi + o) = thi;
-                        *(u16x4*)(a.T_lo + o) = tlo;
-                        *(u16x4*)(a.G_hi + o) = ghi;
-                        *(u16x4*)(a.G_lo + o) = glo;
+                        pp_store8(a.T_hi + o, thi);
+                        pp_store8(a.T_lo + o, tlo);
+                        pp_store8(a.G_hi + o, ghi);
+                        pp_store8(a.G_lo + o, glo);
                     } else {           // forward / infer: only the product is needed - one reciprocal for both
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -393,8 +406,8 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
                             lo[e] = l;
                         }
                     }
-                    *(u16x4*)(a.O_hi + o) = hi;
-                    *(u16x4*)(a.O_lo + o) = lo;
+                    pp_store8(a.O_hi + o, hi);
+                    pp_store8(a.O_lo + o, lo);
                 }
                 hv[half][n] = hi;
                 lv[half][n] = lo;
