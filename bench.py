@@ -369,8 +369,9 @@ def main():
             for name in (GEMM_PMC, "r01_pmc_traffic_v5.json"):
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", name)))
-                    # the gate GEMM runs as two instantiations (shared-B tile for dilation <= 32, plain otherwise)
-                    gk = [v for k, v in pm["kernels"].items() if k.startswith("_Z16conv_gemm_kernelILi0E")]
+                    # the gate GEMM: the ping-pong kernel (round 2), or the two lockstep instantiations of round 1
+                    gk = [v for k, v in pm["kernels"].items() if k.startswith("_Z19gate_gemm_pp_kernel")] or \
+                         [v for k, v in pm["kernels"].items() if k.startswith("_Z16conv_gemm_kernelILi0E")]
                     traffic = sum(v["traffic_bytes_per_launch"] * v["launches"] for v in gk) / sum(v["launches"] for v in gk)
                     tsrc = name
                     break
@@ -379,11 +380,13 @@ def main():
             roof = {"bound": "mfma", "kernel": "conv_gemm_kernel<EPI_GATE> (in_layers+cond_layers+gate)",
                     "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
-                    "traffic_note": "bytes/launch at batch 8x16000 from profiles/%s (separate --pmc passes, tools/pmc_traffic.py; "
-                                    "launch-weighted over the two gate-GEMM instantiations); compulsory bytes are 83 MB read + "
+                    "traffic_note": "bytes/launch at batch 8x16000 from profiles/%s (separate --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                                    "FETCH doubled per the gfx950 note, tools/pmc_traffic.py); algorithmic bytes are 83 MB read + "
                                     "33 MB written" % tsrc,
                     "avg_launch_ms": avg_ms, "launches": len(ms), "algorithmic_flops_per_launch": flops_per_launch,
-                    "note": "split-bf16: 3 bf16 MFMA products per algorithmic MAC, so frac <= 1/3 by construction"}
+                    "note": "split-bf16: 3 bf16 MFMA products per algorithmic MAC, so frac <= 1/3 by construction; in-kernel the "
+                            "chip holds 1.85-1.95 GHz under this load (profiles/r02_summary.md), i.e. a 660 TFLOP/s ceiling for "
+                            "this scheme, and the K loop runs at 91 % of MFMA-bound"}
         total_samples = args.gpus * args.batch * args.segment * args.steps
         out = {
             "metric": "WaveGlow forward audio samples/sec (batch 8x16000 per GPU)" if args.mode == "forward"

@@ -493,47 +493,73 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
             }
         }
     } else if (EPI == EPI_RESSKIP) {
+        // The residual / skip values this wave updates in place are requested in batches of m-tiles BEFORE any of them
+        // is consumed: with load -> add -> store per tile (same arrays read and written, so hipcc keeps that order) the
+        // epilogue was a chain of up to MW * NWT dependent memory round trips.
+        constexpr int MB = MW >= 8 ? 2 : 4;        // m-tiles per batch (256-row tiles hold 128 accumulator registers already)
 #pragma unroll
-        for (int m = 0; m < MW; ++m) {
-            const int prow = mt * MT + wr * (MT / 2) + m * 16 + rq;
-            const f32x4 bv = *(const f32x4*)(a.bias + prow);
-            if (prow < a.n_res) {
-                const int ch = prow;
-                u16* xhi = a.O_hi + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
-                u16* xlo = a.O_lo + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+        for (int m0 = 0; m0 < MW; m0 += MB) {
+            f32x4 bv[MB];
+            u16x4 oh[MB][NWT], ol[MB][NWT];
+            f32x4 sv[MB][NWT];
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi) {
+                const int prow = mt * MT + wr * (MT / 2) + (m0 + mi) * 16 + rq;
+                bv[mi] = *(const f32x4*)(a.bias + prow);
+                const bool is_res = prow < a.n_res;
+                const int ch = is_res ? prow : prow - a.n_res;
+                const size_t base = (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
 #pragma unroll
                 for (int n = 0; n < NWT; ++n) {
                     const int t = t0 + wc * (NWT * 16) + n * 16 + tcol;
-                    if (t >= a.L) continue;
-                    u16x4 oh = {0, 0, 0, 0}, ol = {0, 0, 0, 0};
-                    if (!a.res_init) {
-                        const size_t ro = (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo + t) * 32 + (ch & 31);
-                        oh = *(const u16x4*)((a.R_hi ? a.R_hi : a.O_hi) + ro);
-                        ol = *(const u16x4*)((a.R_lo ? a.R_lo : a.O_lo) + ro);
+                    const size_t ro = base + (size_t)(t < a.L ? t : 0) * 32;
+                    oh[mi][n] = (u16x4){0, 0, 0, 0};
+                    ol[mi][n] = (u16x4){0, 0, 0, 0};
+                    sv[mi][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (is_res) {
+                        if (!a.res_init) {
+                            oh[mi][n] = *(const u16x4*)((a.R_hi ? a.R_hi : a.O_hi) + ro);
+                            ol[mi][n] = *(const u16x4*)((a.R_lo ? a.R_lo : a.O_lo) + ro);
+                        }
+                    } else if (ch < a.C && !a.skip_init) {
+                        sv[mi][n] = *(const f32x4*)(a.skip + ro);
                     }
-                    u16x4 hi, lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = join_bf16(oh[e], ol[e]) + (acc[m][n][e] + bv[e]);
-                        u16 h, l;
-                        split_bf16(v, h, l);
-                        hi[e] = h;
-                        lo[e] = l;
-                    }
-                    *(u16x4*)(xhi + (size_t)t * 32) = hi;
-                    *(u16x4*)(xlo + (size_t)t * 32) = lo;
                 }
-            } else {
-                const int ch = prow - a.n_res;
-                if (ch >= a.C) continue;
-                float* sk = a.skip + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+            }
 #pragma unroll
-                for (int n = 0; n < NWT; ++n) {
-                    const int t = t0 + wc * (NWT * 16) + n * 16 + tcol;
-                    if (t >= a.L) continue;
-                    f32x4 v = acc[m][n] + bv;
-                    if (!a.skip_init) v += *(const f32x4*)(sk + (size_t)t * 32);
-                    *(f32x4*)(sk + (size_t)t * 32) = v;
+            for (int mi = 0; mi < MB; ++mi) {
+                const int m = m0 + mi;
+                const int prow = mt * MT + wr * (MT / 2) + m * 16 + rq;
+                if (prow < a.n_res) {
+                    const int ch = prow;
+                    u16* xhi = a.O_hi + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+                    u16* xlo = a.O_lo + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+#pragma unroll
+                    for (int n = 0; n < NWT; ++n) {
+                        const int t = t0 + wc * (NWT * 16) + n * 16 + tcol;
+                        if (t >= a.L) continue;
+                        u16x4 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = join_bf16(oh[mi][n][e], ol[mi][n][e]) + (acc[m][n][e] + bv[mi][e]);
+                            u16 h, l;
+                            split_bf16(v, h, l);
+                            hi[e] = h;
+                            lo[e] = l;
+                        }
+                        *(u16x4*)(xhi + (size_t)t * 32) = hi;
+                        *(u16x4*)(xlo + (size_t)t * 32) = lo;
+                    }
+                } else {
+                    const int ch = prow - a.n_res;
+                    if (ch >= a.C) continue;
+                    float* sk = a.skip + (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+#pragma unroll
+                    for (int n = 0; n < NWT; ++n) {
+                        const int t = t0 + wc * (NWT * 16) + n * 16 + tcol;
+                        if (t >= a.L) continue;
+                        *(f32x4*)(sk + (size_t)t * 32) = acc[m][n] + bv[mi] + sv[mi][n];
+                    }
                 }
             }
         }
