@@ -185,6 +185,15 @@ hipError_t t2s_launch_gemv(const GemvArgs& a, hipStream_t stream) {
 // Wave (unit, kq) keeps float4 slots v = kq, kq+4, ... of its four gate rows in registers; partial sums
 // meet in LDS and thread (unit, item) applies the cell update.
 // UNITS = hidden units per workgroup (4 -> 1024 threads, 2 -> 512 threads); SAVE = keep gates / cell state (training)
+// weight-row loads of the LSTM cell: each row is streamed once per step by ONE workgroup, so they are non-temporal
+// (MI355X_MICROARCH.md nt-weights; same box, alternating: 39.26 / 39.01 vs 39.60 / 39.66 us per step at B = 1).
+// -DT2S_LSTM_PLAIN_LOADS restores default-policy loads.
+#ifdef T2S_LSTM_PLAIN_LOADS
+#define T2S_WLOAD(p) (*(p))
+#else
+#define T2S_WLOAD(p) __builtin_nontemporal_load(p)
+#endif
+
 template <int NVW, int UNITS, bool SAVE>
 __global__ __launch_bounds__(UNITS * 256) void lstm_cell_kernel(const LstmCellArgs a) {
     PROBE_BEGIN(200 + NVW)
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(UNITS * 256) void lstm_cell_kernel(const LstmCellAr
         for (int g = 0; g < 4; ++g) {
             const size_t row = (size_t)g * a.H + u;
             const float* wp = kc < K1 ? a.W_ih + row * K1 + kc : a.W_hh + row * a.H + (kc - K1);
-            w[g][j] = *(const f32x4*)wp;
+            w[g][j] = T2S_WLOAD((const f32x4*)wp);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
