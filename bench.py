@@ -377,12 +377,13 @@ def main():
                     break
                 except (OSError, KeyError, ValueError, ZeroDivisionError):
                     continue
-            roof = {"bound": "mfma", "kernel": "conv_gemm_kernel<EPI_GATE> (in_layers+cond_layers+gate)",
+            roof = {"bound": "mfma", "kernel": "gate_gemm_pp_kernel (in_layers + cond_layers + tanh*sigmoid gate, ping-pong schedule)",
                     "achieved": achieved, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
                     "traffic_note": "bytes/launch at batch 8x16000 from profiles/%s (separate --pmc FETCH_SIZE / WRITE_SIZE passes, "
                                     "FETCH doubled per the gfx950 note, tools/pmc_traffic.py); algorithmic bytes are 83 MB read + "
-                                    "33 MB written" % tsrc,
+                                    "33 MB written; the fetch side is fabric requests: 74 MB of activations once plus the 8.9 MB "
+                                    "of packed weights once per XCD (8 private L2s)" % tsrc,
                     "avg_launch_ms": avg_ms, "launches": len(ms), "algorithmic_flops_per_launch": flops_per_launch,
                     "note": "split-bf16: 3 bf16 MFMA products per algorithmic MAC, so frac <= 1/3 by construction; in-kernel the "
                             "chip holds 1.85-1.95 GHz under this load (profiles/r02_summary.md), i.e. a 660 TFLOP/s ceiling for "

@@ -58,10 +58,16 @@ __device__ __forceinline__ void pp_glds16(const void* gsrc, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// B-operand source of one K-step: tap-major over the conv input (row offset (tap - taps/2) * dil), then the conditioning
-// planes.  All state is wave-uniform (scalar registers); the per-thread part of the address is inside the base pointers.
+// Operand sources of one K-step.  The conv input is walked channel-chunk-major with the taps innermost: the `taps` tiles of
+// one channel chunk are the same rows shifted by dil, and fetched on consecutive K-steps the second and third are L2 hits
+// (tap-major they were nk_x / taps K-steps apart -- ~16 MB of other tiles per XCD in between -- and each came from the
+// fabric again: 218 MB fetched per launch against 83 MB of operands).  The packed weights stay tap-major, so the A chunk is
+// addressed through the cursor (aoff) instead of by the K-step number; then come the conditioning planes.  All state is
+// wave-uniform (scalar registers); the per-thread part of the address is inside the base pointers.
+// -DT2S_PP_TAP_MAJOR restores the tap-major walk (and with it the round-1 summation order) for A/B runs.
 struct BCursor {
     long off;       // bytes from the X (or S) base
+    long aoff;      // bytes from the A base: packed K-chunk index * Mpad * 64
     int kc, tap;
     bool in_s;
 };
@@ -122,21 +128,30 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
     auto cursor_at = [&](int ks) {
         BCursor c;
         if (ks < a.nk_x) {
+#ifdef T2S_PP_TAP_MAJOR
             c.tap = ks / a.xc;
             c.kc = ks - c.tap * a.xc;
+#else
+            c.kc = ks / a.taps;
+            c.tap = ks - c.kc * a.taps;
+#endif
             c.in_s = false;
             c.off = (long)c.kc * (long)x_cstride + (long)((c.tap - (a.taps >> 1)) * a.dil) * 64;
+            c.aoff = (long)(c.tap * a.xc + c.kc) * (long)a_kstride;
         } else {
             c.tap = a.taps;
             c.kc = ks - a.nk_x;
             c.in_s = true;
             c.off = (long)c.kc * (long)x_cstride;
+            c.aoff = (long)ks * (long)a_kstride;
         }
         return c;
     };
+#ifdef T2S_PP_TAP_MAJOR
     auto advance = [&](BCursor& c) {
         c.kc += 1;
         c.off += (long)x_cstride;
+        c.aoff += (long)a_kstride;
         if (!c.in_s && c.kc == a.xc) {
             c.kc = 0;
             c.tap += 1;
@@ -148,9 +163,37 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
             }
         }
     };
-    auto stage_a = [&](int ks, int half) {
+#else
+    const long tap_step = (long)a.dil * 64;
+    const long a_tap_step = (long)a.xc * (long)a_kstride;
+    auto advance = [&](BCursor& c) {
+        if (c.in_s) {
+            c.kc += 1;
+            c.off += (long)x_cstride;
+            c.aoff += (long)a_kstride;
+            return;
+        }
+        c.tap += 1;
+        c.off += tap_step;
+        c.aoff += a_tap_step;
+        if (c.tap == a.taps) {
+            c.tap = 0;
+            c.kc += 1;
+            c.off = (long)c.kc * (long)x_cstride - (long)(a.taps >> 1) * tap_step;
+            c.aoff = (long)c.kc * (long)a_kstride;
+            if (c.kc == a.xc) {
+                c.in_s = true;
+                c.tap = a.taps;
+                c.kc = 0;
+                c.off = 0;
+                c.aoff = (long)a.nk_x * (long)a_kstride;
+            }
+        }
+    };
+#endif
+    auto stage_a = [&](int ks, const BCursor& c, int half) {
         char* dst = lds_wave + (ks & 1) * PP_BUF + half * PP_HALF;
-        const size_t off = (size_t)ks * a_kstride + (size_t)half * PP_HALF;
+        const size_t off = (size_t)c.aoff + (size_t)half * PP_HALF;
         pp_glds16(A_hi + off, dst);
         pp_glds16(A_lo + off, dst + PP_PLANE);
     };
@@ -175,14 +218,14 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
 
     // ---- prologue: K-step 0 whole, A half 0 / B half 0 of K-step 1 (the steady-state lead) ----
     BCursor c1 = cursor_at(0);          // becomes the cursor of K-step ks + 1
-    stage_a(0, 0);
+    stage_a(0, c1, 0);
     stage_b(0, c1, 0);
     stage_b(0, c1, 1);
-    stage_a(0, 1);
+    stage_a(0, c1, 1);
     advance(c1);                        // K-step 1
     BCursor c2 = c1;                    // cursor of K-step ks + 2
     if (nk > 1) {
-        stage_a(1, 0);
+        stage_a(1, c1, 0);
         stage_b(1, c1, 0);
         advance(c2);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -243,7 +286,7 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
             b1l[n] = *(const bf16x8*)(sb + b_frag + PP_HALF + PP_PLANE + n * 1024);
         }
         }
-        if ((MAIN && !(ABL & 1)) || (!MAIN && ks + 1 < nk)) stage_a(ks + 1, 1);
+        if ((MAIN && !(ABL & 1)) || (!MAIN && ks + 1 < nk)) stage_a(ks + 1, c1, 1);
         if (MAIN && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -267,7 +310,7 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
             afl[m] = *(const bf16x8*)(sb + a_frag + PP_HALF + PP_PLANE + m * 1024);
         }
         }
-        if ((MAIN && !(ABL & 1)) || (!MAIN && ks + 2 < nk)) stage_a(ks + 2, 0);
+        if ((MAIN && !(ABL & 1)) || (!MAIN && ks + 2 < nk)) stage_a(ks + 2, c2, 0);
         if (MAIN && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
