@@ -335,10 +335,134 @@ __global__ __launch_bounds__(256) void upsample_squeeze_kernel(const float* __re
     }
 }
 
+// The same operator as a GEMM on the exact-f32 matrix cores (v_mfma_f32_16x16x4_f32), for the shape WaveGlow uses (n_group 8,
+// ksize = 4 * stride, stride a multiple of 64, n_mel a multiple of 4):
+//   rows    m = (co, p), p = position inside a hop        A[m][k] = W[ci][co][j * stride + p]
+//   columns n = (b, f), f = hop (mel frame) index          B[k][n] = mel[b][ci][f - j]   (0 outside [0, F))
+//   K       k = (ci, j), j = 0..3 the four overlapping hops
+// 6.6 GFLOP at batch 8 x 16000: 438 us on the vector ALUs, 110 us here (the matrix-core floor is 53 us).  One wave owns 16 positions p of the four output
+// channels that make up one 32-channel plane chunk (4 m-tiles) times NT column tiles of 16 frames; one K-step = one input channel
+// (lane >> 4 = j).  Operands go global -> register (each A value is used by NT tiles, each B value by 4; W is 26 MB and every
+// wave streams its slice once, mel is 160 KB and cache-resident), prefetched one K-step ahead.
+// D tile: col = lane & 15 (frame), row = 4 * (lane >> 4) + e -> p = p0 + 4q + e: plane row t = f * (stride / 8) + (p >> 3),
+// squeezed channel co * 8 + (p & 7): the lane's four values are four consecutive channels of one plane row, one 8-B store.
+typedef float f32x4_up __attribute__((ext_vector_type(4)));
+template <int NT, int KB>
+__global__ __launch_bounds__(256) void upsample_mfma_kernel(const float* __restrict__ mel, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, int B, int M, int F, int ksize,
+                                                            int stride, int L, int Lp, int halo, int tiles_per_b, int n_ctiles,
+                                                            int n_pairs, int nz, u16* S_hi, u16* S_lo) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    // Workgroups are dealt round-robin to the 8 XCDs: the nz column groups that share one slice of W (a (position block,
+    // channel chunk) pair) sit on ONE XCD, so its L2 fetches the slice once (any-order placement had every XCD stream all 26 MB)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int pair = (slot / nz) * 8 + xcd;
+    if (pair >= n_pairs) return;
+    const int npb = stride >> 6;                          // position blocks of 64 per hop
+    const int p0 = ((pair % npb) * 4 + wave) * 16;
+    const int chunk = pair / npb;                         // 4 output channels = 32 squeezed channels
+    const int ct0 = (slot % nz) * NT;
+    // A: W[(ci * M + co) * ksize + q * stride + p0 + r], co = chunk * 4 + o4; advancing ci adds M * ksize
+    const float* wa = W + (size_t)(chunk * 4) * ksize + (size_t)q * stride + p0 + r;
+    const size_t wa_step = (size_t)M * ksize;
+    // B: mel[(b * M + ci) * F + f - q]; advancing ci adds F
+    const float* mb[NT];
+    bool mv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int ct = ct0 + n;
+        const int b = ct / tiles_per_b;
+        const int f = (ct - b * tiles_per_b) * 16 + r - q;
+        mv[n] = ct < n_ctiles && b < B && f >= 0 && f < F;
+        mb[n] = mel + ((size_t)(mv[n] ? b : 0) * M) * F + (mv[n] ? f : 0);
+    }
+    f32x4_up acc[4][NT];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[o][n] = (f32x4_up){0.f, 0.f, 0.f, 0.f};
+    // K runs in batches of KB input channels: the KB * (4 + NT) operand loads of batch i + 1 are in flight under the
+    // KB * 4 * NT matrix instructions of batch i
+    float a_cur[KB][4], b_cur[KB][NT], a_nxt[KB][4], b_nxt[KB][NT];
+#pragma unroll
+    for (int kk = 0; kk < KB; ++kk) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) a_cur[kk][o] = wa[(size_t)kk * wa_step + (size_t)o * ksize];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b_cur[kk][n] = mv[n] ? mb[n][(size_t)kk * F] : 0.f;
+    }
+    for (int ci = 0; ci < M; ci += KB) {
+        const int cn = ci + KB < M ? ci + KB : ci;        // the last batch re-reads its own operands (no branch in the loop)
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) a_nxt[kk][o] = wa[(size_t)(cn + kk) * wa_step + (size_t)o * ksize];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) b_nxt[kk][n] = mv[n] ? mb[n][(size_t)(cn + kk) * F] : 0.f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk)
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[o][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[kk][o], b_cur[kk][n], acc[o][n], 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) a_cur[kk][o] = a_nxt[kk][o];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) b_cur[kk][n] = b_nxt[kk][n];
+        }
+    }
+    const int nchunks = (M * 8 + 31) / 32;
+    const int tpf = stride >> 3;                          // plane rows per hop
+    const int pq = p0 + 4 * q;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int ct = ct0 + n;
+        const int b = ct / tiles_per_b;
+        const int f = (ct - b * tiles_per_b) * 16 + r;
+        const int t = f * tpf + (pq >> 3);
+        if (ct >= n_ctiles || b >= B || t >= L) continue;
+        const size_t row = (((size_t)b * nchunks + chunk) * Lp + halo + t) * 32 + (pq & 7);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const float bo = bias[chunk * 4 + o];
+            u16 hi[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_bf16(acc[o][n][e] + bo, hi[e], lo[e]);
+            uint2 ph, pl;
+            ph.x = hi[0] | ((uint32_t)hi[1] << 16); ph.y = hi[2] | ((uint32_t)hi[3] << 16);
+            pl.x = lo[0] | ((uint32_t)lo[1] << 16); pl.y = lo[2] | ((uint32_t)lo[3] << 16);
+            *(uint2*)(S_hi + row + o * 8) = ph;
+            *(uint2*)(S_lo + row + o * 8) = pl;
+        }
+    }
+}
+
 hipError_t t2s_launch_upsample_squeeze(const float* mel, const float* W, const float* bias, int B, int n_mel,
                                        int frames, int ksize, int stride, int n_group, int L, int Lp, int halo,
                                        u16* S_hi, u16* S_lo, hipStream_t stream) {
     const int nchunks = (n_mel * n_group + 31) / 32;
+    static const bool valu_only = getenv("T2S_UPSAMPLE_VALU") != nullptr;      // A/B switch
+    if (!valu_only && n_group == 8 && ksize == 4 * stride && stride % 64 == 0 && n_mel % 4 == 0) {
+        // frames that reach plane rows < L: f <= (8 * L - 1) / stride
+        const int nf = (8 * L - 1) / stride + 1;
+        const int tiles_per_b = (nf + 15) / 16;
+        const int n_ctiles = tiles_per_b * B;
+        constexpr int NT = 2;
+        const int nz = (n_ctiles + NT - 1) / NT;
+        const int n_pairs = (stride / 64) * (n_mel / 4);
+        dim3 grid(8 * ((n_pairs + 7) / 8) * nz);
+        // KB = 1: one K-step of operands in flight per wave, 5 waves per SIMD.  KB = 4 (four K-steps per round trip, 96 VGPRs)
+        // measured slower on MI355X (145 us against 114 us), as did NT = 4 (132 us): the kernel wants waves, not depth.
+        hipLaunchKernelGGL((upsample_mfma_kernel<NT, 1>), grid, dim3(256), 0, stream, mel, W, bias, B, n_mel, frames, ksize,
+                           stride, L, Lp, halo, tiles_per_b, n_ctiles, n_pairs, nz, S_hi, S_lo);
+        return hipGetLastError();
+    }
     constexpr int BB = 8;
     dim3 grid((L + 63) / 64, nchunks, (B + BB - 1) / BB);
     hipLaunchKernelGGL(upsample_squeeze_kernel<BB>, grid, dim3(256), 0, stream, mel, W, bias, B, n_mel, frames, ksize,

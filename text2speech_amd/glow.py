@@ -397,8 +397,10 @@ class _Engine:
         side.wait_stream(main)               # inputs, the job table and earlier users of the workspace are ordered before
         with torch.cuda.stream(side):
             st2 = _lib.current_stream()
-            self._upsample(mel, B, L, w)
             _lib.call("t2s_wg_audio_squeeze", _lib.ptr(audio32), _lib.ptr(z), B, T, G, L, 0, st2)
+            self._upsample(mel, B, L, w)
+            ev_inputs = torch.cuda.Event()       # flow 0 needs z and the conditioning planes; the log-determinants are only
+            ev_inputs.record()                   # outputs and join at the end
             if use_val:
                 _lib.call("t2s_small_logdet_inv_batch_host", ctypes.c_void_p(jobs.data_ptr()), m.n_flows, float(B * L), st2)
             else:
@@ -414,7 +416,8 @@ class _Engine:
         pack_s.wait_stream(main)
         with torch.cuda.stream(pack_s):
             self.pack_weights(dev, force=True, flow_events=pack_events)
-        main.wait_stream(side)
+        if side is not main:
+            main.wait_event(ev_inputs)
         st = _lib.current_stream()
         for k in range(m.n_flows):
             main.wait_event(pack_events[k])
@@ -426,6 +429,7 @@ class _Engine:
             self._end(k, z, log_s, B, L, w, c_off, n_half, reverse=False)
             log_s_list.append(log_s)
             log_det_list.append(log_det[k])
+        main.wait_stream(side)               # log_det
         self._keep_fwd = (audio32, keep)
         return z, log_s_list, log_det_list
 
