@@ -184,6 +184,38 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
 #pragma unroll
         for (int n = 0; n < NWT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // RESSKIP on 128-row tiles (K = 512: a 13 us loop): the residual values the epilogue adds to are requested HERE, in front of
+    // the K loop, and ride out their latency under it.  Ablations (tools/res_gemm_study.sh) put 25 of the kernel's 38 us outside
+    // MFMA and fill: every CU reading, then writing, its 128 x 256 tile of x at the same moment (33 + 33 MB in one burst).  With the
+    // read half moved under the loop only the write burst is left.  64 VGPRs; 256-row tiles have no room for it.
+#ifdef T2S_NO_PREX
+    constexpr bool PREX = false;
+#else
+    constexpr bool PREX = EPI == EPI_RESSKIP && MT == 128;
+#endif
+    u16x4 pre_h[PREX ? MW : 1][PREX ? NWT : 1], pre_l[PREX ? MW : 1][PREX ? NWT : 1];
+    if constexpr (PREX) {
+        const int tcol_p = lane & 15, rq_p = (lane >> 4) * 4;
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            const int prow = mt * MT + wr * (MT / 2) + m * 16 + rq_p;
+            const bool is_res = prow < a.n_res && !a.res_init;
+            const int ch = prow < a.n_res ? prow : 0;
+            const size_t base = (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+#pragma unroll
+            for (int n = 0; n < NWT; ++n) {
+                const int t = t0 + wc * (NWT * 16) + n * 16 + tcol_p;
+                const size_t ro = base + (size_t)(t < a.L ? t : 0) * 32;
+                pre_h[m][n] = (u16x4){0, 0, 0, 0};
+                pre_l[m][n] = (u16x4){0, 0, 0, 0};
+                if (is_res) {
+                    pre_h[m][n] = *(const u16x4*)((a.R_hi ? a.R_hi : a.O_hi) + ro);
+                    pre_l[m][n] = *(const u16x4*)((a.R_lo ? a.R_lo : a.O_lo) + ro);
+                }
+            }
+        }
+    }
+
   if constexpr (EF) {
     const int nk = nk_split;
     const char *nbh = nullptr, *nbl = nullptr;
@@ -517,7 +549,10 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
                     ol[mi][n] = (u16x4){0, 0, 0, 0};
                     sv[mi][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     if (is_res) {
-                        if (!a.res_init) {
+                        if constexpr (PREX) {
+                            oh[mi][n] = pre_h[m0 + mi][n];
+                            ol[mi][n] = pre_l[m0 + mi][n];
+                        } else if (!a.res_init) {
                             oh[mi][n] = *(const u16x4*)((a.R_hi ? a.R_hi : a.O_hi) + ro);
                             ol[mi][n] = *(const u16x4*)((a.R_lo ? a.R_lo : a.O_lo) + ro);
                         }
