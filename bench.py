@@ -54,6 +54,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tacotron", action="store_true", help="skip the Tacotron mel-frames/s block (N=1 only)")
     ap.add_argument("--no-train", action="store_true", help="skip the train-step blocks")
+    ap.add_argument("--event-stride", type=int, default=7,
+                    help="time every n-th gate-GEMM launch with a HIP event pair inside the timed region (roofline.avg_launch_ms); "
+                         "1 = every launch, 0 = none (no roofline block).  7 is coprime with the 8 layers of a flow, so every layer / dilation "
+                         "is sampled; an event pair around EVERY launch costs 0.66 ms per forward (3.6 %), every 7th 0.1 ms")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward: the headline metric (default); train: value = zero_grad+forward+loss+backward+Adam, "
                          "data-parallel over RCCL when launched with N > 1 ranks (BASELINE configs[3])")
@@ -345,7 +349,8 @@ def main():
         for _ in range(args.warmup):
             step()
     torch.cuda.synchronize()
-    eng.gemm_events = [] if (rank == 0 and args.mode == "forward") else None
+    eng.gemm_events = [] if (rank == 0 and args.mode == "forward" and args.event_stride > 0) else None
+    eng.gemm_event_stride = max(1, args.event_stride)
     dt = max_over_ranks(run_steps(step, args.steps, 0, dist, args.mode == "train"))
     evs = eng.gemm_events or []
     eng.gemm_events = None
@@ -384,7 +389,10 @@ def main():
                                     "FETCH doubled per the gfx950 note, tools/pmc_traffic.py); algorithmic bytes are 83 MB read + "
                                     "33 MB written; the fetch side is fabric requests: 74 MB of activations once plus the 8.9 MB "
                                     "of packed weights once per XCD (8 private L2s)" % tsrc,
-                    "avg_launch_ms": avg_ms, "launches": len(ms), "algorithmic_flops_per_launch": flops_per_launch,
+                    "avg_launch_ms": avg_ms, "launches": len(ms),
+                    "launches_note": "HIP-event pairs around every %d-th of the %d gate-GEMM launches of the timed region"
+                                     % (max(1, args.event_stride), 8 * 12 * args.steps),
+                    "algorithmic_flops_per_launch": flops_per_launch,
                     "note": "split-bf16: 3 bf16 MFMA products per algorithmic MAC, so frac <= 1/3 by construction; in-kernel the "
                             "chip holds 1.85-1.95 GHz under this load (profiles/r02_summary.md), i.e. a 660 TFLOP/s ceiling for "
                             "this scheme, and the K loop runs at 91 % of MFMA-bound"}

@@ -139,6 +139,8 @@ class _Engine:
         self.use_fold = True        # no-grad forward / infer: WN.end folded into the skip path (t2s_wg_*_fold)
         self.grad_sync = None       # distributed.GradSync: bucketed RCCL all-reduce issued from inside backward
         self.gemm_events = None     # bench.py: list of (start, end) torch.cuda.Event pairs around the gate GEMM
+        self.gemm_event_stride = 1  # bench.py: time every n-th gate-GEMM launch (an event pair costs ~1.5 us of stream time)
+        self._gemm_launch_no = 0
 
     # ------------------------------------------------------------------ geometry
     def geom(self):
@@ -314,7 +316,9 @@ class _Engine:
                   C, L, w["Lp"], g["halo"], _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), st)
         for i in range(nl):
             ly = fl["layers"][i]
-            if self.gemm_events is not None:
+            timed = self.gemm_events is not None and self._gemm_launch_no % self.gemm_event_stride == 0
+            self._gemm_launch_no += 1
+            if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             if self.use_fold:
@@ -327,7 +331,7 @@ class _Engine:
                           _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), _lib.ptr(w["Sh"]), _lib.ptr(w["Sl"]),
                           _lib.ptr(w["Ah"]), _lib.ptr(w["Al"]), B, C, g["n_cond"], ks, 2 ** i, L, w["Lp"], g["halo"],
                           g["Mpad1"], st)
-            if self.gemm_events is not None:
+            if timed:
                 e1.record()
                 self.gemm_events.append((e0, e1))
             n_res = C if i < nl - 1 else 0
