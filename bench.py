@@ -57,7 +57,7 @@ def parse_args():
     ap.add_argument("--event-stride", type=int, default=7,
                     help="time every n-th gate-GEMM launch with a HIP event pair inside the timed region (roofline.avg_launch_ms); "
                          "1 = every launch, 0 = none (no roofline block).  7 is coprime with the 8 layers of a flow, so every layer / dilation "
-                         "is sampled; an event pair around EVERY launch costs 0.66 ms per forward (3.6 %), every 7th 0.1 ms")
+                         "is sampled; an event pair around EVERY launch costs 0.66 ms per forward (3.6 percent), every 7th 0.1 ms")
     ap.add_argument("--mode", choices=["forward", "train"], default="forward",
                     help="forward: the headline metric (default); train: value = zero_grad+forward+loss+backward+Adam, "
                          "data-parallel over RCCL when launched with N > 1 ranks (BASELINE configs[3])")
@@ -391,7 +391,7 @@ def main():
                                     "of packed weights once per XCD (8 private L2s)" % tsrc,
                     "avg_launch_ms": avg_ms, "launches": len(ms),
                     "launches_note": "HIP-event pairs around every %d-th of the %d gate-GEMM launches of the timed region"
-                                     % (max(1, args.event_stride), 8 * 12 * args.steps),
+                                     % (max(1, args.event_stride), wn["n_layers"] * cfg["n_flows"] * args.steps),
                     "algorithmic_flops_per_launch": flops_per_launch,
                     "note": "split-bf16: 3 bf16 MFMA products per algorithmic MAC, so frac <= 1/3 by construction; in-kernel the "
                             "chip holds 1.85-1.95 GHz under this load (profiles/r02_summary.md), i.e. a 660 TFLOP/s ceiling for "
