@@ -155,20 +155,30 @@ def tacotron_metrics(dev):
     m = m.to(dev).eval()
     out = {}
     ids = (torch.arange(64) % 78 + 2)[None].to(dev)
-    n = 400
-    m.decoder.gate_threshold, m.decoder.max_decoder_steps = 2.0, n
-    m.inference(ids, None)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
+    # BASELINE configs[4] front half: B=1, 64 symbols, 1000 forced frames.  A second length separates the decode step
+    # (slope) from the per-utterance work (intercept: encoder convolutions + BiLSTM, postnet, stop-flag syncs).
+    m.decoder.gate_threshold = 2.0
+    times = {}
+    for n in (200, 1000):
+        m.decoder.max_decoder_steps = n
         m.inference(ids, None)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 3
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            m.inference(ids, None)
+        torch.cuda.synchronize()
+        times[n] = (time.perf_counter() - t0) / 3
+    n = 1000
+    dt = times[n]
+    slope = (times[1000] - times[200]) / 800.0
     dec = m.decoder
     A, D, E, P = dec.attention_rnn_dim, dec.decoder_rnn_dim, dec.encoder_embedding_dim, dec.prenet_dim
     lstm_bytes = 4.0 * (4 * A * (P + E + A) + 4 * D * (A + E + D))          # f32 LSTMCell weights streamed per step
     out["inference_B1"] = {"mel_frames_per_s": n / dt, "us_per_step": dt / n * 1e6, "frames": n, "symbols": 64,
-                           "decoder": getattr(m._eng(), "decoder_kind", "launch chain")}
+                           "decoder": getattr(m._eng(), "decoder_kind", "launch chain"),
+                           "ms_200_frames": times[200] * 1e3, "ms_1000_frames": times[1000] * 1e3,
+                           "decode_us_per_step": slope * 1e6,
+                           "per_utterance_ms": (times[200] - 200 * slope) * 1e3}
     out["roofline"] = {"bound": "hbm", "kernel": "decoder step (2 LSTM cells + attention + projection)",
                        "achieved": lstm_bytes / (dt / n) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": lstm_bytes / (dt / n) / 1e9 / HBM_PEAK_GBS,
@@ -456,6 +466,25 @@ def main():
         if train_block is not None:
             out[train_key] = train_block
         if args.gpus == 1 and args.mode == "forward":
+            if not args.no_tacotron:
+                # the vocoder direction (BASELINE configs[4] back half): B = 1, reverse flow, weights packed once
+                try:
+                    inf = {}
+                    with torch.no_grad():
+                        for frames in (200, 1000):
+                            melv = torch.randn(1, cfg["n_mel_channels"], frames, generator=torch.Generator().manual_seed(frames)).to(dev)
+                            for _ in range(2):
+                                model.infer(melv, sigma=0.666)
+                            torch.cuda.synchronize()
+                            t0 = time.perf_counter()
+                            for _ in range(5):
+                                model.infer(melv, sigma=0.666)
+                            torch.cuda.synchronize()
+                            dti = (time.perf_counter() - t0) / 5
+                            inf["frames_%d" % frames] = {"ms": dti * 1e3, "audio_samples_per_s": frames * 256 / dti}
+                    out["waveglow_infer_B1"] = inf
+                except Exception as e:      # noqa: BLE001
+                    out["waveglow_infer_B1"] = {"error": "%s: %s" % (type(e).__name__, e)}
             del model, eng
             torch.cuda.empty_cache()
             if not args.no_tacotron:

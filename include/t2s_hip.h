@@ -138,8 +138,11 @@ typedef struct t2s_endfold_job {
 } t2s_endfold_job;
 /* jobs: DEVICE array, one per WN layer; run after the weight packing that produced `scale` */
 int t2s_wg_endfold_weights(const t2s_endfold_job* jobs, int n_jobs, int C, void* stream);
-/* t2s_wg_in_cond_gate plus fold_acc[slot][b][j][t] (+)= (W_end W_skip,i)[j] . acts[:, t] over the slot's 64 channels;
- * slot count = 2*ceil(C/128); C % 16 == 0 */
+/* t2s_wg_in_cond_gate plus fold_acc[slot][b][j][t] (+)= (W_end W_skip,i)[j] . acts[:, t] over the slot's channels; C % 16 == 0.
+ * fold_acc holds t2s_wg_gate_fold_slots(B, C, L) slots of [B][8][L] floats: 2*ceil(C/128) with the 256-row tiles, 2*ceil(C/64) when
+ * the shape takes 128-row tiles (a grid of 256-row tiles that would leave half of the CUs idle: short utterances at B = 1).
+ * t2s_wg_end_fold_affine takes the same count as `nslots`. */
+int t2s_wg_gate_fold_slots(int B, int C, int L);
 int t2s_wg_in_cond_gate_fold(const void* A_hi, const void* A_lo, const float* bias, const void* X_hi, const void* X_lo,
                              const void* S_hi, const void* S_lo, void* acts_hi, void* acts_lo, const void* fold_A,
                              float* fold_acc, int fold_init, int B, int C, int n_cond, int taps, int dilation, int L,

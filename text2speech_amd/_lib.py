@@ -37,6 +37,7 @@ SIGNATURES = {
                         c_int, c_int, c_vp],
     "t2s_wg_endfold_weights": [c_vp, c_int, c_int, c_vp],
     "t2s_wg_in_cond_gate_fold": [c_vp] * 11 + [c_int] * 10 + [c_vp],
+    "t2s_wg_gate_fold_slots": [c_int, c_int, c_int],
     "t2s_wg_res_only": [c_vp] * 7 + [c_int] * 6 + [c_vp],
     "t2s_wg_end_fold_affine": [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
     "t2s_wg_end_affine": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
     // ---- epilogue.  C/D map of mfma 16x16: col = lane&15 (time), row = 4*(lane>>4) + reg (channel) ----
     const int tcol = lane & 15;
     const int rq = (lane >> 4) * 4;
-    if (EPI == EPI_GATE && MT == 256) {
+    if (EPI == EPI_GATE) {
         // packed rows of this wave: m even = tanh rows, m odd = sigmoid rows of the same 16 channels.
         // WN.end folded in (a.fold_A): the 8 x C matrix (W_end W_skip,i) times this wave's 64 gate-output channels is
         // itself a small GEMM whose B operand is the gate output as it sits in the accumulator layout (col = time on
@@ -446,15 +446,17 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
 #pragma unroll
         for (int n = 0; n < NWT; ++n) facc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int pair = 0; pair < 2; ++pair) {
+        // MT = 256: a wave owns 128 packed rows = 64 channels = two 32-channel fold blocks; MT = 128 (small grids: twice the
+        // workgroups at half the tile): 64 packed rows = one block
+        for (int pair = 0; pair < MW / 4; ++pair) {
             u16x4 hv[2][NWT], lv[2][NWT];
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int mp = pair * 2 + half;
-                const int prow = mt * MT + wr * 128 + mp * 32 + rq;               // tanh rows prow..prow+3
+                const int prow = mt * MT + wr * (MT / 2) + mp * 32 + rq;          // tanh rows prow..prow+3
                 const f32x4 bt = *(const f32x4*)(a.bias + prow);
                 const f32x4 bs = *(const f32x4*)(a.bias + prow + 16);
-                const int ch = mt * 128 + wr * 64 + mp * 16 + rq;                  // channels ch..ch+3
+                const int ch = mt * (MT / 2) + wr * (MT / 4) + mp * 16 + rq;       // channels ch..ch+3
                 const bool chv = ch < a.C;
                 const size_t obase = (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
 #pragma unroll
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
                 }
             }
             if (a.fold_A) {
-                const u16* fa = a.fold_A + ((size_t)((mt * 2 + wr) * 2 + pair) * 2 * 64 + lane) * 8;
+                const u16* fa = a.fold_A + ((size_t)(mt * (MT / 64) + wr * (MT / 128) + pair) * 2 * 64 + lane) * 8;
                 const bf16x8 wh = *(const bf16x8*)fa;
                 const bf16x8 wl = *(const bf16x8*)(fa + 64 * 8);
 #pragma unroll
@@ -695,6 +697,7 @@ hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a_in, int epi, hipStream_t s
         if (epi == EPI_GATE_BWD && ns3) return launch_one<EPI_GATE_BWD, 128, 4, false, false, false, 3>(a, stream);
         if (epi == EPI_RESSKIP) return launch_one<EPI_RESSKIP, 128>(a, stream);
         if (epi == EPI_GATE_BWD) return launch_one<EPI_GATE_BWD, 128>(a, stream);
+        if (epi == EPI_GATE && a.ksplit <= 1 && a.k0 == 0 && a.kflat == 0) return launch_one<EPI_GATE, 128>(a, stream);
         return hipErrorInvalidValue;
     }
     // default gate GEMM: the ping-pong schedule (csrc/gate_gemm_pp.hip); T2S_GEMM_PP=0 falls back to the lockstep kernels below

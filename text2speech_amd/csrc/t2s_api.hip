@@ -2,6 +2,7 @@
 #include "../../include/t2s_hip.h"
 #include "t2s_kernels.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_hip_err[256] = "";
@@ -187,6 +188,20 @@ int t2s_wg_endfold_weights(const t2s_endfold_job* jobs, int n_jobs, int C, void*
     return T2S_OK;
 }
 
+// Gate GEMM tile height for a shape: 256-row tiles (the ping-pong kernel) unless they leave at least half of the chip's 256 CUs
+// without a workgroup - short utterances at B = 1 - where 128-row tiles give twice the workgroups at half the work each.
+static int gate_tile_rows(int B, int C, int L) {
+    static const int force = getenv("T2S_GATE_TILE") ? atoi(getenv("T2S_GATE_TILE")) : 0;      // 128 / 256: A/B switch
+    if (force == 128 || force == 256) return (force == 128 && C % 64 == 0) ? 128 : 256;
+    const long wg256 = (long)cdiv(C, 128) * cdiv(L, 256) * B;
+    return (wg256 <= 128 && C % 64 == 0) ? 128 : 256;
+}
+
+int t2s_wg_gate_fold_slots(int B, int C, int L) {
+    if (B <= 0 || C <= 0 || L <= 0) return T2S_EINVAL;
+    return gate_tile_rows(B, C, L) == 128 ? 2 * cdiv(C, 64) : 2 * cdiv(C, 128);
+}
+
 int t2s_wg_in_cond_gate_fold(const void* A_hi, const void* A_lo, const float* bias, const void* X_hi, const void* X_lo,
                              const void* S_hi, const void* S_lo, void* acts_hi, void* acts_lo, const void* fold_A,
                              float* fold_acc, int fold_init, int B, int C, int n_cond, int taps, int dilation, int L,
@@ -208,9 +223,10 @@ int t2s_wg_in_cond_gate_fold(const void* A_hi, const void* A_lo, const float* bi
     a.taps = taps; a.dil = dilation;
     a.nk_x = taps * a.xc; a.nk = a.nk_x + a.sc;
     a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
-    a.n_mtiles = cdiv(C, 128); a.n_ttiles = cdiv(L, 256);
+    const int rows = gate_tile_rows(B, C, L);          // fold_acc holds t2s_wg_gate_fold_slots(B, C, L) slots
+    a.n_mtiles = cdiv(C, rows / 2); a.n_ttiles = cdiv(L, 256);
     a.C = C;
-    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_GATE, (hipStream_t)stream));
+    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_GATE, (hipStream_t)stream, rows));
     return T2S_OK;
 }
 

@@ -282,7 +282,8 @@ class _Engine:
                      Ah=torch.zeros(B, xc, Lp, 32, **bf), Al=torch.zeros(B, xc, Lp, 32, **bf),
                      Sh=torch.zeros(B, sc, Lp, 32, **bf), Sl=torch.zeros(B, sc, Lp, 32, **bf),
                      skip=torch.zeros(B, xc, Lp, 32, dtype=torch.float32, device=device),
-                     fold_acc=torch.zeros(2 * (-(-g["C"] // 128)), B, 8, L, dtype=torch.float32, device=device))
+                     fold_acc=torch.zeros(_lib.load().t2s_wg_gate_fold_slots(B, g["C"], L), B, 8, L, dtype=torch.float32,
+                                          device=device))
             self.ws = {key: w}      # keep one shape resident
         return w
 
