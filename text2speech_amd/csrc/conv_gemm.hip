@@ -698,6 +698,10 @@ hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a_in, int epi, hipStream_t s
         if (epi == EPI_RESSKIP) return launch_one<EPI_RESSKIP, 128>(a, stream);
         if (epi == EPI_GATE_BWD) return launch_one<EPI_GATE_BWD, 128>(a, stream);
         if (epi == EPI_GATE && a.ksplit <= 1 && a.k0 == 0 && a.kflat == 0) return launch_one<EPI_GATE, 128>(a, stream);
+        // small grids (Tacotron encoder / postnet at B = 1: 2-8 workgroups walking 80 K-steps): each step is one exposed fill
+        // latency with two stages; three stages of the 48 KB tile keep two fills in flight
+        if (epi == EPI_BIAS_ACT && a.ksplit <= 1 && a.k0 == 0 && a.kflat == 0)
+            return launch_one<EPI_BIAS_ACT, 128, 4, false, false, false, 3>(a, stream);
         return hipErrorInvalidValue;
     }
     // default gate GEMM: the ping-pong schedule (csrc/gate_gemm_pp.hip); T2S_GEMM_PP=0 falls back to the lockstep kernels below

@@ -287,9 +287,12 @@ int t2s_conv_bias_act(const void* A_hi, const void* A_lo, const float* bias, con
     a.taps = taps; a.dil = dilation;
     a.nk_x = taps * a.xc; a.nk = a.nk_x;
     a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
-    a.n_mtiles = cdiv(Cout, 256); a.n_ttiles = cdiv(L, 256);
+    // a grid of at most 64 workgroups is latency-bound per K-step: 128-row tiles with three LDS stages (conv_gemm.hip)
+    static const int tile_env = getenv("T2S_CONV_TILE") ? atoi(getenv("T2S_CONV_TILE")) : 0;      // 128 / 256: A/B switch
+    const int rows = tile_env == 128 || tile_env == 256 ? tile_env : ((long)cdiv(Cout, 256) * cdiv(L, 256) * B <= 64 ? 128 : 256);
+    a.n_mtiles = cdiv(Cout, rows); a.n_ttiles = cdiv(L, 256);
     a.C = Cout; a.act = act; a.f32_cl = f32_channel_last;
-    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_BIAS_ACT, (hipStream_t)stream));
+    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_BIAS_ACT, (hipStream_t)stream, rows));
     return T2S_OK;
 }
 
