@@ -44,6 +44,42 @@ def test_waveglow_forward_odd_sizes(B, T, frames):
         assert abs(float(a) - float(b)) < 1e-3 * max(1.0, abs(float(b)))
 
 
+@pytest.mark.parametrize("B,frames,rows", [(8, 139, 256), (1, 139, 128)])
+def test_waveglow_gate_tile_heights(B, frames, rows):
+    """The folded gate GEMM picks its tile height from the grid: 256-row tiles (ping-pong kernel) when they give more than 128
+    workgroups, 128-row tiles (lockstep kernel) below - short utterances at B = 1.  Both against the oracle, forward and
+    inverse, at a length that is not a tile multiple."""
+    from oracle import waveglow_oracle as O
+    lib = _lib.load()
+    cfg = synth.WAVEGLOW_SMALL
+    C = cfg["WN_config"]["n_channels"]
+    T = 256 * (frames - 1)
+    L = T // cfg["n_group"]
+    slots = lib.t2s_wg_gate_fold_slots(B, C, L)
+    assert slots == (2 * -(-C // 128) if rows == 256 else 2 * -(-C // 64))
+    assert (-(-C // 128) * -(-L // 256) * B > 128) == (rows == 256)
+    m = _wg(cfg)
+    gen = torch.Generator().manual_seed(frames + B)
+    mel = torch.randn(B, 80, frames, generator=gen)
+    audio = torch.rand(B, T, generator=gen) - 0.5
+    with torch.no_grad():
+        z, log_s, _ = m((mel.to(DEV), audio.to(DEV)))
+        zo, lso, _ = O.waveglow_forward(synth.waveglow_state(cfg), cfg, mel, audio)
+        assert _rel(z, zo) < 1e-4
+        for a, b in zip(log_s, lso):
+            assert _rel(a, b) < 1e-3
+        # inverse direction through the same kernels: infer(sigma = 0) is deterministic
+        if rows == 128:
+            fr = 40
+            Li = 256 * fr // cfg["n_group"]
+            n_early = sum(1 for k in range(cfg["n_flows"]) if k % cfg["n_early_every"] == 0 and k > 0)
+            nf = torch.randn(B, cfg["n_group"] - n_early * cfg["n_early_size"], Li, generator=gen)
+            ne = [torch.randn(B, cfg["n_early_size"], Li, generator=gen) for _ in range(n_early)]
+            a_gpu = m.infer(mel[:, :, :fr].to(DEV), sigma=0.5, noise=(nf, ne))
+            a_cpu = O.waveglow_infer(synth.waveglow_state(cfg), cfg, mel[:, :, :fr], nf, ne, sigma=0.5)
+            assert _rel(a_gpu, a_cpu) < 1e-3
+
+
 def test_waveglow_rejects_short_mel():
     """reference glow.py:216 asserts the upsampled spectrogram covers the audio"""
     cfg = synth.WAVEGLOW_SMALL
