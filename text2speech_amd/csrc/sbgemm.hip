@@ -65,9 +65,10 @@ static __device__ __forceinline__ void sb_mma(const SbFrag& f, f32x4& acc0, f32x
         }
 }
 
+#ifdef T2S_SBGEMM_VGPR
 // One workgroup's 16 rows x 32 items; partial sums of the 8 waves end in s_part[wave][half][reg][lane].
 static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow, bool row_ok, int item_base,
-                                               float (*s_part)[2][4][64]) {
+                                               float (*s_part)[2][4][64], char*) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, item0 = item_base + (lane & 15);
     const int nsteps = o.K >> 4;
@@ -94,18 +95,137 @@ static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow,
     __syncthreads();
 }
 
+#else
+// Operand ring in LDS, filled by LDS-DMA (round 2).  The register ring above never had more than ~5 loads in flight per lane:
+// hipcc puts a branch and a `vmcnt(0)` around each conditional operand load (18 full waits for 82 loads), and both rewrites
+// with unconditional loads lost more to extra instructions than they won (profiles/r02_summary.md).  `global_load_lds` takes no
+// VGPRs and no compiler-inserted waits: every wave owns SB_R slots of 3 KB - the A, B0 and B1 fragments of one 16-wide K-step,
+// each exactly the 1 KB a wave-wide 16-byte DMA writes, in lane order, so the fragment read is a conflict-free ds_read_b128 at
+// lane * 16 - keeps SB_R - 1 K-steps (12 KB) in flight and waits with a counted vmcnt.  A wave fills and drains its own slots:
+// no workgroup barrier in the loop.  8 waves x 3 steps x 3 KB = 72 KB in flight per CU (96 KB of ring; the partial sums of the
+// cross-wave reduction reuse each wave's first slot).  Depth is not the limit: 4 / 5 / 6 slots measure 17.98 / 18.37 / 18.54 us -
+// the launch moves 126 MB from L2 into 256 CUs (every workgroup re-reads the 32 input vectors: 2/3 of the bytes) at 13 TB/s.  Ablations at 4096 x 2560, B = 32 (tools/microbench/sbgemm_bench.py): 18.3 us =
+// 7.2 launch + prologue + epilogue, + 9.5 fill (52 GB/s per CU), + 4.1 MFMA of which 2.5 hide under the fill.
+#ifndef SB_R_SLOTS
+#define SB_R_SLOTS 4
+#endif
+constexpr int SB_R = SB_R_SLOTS;
+constexpr int SB_SLOT = 3 * 1024;
+constexpr int SB_RING_BYTES = 8 * SB_R * SB_SLOT;
+
+static __device__ __forceinline__ void sb_glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow, bool row_ok, int item_base,
+                                               float (*s_part)[2][4][64], char* ring) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = lane >> 4, r16 = lane & 15;
+    const int nsteps = o.K >> 4;
+    const int s0 = (wave * nsteps) >> 3, s1 = ((wave + 1) * nsteps) >> 3;
+    // every DMA reads valid memory: rows / items past the end are clamped here and zeroed after the fragment read
+    const size_t growc = row_ok ? grow : 0;
+    const bool v0 = item_base + r16 < o.items, v1 = item_base + 16 + r16 < o.items;
+    const size_t it0 = v0 ? item_base + r16 : o.items - 1, it1 = v1 ? item_base + 16 + r16 : o.items - 1;
+    char* const my = ring + wave * (SB_R * SB_SLOT);
+    int slot_in = 0;                                        // slot the next issue fills (wave-uniform)
+    auto issue = [&](int st) {
+        const int k = st * 16;                              // wave-uniform: a K-step lies inside one operand segment
+        const float* wp = k < o.k1 ? o.W1 + growc * o.ld1 + k : o.W2 + growc * o.ld2 + (k - o.k1);
+        const float* xp;
+        long sx;
+        if (k < o.n0) { xp = o.x0 + k; sx = o.sx0; }
+        else if (k < o.n0 + o.n1) { xp = o.x1 + (k - o.n0); sx = o.sx1; }
+        else { xp = o.x2 + (k - o.n0 - o.n1); sx = o.sx2; }
+        char* dst = my + slot_in * SB_SLOT;
+        sb_glds16(wp + q * 4, dst);
+        sb_glds16(xp + q * 4 + it0 * sx, dst + 1024);
+        sb_glds16(xp + q * 4 + it1 * sx, dst + 2048);
+        slot_in = slot_in + 1 == SB_R ? 0 : slot_in + 1;
+    };
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    // Every workgroup reads the SAME input vectors; walking K in the same order they would all ask the same L2 channels for
+    // the same lines at the same moment.  Each workgroup starts its waves' ranges at its own rotation (SB_ROT).
+    const int nmine = s1 - s0;
+#ifdef T2S_SB_NO_ROT
+    const int rot = 0;
+#else
+    const int rot = nmine > 0 ? (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)nmine) : 0;
+#endif
+    auto step_of = [&](int i) { const int j = i + rot; return s0 + (j >= nmine ? j - nmine : j); };
+    int issued = 0;                                         // steps are counted 0 .. nmine - 1 in walking order
+#pragma unroll 1
+    for (int i = 0; i < SB_R - 1 && issued < nmine; ++i) issue(step_of(issued++));
+    int slot_out = 0;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int s = 0; s < nmine; ++s) {
+        // steps s .. issued - 1 are in flight; step s has landed once at most the issued - s - 1 newer ones are outstanding
+        if (issued - s == SB_R - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (SB_R - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the last SB_R - 2 steps of the range drain
+        const char* src = my + slot_out * SB_SLOT + lane * 16;
+        f32x4 fa = *(const f32x4*)src;
+        f32x4 fb0 = *(const f32x4*)(src + 1024);
+        f32x4 fb1 = *(const f32x4*)(src + 2048);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        slot_out = slot_out + 1 == SB_R ? 0 : slot_out + 1;
+        // the slot read in the PREVIOUS iteration is free (its reads were waited for there): refill it
+#if !defined(SB_ABL) || !(SB_ABL & 1)
+        if (issued < nmine) issue(step_of(issued++));
+#else
+        if (issued < nmine) issued++;                      // timing-only ablation: no fill after the prologue (results are wrong)
+#endif
+        if (!row_ok) fa = zero;
+        if (!v0) fb0 = zero;
+        if (!v1) fb1 = zero;
+#if !defined(SB_ABL) || !(SB_ABL & 2)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb0[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb1[j], acc1, 0, 0, 0);
+        }
+#else
+        asm volatile("" ::"v"(fa), "v"(fb0), "v"(fb1));    // timing-only ablation: no MFMA
+#endif
+    }
+    // this wave's slots are drained (every fragment read above was waited for): its partial sums go into its own first slot
+    float* part = (float*)my;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        part[(0 * 4 + r) * 64 + lane] = acc0[r];
+        part[(1 * 4 + r) * 64 + lane] = acc1[r];
+    }
+    __syncthreads();
+}
+#endif
+
 // tile row r (0..15) of item it (0..31 within the group): D[row][col]: lane = (row/4)*16 + col%16, reg = row%4, half = col/16
-static __device__ __forceinline__ float sb_sum(float (*s_part)[2][4][64], int r, int it) {
+#ifdef T2S_SBGEMM_VGPR
+static __device__ __forceinline__ float sb_sum(float (*s_part)[2][4][64], const char*, int r, int it) {
     const int ln = (r >> 2) * 16 + (it & 15), half = it >> 4, reg = r & 3;
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) s += s_part[w][half][reg][ln];
     return s;
 }
+#define SB_DECL_PART __shared__ float s_part[8][2][4][64];
+#else
+static __device__ __forceinline__ float sb_sum(float (*)[2][4][64], const char* ring, int r, int it) {
+    const int ln = (r >> 2) * 16 + (it & 15), half = it >> 4, reg = r & 3;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += ((const float*)(ring + w * (SB_R * SB_SLOT)))[(half * 4 + reg) * 64 + ln];
+    return s;
+}
+#define SB_DECL_PART float (*s_part)[2][4][64] = nullptr;
+#endif
 
 // ---- plain epilogue: GemvArgs semantics (no split_row / masks) -------------------------------------------------------
 __global__ __launch_bounds__(512) void sbgemm_plain_kernel(const GemvArgs a) {
-    __shared__ float s_part[8][2][4][64];
+    SB_DECL_PART
+    extern __shared__ __attribute__((aligned(16))) char sb_ring[];
     SbOperands o;
     o.W1 = a.W1; o.ld1 = a.ld1; o.k1 = a.k1; o.W2 = a.W2; o.ld2 = a.ld2;
     o.x0 = a.x1; o.x1 = a.x2; o.x2 = a.x3; o.n0 = a.n1; o.n1 = a.n2; o.n2 = a.n3;
@@ -113,11 +233,11 @@ __global__ __launch_bounds__(512) void sbgemm_plain_kernel(const GemvArgs a) {
     o.K = a.n1 + a.n2 + a.n3; o.items = a.items;
     const int row0 = blockIdx.x * 16, item_base = blockIdx.y * 32;
     const int lrow = row0 + (threadIdx.x & 15);
-    sb_core(o, (size_t)lrow, lrow < a.rows, item_base, s_part);
+    sb_core(o, (size_t)lrow, lrow < a.rows, item_base, s_part, sb_ring);
     const int r = threadIdx.x & 15, it = threadIdx.x >> 4;          // 512 threads = 16 rows x 32 items
     const int row = row0 + r, item = item_base + it;
     if (row < a.rows && item < a.items) {
-        float y = sb_sum(s_part, r, it) + (a.bias1 ? a.bias1[row] : 0.f) + (a.bias2 ? a.bias2[row] : 0.f);
+        float y = sb_sum(s_part, sb_ring, r, it) + (a.bias1 ? a.bias1[row] : 0.f) + (a.bias2 ? a.bias2[row] : 0.f);
         if (a.act == ACT_RELU) y = fmaxf(y, 0.f);
         else if (a.act == ACT_TANH) y = tanhf(y);
         a.y[(size_t)item * a.sy_item + (size_t)row * a.sy_row] = y;
@@ -138,14 +258,23 @@ bool t2s_sbgemm_plain_ok(const GemvArgs& a) {
 
 hipError_t t2s_launch_sbgemm_plain(const GemvArgs& a, hipStream_t stream) {
     dim3 grid((a.rows + 15) / 16, (a.items + 31) / 32);
-    hipLaunchKernelGGL(sbgemm_plain_kernel, grid, dim3(512), 0, stream, a);
+#ifdef T2S_SBGEMM_VGPR
+    constexpr int lds = 0;
+#else
+    constexpr int lds = SB_RING_BYTES;
+    static std::atomic<unsigned long long> attr_mask{0};
+    const hipError_t e = t2s_raise_lds_limit((const void*)sbgemm_plain_kernel, lds, attr_mask);
+    if (e != hipSuccess) return e;
+#endif
+    hipLaunchKernelGGL(sbgemm_plain_kernel, grid, dim3(512), lds, stream, a);
     return hipGetLastError();
 }
 
 // ---- fused LSTMCell epilogue: LstmCellArgs semantics ---------------------------------------------------------------
 // Workgroup = hidden units u0..u0+3; tile row r = unit*4 + gate  ->  weight row gate*H + u0 + unit.
 __global__ __launch_bounds__(512) void sbgemm_lstm_kernel(const LstmCellArgs a) {
-    __shared__ float s_part[8][2][4][64];
+    SB_DECL_PART
+    extern __shared__ __attribute__((aligned(16))) char sb_ring[];
     SbOperands o;
     const int K1 = a.n1 + a.n2;
     o.W1 = a.W_ih; o.ld1 = K1; o.k1 = K1; o.W2 = a.W_hh; o.ld2 = a.H;
@@ -154,7 +283,7 @@ __global__ __launch_bounds__(512) void sbgemm_lstm_kernel(const LstmCellArgs a) 
     o.K = K1 + a.H; o.items = a.B;
     const int u0 = blockIdx.x * 4, item_base = blockIdx.y * 32;
     const int lr = threadIdx.x & 15;
-    sb_core(o, (size_t)(lr & 3) * a.H + u0 + (lr >> 2), true, item_base, s_part);
+    sb_core(o, (size_t)(lr & 3) * a.H + u0 + (lr >> 2), true, item_base, s_part, sb_ring);
     if (threadIdx.x < 128) {
         const int ul = threadIdx.x & 3, it = threadIdx.x >> 2;
         const int item = item_base + it, u = u0 + ul;
@@ -162,7 +291,7 @@ __global__ __launch_bounds__(512) void sbgemm_lstm_kernel(const LstmCellArgs a) 
             float g[4];
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi)
-                g[gi] = sb_sum(s_part, ul * 4 + gi, it) + (a.b_ih[gi * a.H + u] + a.b_hh[gi * a.H + u]);
+                g[gi] = sb_sum(s_part, sb_ring, ul * 4 + gi, it) + (a.b_ih[gi * a.H + u] + a.b_hh[gi * a.H + u]);
             const size_t idx = (size_t)item * a.H + u;
             const float gi_ = sb_sigmoid(g[0]), gf = sb_sigmoid(g[1]), gg = tanhf(g[2]), go_ = sb_sigmoid(g[3]);
             const float c2 = gf * a.c[idx] + gi_ * gg;
@@ -192,6 +321,14 @@ bool t2s_sbgemm_lstm_ok(const LstmCellArgs& a) {
 
 hipError_t t2s_launch_sbgemm_lstm(const LstmCellArgs& a, hipStream_t stream) {
     dim3 grid(a.H / 4, (a.B + 31) / 32);
-    hipLaunchKernelGGL(sbgemm_lstm_kernel, grid, dim3(512), 0, stream, a);
+#ifdef T2S_SBGEMM_VGPR
+    constexpr int lds = 0;
+#else
+    constexpr int lds = SB_RING_BYTES;
+    static std::atomic<unsigned long long> attr_mask{0};
+    const hipError_t e = t2s_raise_lds_limit((const void*)sbgemm_lstm_kernel, lds, attr_mask);
+    if (e != hipSuccess) return e;
+#endif
+    hipLaunchKernelGGL(sbgemm_lstm_kernel, grid, dim3(512), lds, stream, a);
     return hipGetLastError();
 }
