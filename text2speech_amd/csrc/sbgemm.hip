@@ -26,6 +26,7 @@ struct SbOperands {
     int items;
 };
 
+#ifdef T2S_SBGEMM_VGPR      // round-1 operand path (register ring), kept for A/B builds
 struct SbFrag {
     f32x4 a[4], b0[4], b1[4];
 };
@@ -65,7 +66,6 @@ static __device__ __forceinline__ void sb_mma(const SbFrag& f, f32x4& acc0, f32x
         }
 }
 
-#ifdef T2S_SBGEMM_VGPR
 // One workgroup's 16 rows x 32 items; partial sums of the 8 waves end in s_part[wave][half][reg][lane].
 static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow, bool row_ok, int item_base,
                                                float (*s_part)[2][4][64], char*) {
