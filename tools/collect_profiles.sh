@@ -1,5 +1,5 @@
 #!/bin/bash
-# Reproduce the evidence under profiles/ on a 1-GPU MI355X box (run from the repo root; ~6 GPU-minutes).
+# Reproduce the evidence under profiles/ on a 1-GPU MI355X box (run from the repo root; ~8 GPU-minutes).
 # rocprofv3 7.2 writes a rocpd SQLite database; tools/rocpd_stats.py, tools/pmc_traffic.py and tools/pmc_counters.py turn
 # it into the tables / JSON that profiles/r02_summary.md quotes.  Counters are collected in their own passes (no trace
 # domains next to --pmc).  The program after `--` is always python3 itself (never env / bash -c: MI355X pool rule).
@@ -22,5 +22,8 @@ python3 tools/rocpd_stats.py "$OUT/taco_inf/ti_results.db" 1 14 > "$OUT/taco_inf
 python3 tools/rocpd_stats.py "$OUT/taco_train/tt_results.db" 4 16 > "$OUT/taco_train_kernels.md"
 python3 tools/pmc_traffic.py "$OUT/pmc_fetch/f_results.db" "$OUT/pmc_write/w_results.db" > "$OUT/pmc_traffic.json"
 rm -rf "$OUT"/fwd "$OUT"/train "$OUT"/taco_inf "$OUT"/taco_train "$OUT"/pmc_fetch "$OUT"/pmc_write     # databases are large
+python3 tools/bench_e2e.py > "$OUT/e2e.json" 2> /dev/null
+python3 tools/bench_infer_lengths.py > "$OUT/infer_lengths.json" 2> /dev/null
+python3 tools/microbench/sbgemm_bench.py > "$OUT/sbgemm_bench.json" 2> /dev/null
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "wrote $OUT"
