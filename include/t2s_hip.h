@@ -148,6 +148,26 @@ int t2s_wg_in_cond_gate_fold(const void* A_hi, const void* A_lo, const float* bi
                              float* fold_acc, int fold_init, int B, int C, int n_cond, int taps, int dilation, int L,
                              int Lp, int halo, int Mpad, void* stream);
 /* residual half only: x += W_res acts + b  (rows [0, C) of the packed res_skip weights; 128-row tiles) */
+/* Composed conditioning for the inverse flow (weights packed once).  The ConvTranspose upsampler is linear and only ksize / stride
+ * hops overlap, so cond_layers[i](upsample(mel)) at plane row t = P f + phi (P = stride / n_group) is (W_cond,i U_phi) applied to the
+ * mel window [mel(f), mel(f-1), ...] of K2 = (ksize / stride) * n_mel values: the conditioning half of the gate GEMM shrinks from
+ * n_mel * n_group to K2 columns (glow.py:159-162,215-221 / :252-258; 640 -> 320 at config.json defaults) and the upsampler goes away.
+ *  t2s_wg_upsample_basis: U as conditioning planes [1][n_mel*n_group/32][Lp][32] whose time axis is the column (phi, k), plus a last
+ *    column with the expanded bias; Lp = t2s_plane_rows(P * K2 + 1, halo).
+ *  (caller: t2s_conv_bias_act with A = the conditioning K-chunks of the packed gate weights, X = U, f32 output [2C][ld])
+ *  t2s_wg_compose_cond: that f32 result -> A2[phi][K2/32][Mpad][32] (hi, lo); bias_out = bias_in + its last column.
+ *  t2s_wg_melwin_planes: mel [B][n_mel][frames] -> M[B][K2/32][Fp][32], row f = the window of frame f (zeros outside the clip).
+ *  t2s_wg_in_melwin_gate_fold: t2s_wg_in_cond_gate_fold with (A2, M) in place of the conditioning weights and planes; always the
+ *    256-row tiles (fold_acc: 2*ceil(C/128) slots); Fp >= ceil(L / P). */
+int t2s_wg_upsample_basis(const float* W, const float* bias, int n_mel, int ksize, int stride, int n_group, int Lp, int halo,
+                          void* U_hi, void* U_lo, void* stream);
+int t2s_wg_compose_cond(const float* tmp, const float* bias_in, int rows, int Mpad, int P, int K2, long ld, void* A2_hi,
+                        void* A2_lo, float* bias_out, void* stream);
+int t2s_wg_melwin_planes(const float* mel, int B, int n_mel, int frames, int nlag, int Fp, void* M_hi, void* M_lo, void* stream);
+int t2s_wg_in_melwin_gate_fold(const void* A_hi, const void* A_lo, const void* A2_hi, const void* A2_lo, const float* bias,
+                               const void* X_hi, const void* X_lo, const void* M_hi, const void* M_lo, void* acts_hi,
+                               void* acts_lo, const void* fold_A, float* fold_acc, int fold_init, int B, int C, int K2,
+                               int taps, int dilation, int L, int Lp, int halo, int Mpad, int P, int Fp, void* stream);
 int t2s_wg_res_only(const void* A_hi, const void* A_lo, const float* bias, const void* acts_hi, const void* acts_lo,
                     void* X_hi, void* X_lo, int B, int C, int L, int Lp, int halo, int Mpad, void* stream);
 /* WN.end output from the folded accumulators + affine coupling (forward or reverse) */

@@ -90,7 +90,11 @@ __device__ unsigned long long t2s_pp_stamps[1024 * 8];
 #define PP_RSTAMP(i)
 #endif
 
-template <int ABL>
+// PH (phase mode, vocoder inference with composed conditioning weights): the 256 tile columns are 256 /
+// ph_FT batch entries x ph_FT mel frames of ONE phase phi = t mod ph_P of the hop (plane rows t = ph_P * f + phi, 2 KB apart);
+// the conditioning operand is the mel-window planes S[b][sc][ph_Fp][32] (row = frame) against the phase's composed weights
+// A2[phi][sc][Mpad][32].  Everything else - tile, schedule, epilogue arithmetic - is the kernel above.
+template <int ABL, bool PH>
 __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -108,20 +112,57 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int mt = logical % a.n_mtiles;
     const int tt_all = logical / a.n_mtiles;
-    const int b = tt_all / a.n_ttiles;
-    const int t0 = (tt_all % a.n_ttiles) * T2S_TILE_N;
+    int b, t0, phi = 0, ft = 0, bt = 0;
+    if constexpr (PH) {
+        phi = tt_all % a.ph_P;
+        const int r2 = tt_all / a.ph_P;
+        ft = r2 % a.ph_nft;
+        bt = r2 / a.ph_nft;
+        b = bt * a.ph_bper;
+        t0 = 0;
+    } else {
+        b = tt_all / a.n_ttiles;
+        t0 = (tt_all % a.n_ttiles) * T2S_TILE_N;
+    }
 
     // ---- DMA sources.  LDS slot p = tid (16 B each) of a half-plane: row = tid >> 2, k-chunk slot = tid & 3, which holds
     // logical chunk (tid & 3) ^ s[(row >> 2) & 3] (the swizzle lives on the SOURCE address and on the read address) ----
-    const int thr_off = (tid >> 2) * 64 + (((tid & 3) ^ pp_swz4((tid >> 4) & 3)) * 16);
+    const int inrow = ((tid & 3) ^ pp_swz4((tid >> 4) & 3)) * 16;
+    const int thr_off = (tid >> 2) * 64 + inrow;
     const size_t a_kstride = (size_t)a.Mpad * 64;
     const size_t x_cstride = (size_t)a.Lp * 64;
+    const size_t s_cstride = PH ? (size_t)a.ph_Fp * 64 : x_cstride;
     const char* const A_hi = (const char*)a.A_hi + (size_t)mt * 256 * 64 + thr_off;
     const char* const A_lo = (const char*)a.A_lo + (size_t)mt * 256 * 64 + thr_off;
-    const char* const X_hi = (const char*)a.X_hi + (((size_t)b * a.xc) * a.Lp + a.halo + t0) * 64 + thr_off;
-    const char* const X_lo = (const char*)a.X_lo + (((size_t)b * a.xc) * a.Lp + a.halo + t0) * 64 + thr_off;
-    const char* const S_hi = (const char*)a.S_hi + ((size_t)b * a.sc * a.Lp + a.halo + t0) * 64 + thr_off;
-    const char* const S_lo = (const char*)a.S_lo + ((size_t)b * a.sc * a.Lp + a.halo + t0) * 64 + thr_off;
+    // B sources: one (hi) base per 128-row half; the lo plane is a wave-uniform byte distance away
+    const long xlo_d = (const char*)a.X_lo - (const char*)a.X_hi;
+    const long slo_d = (const char*)a.S_lo - (const char*)a.S_hi;
+    const char* Xb[2];
+    const char* Sb[2];
+    long a2d_hi = 0, a2d_lo = 0;        // PH: byte distance from the packed in-layer weights to this phase's composed weights
+    if constexpr (PH) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rr = (tid >> 2) + h * 128;                  // tile column of this thread's DMA piece
+            const int bl = rr / a.ph_FT, fl = rr - bl * a.ph_FT;
+            int bb = b + bl;
+            bb = bb < a.B ? bb : a.B - 1;                         // columns past the batch / the utterance read valid rows;
+            const int f = ft * a.ph_FT + fl;                      // their results are never stored
+            int t = a.ph_P * f + phi;
+            t = t < a.L ? t : a.L - 1;
+            const int fm = f < a.ph_Fp ? f : a.ph_Fp - 1;
+            Xb[h] = (const char*)a.X_hi + (((size_t)bb * a.xc) * a.Lp + a.halo + t) * 64 + inrow;
+            Sb[h] = (const char*)a.S_hi + (((size_t)bb * a.sc) * a.ph_Fp + fm) * 64 + inrow;
+        }
+        const long ph_off = (long)phi * (long)a.sc * (long)a_kstride;
+        a2d_hi = ((const char*)a.A2_hi + ph_off) - (const char*)a.A_hi;
+        a2d_lo = ((const char*)a.A2_lo + ph_off) - (const char*)a.A_lo;
+    } else {
+        Xb[0] = (const char*)a.X_hi + (((size_t)b * a.xc) * a.Lp + a.halo + t0) * 64 + thr_off;
+        Sb[0] = (const char*)a.S_hi + ((size_t)b * a.sc * a.Lp + a.halo + t0) * 64 + thr_off;
+        Xb[1] = Xb[0] + PP_HALF;
+        Sb[1] = Sb[0] + PP_HALF;
+    }
     char* const lds_wave = smem + wave * 1024;            // + lane * 16 is implicit in the DMA
 
     const int nk = a.nk;
@@ -142,15 +183,15 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
             c.tap = a.taps;
             c.kc = ks - a.nk_x;
             c.in_s = true;
-            c.off = (long)c.kc * (long)x_cstride;
-            c.aoff = (long)ks * (long)a_kstride;
+            c.off = (long)c.kc * (long)s_cstride;
+            c.aoff = (long)(PH ? c.kc : ks) * (long)a_kstride;
         }
         return c;
     };
 #ifdef T2S_PP_TAP_MAJOR
     auto advance = [&](BCursor& c) {
         c.kc += 1;
-        c.off += (long)x_cstride;
+        c.off += c.in_s ? (long)s_cstride : (long)x_cstride;
         c.aoff += (long)a_kstride;
         if (!c.in_s && c.kc == a.xc) {
             c.kc = 0;
@@ -158,6 +199,7 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
             if (c.tap == a.taps) {
                 c.in_s = true;
                 c.off = 0;
+                if (PH) c.aoff = 0;
             } else {
                 c.off = (long)((c.tap - (a.taps >> 1)) * a.dil) * 64;
             }
@@ -169,7 +211,7 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
     auto advance = [&](BCursor& c) {
         if (c.in_s) {
             c.kc += 1;
-            c.off += (long)x_cstride;
+            c.off += (long)s_cstride;
             c.aoff += (long)a_kstride;
             return;
         }
@@ -186,22 +228,22 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
                 c.tap = a.taps;
                 c.kc = 0;
                 c.off = 0;
-                c.aoff = (long)a.nk_x * (long)a_kstride;
+                c.aoff = PH ? 0 : (long)a.nk_x * (long)a_kstride;
             }
         }
     };
 #endif
     auto stage_a = [&](int ks, const BCursor& c, int half) {
         char* dst = lds_wave + (ks & 1) * PP_BUF + half * PP_HALF;
-        const size_t off = (size_t)c.aoff + (size_t)half * PP_HALF;
-        pp_glds16(A_hi + off, dst);
-        pp_glds16(A_lo + off, dst + PP_PLANE);
+        const long off = c.aoff + (long)half * PP_HALF;
+        pp_glds16(A_hi + off + ((PH && c.in_s) ? a2d_hi : 0), dst);
+        pp_glds16(A_lo + off + ((PH && c.in_s) ? a2d_lo : 0), dst + PP_PLANE);
     };
     auto stage_b = [&](int ks, const BCursor& c, int half) {
         char* dst = lds_wave + (ks & 1) * PP_BUF + 2 * PP_PLANE + half * PP_HALF;
-        const long off = c.off + (long)half * PP_HALF;
-        pp_glds16((c.in_s ? S_hi : X_hi) + off, dst);
-        pp_glds16((c.in_s ? S_lo : X_lo) + off, dst + PP_PLANE);
+        const char* src = (c.in_s ? Sb[half] : Xb[half]) + c.off;
+        pp_glds16(src, dst);
+        pp_glds16(src + (c.in_s ? slo_d : xlo_d), dst + PP_PLANE);
     };
 
     // ---- per-lane fragment read offsets: row = lane & 15, logical k-chunk = lane >> 4 ----
@@ -362,6 +404,22 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
     // n-tile n covers tile columns (n >> 1) * 128 + wc * 32 + (n & 1) * 16.
     const int tcol = lane & 15;
     const int rq = (lane >> 4) * 4;
+    // column -> (batch entry, time step) of this lane's four n-tiles; cok = the column exists
+    int cb[4], ct[4];
+    bool cok[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int col = (n >> 1) * 128 + wc * 32 + (n & 1) * 16 + tcol;
+        if constexpr (PH) {
+            const int bl = col / a.ph_FT, fl = col - bl * a.ph_FT;
+            cb[n] = b + bl;
+            ct[n] = a.ph_P * (ft * a.ph_FT + fl) + phi;
+        } else {
+            cb[n] = b;
+            ct[n] = t0 + col;
+        }
+        cok[n] = cb[n] < a.B && ct[n] < a.L;
+    }
     // Everything the epilogue reads from memory is requested here in one batch (the fragment registers are free now): the 16
     // bias vectors, the folded-WN.end weights and - for layers after the first - the running fold sums this wave adds to.  One
     // memory round trip instead of a dependent one in front of each (pair, half) block and a read-modify-write at the very end.
@@ -388,10 +446,9 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
         const int slot = mt * 2 + wr;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            const int t = t0 + (n >> 1) * 128 + wc * 32 + (n & 1) * 16 + tcol;
-            const int tc = t < a.L ? t : 0;
+            const int tc = cok[n] ? ct[n] : 0, bc = cok[n] ? cb[n] : 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) facc[n][e] = a.fold_acc[(((size_t)slot * a.B + b) * 8 + rq + e) * a.L + tc];
+            for (int e = 0; e < 4; ++e) facc[n][e] = a.fold_acc[(((size_t)slot * a.B + bc) * 8 + rq + e) * a.L + tc];
         }
     }
 #pragma unroll
@@ -407,13 +464,12 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
             const f32x4 bt = bt_all[mp] * (2.0f * L2E), bs = bs_all[mp] * (-L2E);
             const int ch = mt * 128 + pair * 64 + wr * 32 + half * 16 + rq;             // channels ch..ch+3
             const bool chv = ch < a.C;
-            const size_t obase = (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+            const size_t obase = ((size_t)(ch >> 5) * a.Lp + a.halo) * 32 + (ch & 31);
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                const int t = t0 + (n >> 1) * 128 + wc * 32 + (n & 1) * 16 + tcol;
                 u16x4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
-                if (chv && t < a.L) {
-                    const size_t o = obase + (size_t)t * 32;
+                if (chv && cok[n]) {
+                    const size_t o = obase + ((size_t)cb[n] * a.oc * a.Lp + (size_t)ct[n]) * 32;
                     if (a.T_hi) {      // training: tanh and sigmoid are kept for the backward pass
                         u16x4 thi, tlo, ghi, glo;
 #pragma unroll
@@ -478,11 +534,10 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
         const int slot = mt * 2 + wr;
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            const int t = t0 + (n >> 1) * 128 + wc * 32 + (n & 1) * 16 + tcol;
-            if (t >= a.L) continue;
+            if (!cok[n]) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                a.fold_acc[(((size_t)slot * a.B + b) * 8 + rq + e) * a.L + t] = facc[n][e];
+                a.fold_acc[(((size_t)slot * a.B + cb[n]) * 8 + rq + e) * a.L + ct[n]] = facc[n][e];
             }
         }
     }
@@ -493,14 +548,14 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
     PP_RSTAMP(5)
 }
 
-template <int ABL>
+template <int ABL, bool PH = false>
 static hipError_t launch_pp(const ConvGemmArgs& a, hipStream_t stream) {
-    const int nwg = a.n_mtiles * a.n_ttiles * a.B;
+    const int nwg = PH ? a.n_mtiles * a.ph_P * a.ph_nft * ((a.B + a.ph_bper - 1) / a.ph_bper) : a.n_mtiles * a.n_ttiles * a.B;
     constexpr int lds = 2 * PP_BUF;
     static std::atomic<unsigned long long> attr_mask{0};
-    const hipError_t e = t2s_raise_lds_limit((const void*)gate_gemm_pp_kernel<ABL>, lds, attr_mask);
+    const hipError_t e = t2s_raise_lds_limit((const void*)gate_gemm_pp_kernel<ABL, PH>, lds, attr_mask);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(gate_gemm_pp_kernel<ABL>, dim3(nwg), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((gate_gemm_pp_kernel<ABL, PH>), dim3(nwg), dim3(512), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -524,5 +579,6 @@ hipError_t t2s_launch_gate_gemm_pp(const ConvGemmArgs& a, hipStream_t stream) {
         default: break;
     }
 #endif
+    if (a.ph_P > 0) return launch_pp<0, true>(a, stream);
     return launch_pp<0>(a, stream);
 }

@@ -230,6 +230,68 @@ int t2s_wg_in_cond_gate_fold(const void* A_hi, const void* A_lo, const float* bi
     return T2S_OK;
 }
 
+int t2s_wg_upsample_basis(const float* W, const float* bias, int n_mel, int ksize, int stride, int n_group, int Lp, int halo,
+                          void* U_hi, void* U_lo, void* stream) {
+    if (!W || !bias || !check_planes(U_hi, U_lo)) return T2S_EINVAL;
+    if (n_mel <= 0 || n_group <= 0 || stride <= 0 || ksize <= 0 || ksize % stride || stride % n_group) return T2S_EINVAL;
+    const int ncols = (stride / n_group) * (ksize / stride) * n_mel + 1;
+    if (halo < 0 || Lp != t2s_plane_rows(ncols, halo)) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_upbasis_planes(W, bias, n_mel, ksize, stride, n_group, Lp, halo, (u16*)U_hi, (u16*)U_lo,
+                                            (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_wg_compose_cond(const float* tmp, const float* bias_in, int rows, int Mpad, int P, int K2, long ld, void* A2_hi,
+                        void* A2_lo, float* bias_out, void* stream) {
+    if (!tmp || !bias_in || !bias_out || !check_planes(A2_hi, A2_lo)) return T2S_EINVAL;
+    if (rows <= 0 || Mpad % 256 || rows > Mpad || P <= 0 || K2 <= 0 || K2 % 32 || ld < (long)P * K2 + 1) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_compose_pack(tmp, bias_in, rows, Mpad, P, K2, (int)ld, (u16*)A2_hi, (u16*)A2_lo, bias_out,
+                                          (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_wg_melwin_planes(const float* mel, int B, int n_mel, int frames, int nlag, int Fp, void* M_hi, void* M_lo, void* stream) {
+    if (!mel || !check_planes(M_hi, M_lo)) return T2S_EINVAL;
+    if (B <= 0 || n_mel <= 0 || frames <= 0 || nlag <= 0 || Fp < frames) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_melwin_planes(mel, B, n_mel, frames, nlag, Fp, (u16*)M_hi, (u16*)M_lo, (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_wg_in_melwin_gate_fold(const void* A_hi, const void* A_lo, const void* A2_hi, const void* A2_lo, const float* bias,
+                               const void* X_hi, const void* X_lo, const void* M_hi, const void* M_lo, void* acts_hi,
+                               void* acts_lo, const void* fold_A, float* fold_acc, int fold_init, int B, int C, int K2,
+                               int taps, int dilation, int L, int Lp, int halo, int Mpad, int P, int Fp, void* stream) {
+    if (!check_planes(A_hi, A_lo) || !check_planes(A2_hi, A2_lo) || !check_planes(X_hi, X_lo) || !check_planes(M_hi, M_lo) ||
+        !check_planes(acts_hi, acts_lo) || !bias)
+        return T2S_EINVAL;
+    if (!fold_A || !fold_acc || !aligned16(fold_A) || C % 16) return T2S_EINVAL;
+    if (B <= 0 || L <= 0 || C <= 0 || C % 4 || taps <= 0 || !(taps & 1) || dilation <= 0 || K2 <= 0 || K2 % 32) return T2S_EINVAL;
+    if ((taps / 2) * dilation > halo || Lp != t2s_plane_rows(L, halo)) return T2S_EINVAL;
+    if (Mpad % 256 || Mpad < cdiv(C, 128) * 256 || !aligned16(bias) || P <= 0) return T2S_EINVAL;
+    const int F = cdiv(L, P);
+    if (Fp < F) return T2S_EINVAL;
+    ConvGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A_hi = (const u16*)A_hi; a.A_lo = (const u16*)A_lo;
+    a.A2_hi = (const u16*)A2_hi; a.A2_lo = (const u16*)A2_lo;
+    a.X_hi = (const u16*)X_hi; a.X_lo = (const u16*)X_lo;
+    a.S_hi = (const u16*)M_hi; a.S_lo = (const u16*)M_lo;
+    a.bias = bias; a.O_hi = (u16*)acts_hi; a.O_lo = (u16*)acts_lo;
+    a.fold_A = (const u16*)fold_A; a.fold_acc = fold_acc; a.fold_init = fold_init;
+    a.xc = cdiv(C, 32); a.sc = K2 / 32; a.oc = cdiv(C, 32);
+    a.taps = taps; a.dil = dilation;
+    a.nk_x = taps * a.xc; a.nk = a.nk_x + a.sc;
+    a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
+    a.n_mtiles = cdiv(C, 128); a.n_ttiles = 0;
+    a.C = C;
+    a.ph_P = P; a.ph_Fp = Fp;
+    a.ph_FT = F <= 64 ? 64 : (F <= 128 ? 128 : 256);
+    a.ph_bper = 256 / a.ph_FT;
+    a.ph_nft = cdiv(F, a.ph_FT);
+    T2S_CHECK_HIP(t2s_launch_gate_gemm_pp(a, (hipStream_t)stream));
+    return T2S_OK;
+}
+
 int t2s_wg_res_only(const void* A_hi, const void* A_lo, const float* bias, const void* acts_hi, const void* acts_lo,
                     void* X_hi, void* X_lo, int B, int C, int L, int Lp, int halo, int Mpad, void* stream) {
     if (!check_planes(A_hi, A_lo) || !check_planes(acts_hi, acts_lo) || !check_planes(X_hi, X_lo) || !bias) return T2S_EINVAL;

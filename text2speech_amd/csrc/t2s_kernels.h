@@ -50,6 +50,14 @@ struct ConvGemmArgs {
     const u16* fold_A;     // (W_end . W_skip_i) as MFMA A fragments [mt][wr][pair][hi,lo][lane][8] (endfold_weights_kernel)
     float* fold_acc;       // [2*n_mtiles][B][8][L]
     int fold_init;         // 1: store, 0: accumulate (first / later layers of a flow)
+    // gate GEMM, phase mode (vocoder inference with composed conditioning weights): ph_P > 0 selects it
+    const u16* A2_hi;      // composed conditioning weights [ph_P][sc][Mpad][32]
+    const u16* A2_lo;
+    int ph_P;              // phases = hop / n_group plane rows per mel frame
+    int ph_FT;             // frames per batch entry in a 256-column tile (64, 128 or 256)
+    int ph_bper;           // batch entries per tile = 256 / ph_FT
+    int ph_nft;            // frame tiles per batch entry
+    int ph_Fp;             // rows of the mel-window planes S[B][sc][ph_Fp][32]
     int dbg;               // timing-only ablations (env T2S_DBG_GEMM): 1 = no DMA in the K loop, 2 = no MFMA; results are wrong
 };
 
@@ -101,6 +109,12 @@ struct PackJob {               // mirrors t2s_pack_job in include/t2s_hip.h (all
 hipError_t t2s_launch_pack_table(const PackJob* jobs, int n_jobs, long total_rows, hipStream_t stream);
 hipError_t t2s_launch_weightnorm_small(const float* v, const float* g, int O, int K, float* w, hipStream_t stream);
 
+hipError_t t2s_launch_upbasis_planes(const float* W, const float* bias, int n_mel, int ksize, int stride, int n_group, int Lp,
+                                     int halo, u16* U_hi, u16* U_lo, hipStream_t stream);
+hipError_t t2s_launch_compose_pack(const float* tmp, const float* bias_in, int rows, int Mpad, int P, int K2, int ld, u16* A2_hi,
+                                   u16* A2_lo, float* bias_out, hipStream_t stream);
+hipError_t t2s_launch_melwin_planes(const float* mel, int B, int n_mel, int frames, int nlag, int Fp, u16* S_hi, u16* S_lo,
+                                    hipStream_t stream);
 hipError_t t2s_launch_upsample_squeeze(const float* mel, const float* W, const float* bias, int B, int n_mel,
                                        int frames, int ksize, int stride, int n_group, int L, int Lp, int halo,
                                        u16* S_hi, u16* S_lo, hipStream_t stream);

@@ -471,6 +471,131 @@ hipError_t t2s_launch_upsample_squeeze(const float* mel, const float* W, const f
 }
 
 // ------------------------------------------------------------------------------------------------
+// Composed conditioning (vocoder inference).  The upsampled spectrogram at plane row t = P * f + phi is
+//   spect[co * G + g][t] = bias[co] + sum_{ci, j} mel[ci][f - j] * W[ci][co][stride * j + G * phi + g],   j = 0 .. ksize / stride - 1,
+// a linear map U_phi of the mel WINDOW of frame f (K2 = nlag * n_mel values, k = j * n_mel + ci).  So
+//   cond_layers[i](spect)[:, t] = (W_cond,i U_phi) melwindow(f) + W_cond,i bias_expanded:
+// (1) upbasis_planes_kernel lays U out as ordinary conditioning planes whose "time" axis is the column (phi, k) - plus one last
+//     column holding the expanded bias - so that the existing 1x1 GEMM (t2s_conv_bias_act on the conditioning slice of the packed
+//     gate weights) produces W_cond,i U for all phases at once, in packed row order;
+// (2) compose_pack_kernel splits that f32 result into the A-operand planes A2[phi][k / 32][row][k % 32] and folds the last column
+//     into the layer's bias;
+// (3) melwin_planes_kernel builds the mel-window planes M[b][k / 32][f][k % 32] per utterance (160 KB of mel -> 0.6 MB).
+__global__ __launch_bounds__(256) void upbasis_planes_kernel(const float* __restrict__ W, const float* __restrict__ bias, int M,
+                                                             int ksize, int stride, int G, int P, int K2, int Lp, int halo,
+                                                             u16* U_hi, u16* U_lo) {
+    const int q = threadIdx.x & 3;
+    const int col = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int chunk = blockIdx.y;
+    const int ncols = P * K2 + 1;
+    if (col >= ncols) return;
+    const int c8 = chunk * 32 + q * 8;
+    u16 hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c8 + e;
+        float v = 0.f;
+        if (c < M * G) {
+            const int co = c / G, g = c - co * G;
+            if (col == ncols - 1) {
+                v = bias[co];
+            } else {
+                const int phi = col / K2, k = col - phi * K2;
+                const int j = k / M, ci = k - j * M;
+                v = W[((size_t)ci * M + co) * ksize + (size_t)stride * j + G * phi + g];
+            }
+        }
+        split_bf16(v, hi[e], lo[e]);
+    }
+    const size_t row = ((size_t)chunk * Lp + halo + col) * 32 + q * 8;
+    uint4 ph, pl;
+    ph.x = hi[0] | ((uint32_t)hi[1] << 16); ph.y = hi[2] | ((uint32_t)hi[3] << 16);
+    ph.z = hi[4] | ((uint32_t)hi[5] << 16); ph.w = hi[6] | ((uint32_t)hi[7] << 16);
+    pl.x = lo[0] | ((uint32_t)lo[1] << 16); pl.y = lo[2] | ((uint32_t)lo[3] << 16);
+    pl.z = lo[4] | ((uint32_t)lo[5] << 16); pl.w = lo[6] | ((uint32_t)lo[7] << 16);
+    *(uint4*)(U_hi + row) = ph;
+    *(uint4*)(U_lo + row) = pl;
+}
+hipError_t t2s_launch_upbasis_planes(const float* W, const float* bias, int n_mel, int ksize, int stride, int n_group, int Lp,
+                                     int halo, u16* U_hi, u16* U_lo, hipStream_t stream) {
+    const int P = stride / n_group, K2 = (ksize / stride) * n_mel;
+    const int ncols = P * K2 + 1;
+    dim3 grid((ncols + 63) / 64, (n_mel * n_group + 31) / 32);
+    hipLaunchKernelGGL(upbasis_planes_kernel, grid, dim3(256), 0, stream, W, bias, n_mel, ksize, stride, n_group, P, K2, Lp, halo,
+                       U_hi, U_lo);
+    return hipGetLastError();
+}
+
+// tmp [rows][ncols] f32 (row = packed gate row) -> A2[phi][kc][Mpad][32] (hi, lo), bias_out[row] = bias_in[row] + tmp[row][P * K2]
+__global__ __launch_bounds__(256) void compose_pack_kernel(const float* __restrict__ tmp, const float* __restrict__ bias_in,
+                                                           int rows, int Mpad, int P, int K2, int ld, u16* A2_hi, u16* A2_lo,
+                                                           float* bias_out) {
+    const int q = threadIdx.x & 3;
+    const int m = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int kc = blockIdx.y, phi = blockIdx.z;
+    if (m >= Mpad) return;
+    u16 hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = kc * 32 + q * 8 + e;
+        const float v = (m < rows && k < K2) ? tmp[(size_t)m * ld + (size_t)phi * K2 + k] : 0.f;
+        split_bf16(v, hi[e], lo[e]);
+    }
+    const int mc = (K2 + 31) / 32;
+    const size_t o = ((((size_t)phi * mc + kc) * Mpad) + m) * 32 + q * 8;
+    uint4 ph, pl;
+    ph.x = hi[0] | ((uint32_t)hi[1] << 16); ph.y = hi[2] | ((uint32_t)hi[3] << 16);
+    ph.z = hi[4] | ((uint32_t)hi[5] << 16); ph.w = hi[6] | ((uint32_t)hi[7] << 16);
+    pl.x = lo[0] | ((uint32_t)lo[1] << 16); pl.y = lo[2] | ((uint32_t)lo[3] << 16);
+    pl.z = lo[4] | ((uint32_t)lo[5] << 16); pl.w = lo[6] | ((uint32_t)lo[7] << 16);
+    *(uint4*)(A2_hi + o) = ph;
+    *(uint4*)(A2_lo + o) = pl;
+    if (kc == 0 && phi == 0 && q == 0) bias_out[m] = bias_in[m] + (m < rows ? tmp[(size_t)m * ld + (size_t)P * K2] : 0.f);
+}
+hipError_t t2s_launch_compose_pack(const float* tmp, const float* bias_in, int rows, int Mpad, int P, int K2, int ld, u16* A2_hi,
+                                   u16* A2_lo, float* bias_out, hipStream_t stream) {
+    dim3 grid((Mpad + 63) / 64, (K2 + 31) / 32, P);
+    hipLaunchKernelGGL(compose_pack_kernel, grid, dim3(256), 0, stream, tmp, bias_in, rows, Mpad, P, K2, ld, A2_hi, A2_lo, bias_out);
+    return hipGetLastError();
+}
+
+// mel [B][M][F] f32 -> mel-window planes S[b][k / 32][f][k % 32], k = j * M + ci  ->  mel[b][ci][f - j] (0 outside [0, F))
+__global__ __launch_bounds__(256) void melwin_planes_kernel(const float* __restrict__ mel, int M, int F, int nlag, int Fp,
+                                                            u16* S_hi, u16* S_lo) {
+    const int q = threadIdx.x & 3;
+    const int f = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int chunk = blockIdx.y, b = blockIdx.z;
+    if (f >= Fp) return;
+    const int K2 = nlag * M, mc = (K2 + 31) / 32;
+    u16 hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = chunk * 32 + q * 8 + e;
+        float v = 0.f;
+        if (k < K2) {
+            const int j = k / M, ci = k - j * M;
+            const int ff = f - j;
+            if (ff >= 0 && ff < F) v = mel[((size_t)b * M + ci) * F + ff];
+        }
+        split_bf16(v, hi[e], lo[e]);
+    }
+    const size_t o = (((size_t)b * mc + chunk) * Fp + f) * 32 + q * 8;
+    uint4 ph, pl;
+    ph.x = hi[0] | ((uint32_t)hi[1] << 16); ph.y = hi[2] | ((uint32_t)hi[3] << 16);
+    ph.z = hi[4] | ((uint32_t)hi[5] << 16); ph.w = hi[6] | ((uint32_t)hi[7] << 16);
+    pl.x = lo[0] | ((uint32_t)lo[1] << 16); pl.y = lo[2] | ((uint32_t)lo[3] << 16);
+    pl.z = lo[4] | ((uint32_t)lo[5] << 16); pl.w = lo[6] | ((uint32_t)lo[7] << 16);
+    *(uint4*)(S_hi + o) = ph;
+    *(uint4*)(S_lo + o) = pl;
+}
+hipError_t t2s_launch_melwin_planes(const float* mel, int B, int n_mel, int frames, int nlag, int Fp, u16* S_hi, u16* S_lo,
+                                    hipStream_t stream) {
+    dim3 grid((Fp + 63) / 64, (nlag * n_mel + 31) / 32, B);
+    hipLaunchKernelGGL(melwin_planes_kernel, grid, dim3(256), 0, stream, mel, n_mel, frames, nlag, Fp, S_hi, S_lo);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // audio [B][T] <-> z [B][G][L], z[b][g][t] = audio[b][G*t + g]  (reference glow.py:223 / 291)
 __global__ void audio_squeeze_kernel(const float* audio, float* z, int B, int T, int G, int L, int unsq) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

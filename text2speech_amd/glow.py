@@ -268,6 +268,55 @@ class _Engine:
         self._keep = keep
         return self.packed
 
+    # ------------------------------------------------------------------ composed conditioning (inverse flow)
+    def compose_geom(self):
+        """(P, nlag, K2) when the conditioning path can be composed with the upsampler, else None."""
+        m, g = self.m, self.geom()
+        up = m.upsample
+        ksz, stride, G = up.kernel_size[0], up.stride[0], m.n_group
+        if os.environ.get("T2S_COND_COMPOSE") == "0" or not self.use_fold:
+            return None
+        if ksz % stride or stride % G or ((ksz // stride) * up.in_channels) % 32 or g["C"] % 16:
+            return None
+        return stride // G, ksz // stride, (ksz // stride) * up.in_channels
+
+    def compose_cond(self, device):
+        """(W_cond,i . U_phi) for every layer and phase as A-operand planes, and the biases with the upsampler's bias folded in.
+        Built from the packed weights, so it is keyed like them; 42 MB per layer at config.json defaults (4 GB: sized for 288 GB)."""
+        if self.packed.get("compose_key") == self.packed_key:
+            return
+        m, g = self.m, self.geom()
+        P, nlag, K2 = self.compose_geom()
+        C, nl, ks = g["C"], g["nl"], g["ks"]
+        up = m.upsample
+        st = _lib.current_stream()
+        ncols = P * K2 + 1
+        Lp_u = _lib.plane_rows(ncols, 0)
+        sc = g["Spad"] // 32
+        bf = dict(dtype=torch.bfloat16, device=device)
+        U_h, U_l = torch.zeros(1, sc, Lp_u, 32, **bf), torch.zeros(1, sc, Lp_u, 32, **bf)
+        W, bias = _f32c(up.weight), _f32c(up.bias)
+        _lib.call("t2s_wg_upsample_basis", _lib.ptr(W), _lib.ptr(bias), up.in_channels, up.kernel_size[0], up.stride[0],
+                  m.n_group, Lp_u, 0, _lib.ptr(U_h), _lib.ptr(U_l), st)
+        tmp = torch.empty(2 * C, ncols, dtype=torch.float32, device=device)
+        zb = torch.zeros(g["Mpad1"], dtype=torch.float32, device=device)
+        cond_off = (ks * g["Cpad"] // 32) * g["Mpad1"] * 32 * 2          # bytes: the conditioning K-chunks of the packed gate weights
+        mc = K2 // 32
+        for k in range(m.n_flows):
+            for i in range(nl):
+                ly = self.packed["flows"][k]["layers"][i]
+                if "Ach" not in ly:
+                    ly["Ach"] = torch.zeros(P, mc, g["Mpad1"], 32, **bf)
+                    ly["Acl"] = torch.zeros(P, mc, g["Mpad1"], 32, **bf)
+                    ly["b1c"] = torch.zeros(g["Mpad1"], dtype=torch.float32, device=device)
+                _lib.call("t2s_conv_bias_act", _lib.c_vp(ly["A1h"].data_ptr() + cond_off), _lib.c_vp(ly["A1l"].data_ptr() + cond_off),
+                          _lib.ptr(zb), _lib.ptr(U_h), _lib.ptr(U_l), None, None, _lib.ptr(tmp), 0, 1, g["n_cond"], 2 * C, 1, 1, 0,
+                          ncols, Lp_u, 0, g["Mpad1"], st)
+                _lib.call("t2s_wg_compose_cond", _lib.ptr(tmp), _lib.ptr(ly["b1"]), 2 * C, g["Mpad1"], P, K2, ncols,
+                          _lib.ptr(ly["Ach"]), _lib.ptr(ly["Acl"]), _lib.ptr(ly["b1c"]), st)
+        self._keep_compose = (U_h, U_l, tmp, zb, W, bias)
+        self.packed["compose_key"] = self.packed_key
+
     # ------------------------------------------------------------------ workspaces
     def workspace(self, B, L, device):
         key = (B, L, str(device))
@@ -304,8 +353,9 @@ class _Engine:
                   _lib.ptr(w["Sh"]), _lib.ptr(w["Sl"]), _lib.current_stream())
         self._keep_up = (mel32, W, bias)
 
-    def _wn(self, k, z, B, L, w, c_off, n_half):
-        """start -> n_layers x (in+cond+gate, res/skip); leaves the skip sum in w['skip']."""
+    def _wn(self, k, z, B, L, w, c_off, n_half, ph=None):
+        """start -> n_layers x (in+cond+gate, res/skip); leaves the skip sum in w['skip'].  ph = (M_hi, M_lo, Fp, P, K2):
+        conditioning through the composed weights and the mel-window planes (inverse flow)."""
         m, g = self.m, self.geom()
         C, nl, ks = g["C"], g["nl"], g["ks"]
         fl = self.packed["flows"][k]
@@ -322,7 +372,13 @@ class _Engine:
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            if self.use_fold:
+            if ph is not None:
+                Mh, Ml, Fp, P, K2 = ph
+                _lib.call("t2s_wg_in_melwin_gate_fold", _lib.ptr(ly["A1h"]), _lib.ptr(ly["A1l"]), _lib.ptr(ly["Ach"]),
+                          _lib.ptr(ly["Acl"]), _lib.ptr(ly["b1c"]), _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), _lib.ptr(Mh), _lib.ptr(Ml),
+                          _lib.ptr(w["Ah"]), _lib.ptr(w["Al"]), _lib.ptr(ly["fold_A"]), _lib.ptr(w["fold_acc"]),
+                          1 if i == 0 else 0, B, C, K2, ks, 2 ** i, L, w["Lp"], g["halo"], g["Mpad1"], P, Fp, st)
+            elif self.use_fold:
                 _lib.call("t2s_wg_in_cond_gate_fold", _lib.ptr(ly["A1h"]), _lib.ptr(ly["A1l"]), _lib.ptr(ly["b1"]),
                           _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), _lib.ptr(w["Sh"]), _lib.ptr(w["Sl"]),
                           _lib.ptr(w["Ah"]), _lib.ptr(w["Al"]), _lib.ptr(ly["fold_A"]), _lib.ptr(w["fold_acc"]),
@@ -451,7 +507,27 @@ class _Engine:
         self.pack_weights(dev, force=False)
         w = self.workspace(B, L, dev)
         st = _lib.current_stream()
-        self._upsample(mel, B, L, w)
+        # Weights are packed once here, so the conditioning path can be composed with the upsampler (K = 640 -> 320 in the gate
+        # GEMM, no upsampler launch) - wherever the grid is large enough for the 256-row ping-pong tiles anyway
+        cg = self.compose_geom()
+        C = self.geom()["C"]
+        ph = None
+        if cg is not None and -(-C // 128) * -(-L // 256) * B > 128:
+            P, nlag, K2 = cg
+            self.compose_cond(dev)
+            Fp = -(-frames // 256) * 256
+            key = ("melwin", B, Fp, str(dev))
+            mw = self.ws.get(key)
+            if mw is None:
+                mw = (torch.zeros(B, K2 // 32, Fp, 32, dtype=torch.bfloat16, device=dev),
+                      torch.zeros(B, K2 // 32, Fp, 32, dtype=torch.bfloat16, device=dev))
+                self.ws[key] = mw
+            mel32 = _f32c(mel)
+            _lib.call("t2s_wg_melwin_planes", _lib.ptr(mel32), B, mel32.size(1), frames, nlag, Fp, _lib.ptr(mw[0]), _lib.ptr(mw[1]), st)
+            self._keep_up = (mel32,)
+            ph = (mw[0], mw[1], Fp, P, K2)
+        else:
+            self._upsample(mel, B, L, w)
         # All Gaussian draws of glow.py:260-267,284-289 live in one [B, G, L] buffer: the final
         # n_remaining channels, and in front of them the n_early_size channels re-attached at each early flow.
         z = torch.empty(B, G, L, dtype=torch.float32, device=dev)
@@ -474,7 +550,7 @@ class _Engine:
                 fl["w_inv"] = torch.empty(n_rem, n_rem, dtype=torch.float32, device=dev)
                 _lib.call("t2s_small_logdet_inv", _lib.ptr(Wk), n_rem, 1.0, None, _lib.ptr(fl["w_inv"]), st)
                 fl["_Wk"] = Wk
-            self._wn(k, z, B, L, w, c_off, n_half)
+            self._wn(k, z, B, L, w, c_off, n_half, ph=ph)
             self._end(k, z, None, B, L, w, c_off, n_half, reverse=True)
             _lib.call("t2s_wg_convinv", _lib.ptr(z), _lib.ptr(fl["w_inv"]), B, G, c_off, n_rem, L, st)
         audio = torch.empty(B, L * G, dtype=torch.float32, device=dev)
