@@ -82,30 +82,28 @@ def test_waveglow_gate_tile_heights(B, frames, rows):
 
 @pytest.mark.parametrize("B,frames", [(4, 264), (1, 1100)])
 def test_waveglow_infer_composed_conditioning(B, frames, monkeypatch):
-    """Inverse flow with the conditioning layers composed with the upsampler (K = 640 -> 320 in the gate GEMM, phase-major column
-    tiles, mel-window planes): against the oracle and against the uncomposed kernels, batch entries and frame counts that do not
-    fill the 256-column tiles."""
-    from oracle import waveglow_oracle as O
+    """Inverse flow with the conditioning layers composed with the upsampler (opt-in T2S_COND_COMPOSE=1: K = 640 -> 320 in the gate
+    GEMM, phase-major column tiles, mel-window planes) against the default kernels on the same inputs - which the golden and oracle
+    tests pin - at batch entries and frame counts that do not fill the 256-column tiles."""
     _lib.load()
     cfg = synth.WAVEGLOW_SMALL
     m = _wg(cfg)
     eng = m._eng()
-    assert eng.compose_geom() == (32, 4, 320)
     gen = torch.Generator().manual_seed(frames)
     mel = torch.randn(B, 80, frames, generator=gen)
     Li = 256 * frames // cfg["n_group"]
     n_early = sum(1 for k in range(cfg["n_flows"]) if k % cfg["n_early_every"] == 0 and k > 0)
     nf = torch.randn(B, cfg["n_group"] - n_early * cfg["n_early_size"], Li, generator=gen)
     ne = [torch.randn(B, cfg["n_early_size"], Li, generator=gen) for _ in range(n_early)]
+    assert eng.compose_geom() is None
+    a_plain = m.infer(mel.to(DEV), sigma=0.6, noise=(nf, ne))
+    assert eng.packed.get("compose_key") is None
+    monkeypatch.setenv("T2S_COND_COMPOSE", "1")
+    assert eng.compose_geom() == (32, 4, 320)
     a_comp = m.infer(mel.to(DEV), sigma=0.6, noise=(nf, ne))
     assert eng.packed.get("compose_key") is not None, "the composed path did not run"
-    monkeypatch.setenv("T2S_COND_COMPOSE", "0")
-    a_plain = m.infer(mel.to(DEV), sigma=0.6, noise=(nf, ne))
-    monkeypatch.delenv("T2S_COND_COMPOSE")
+    assert bool(torch.isfinite(a_comp).all())
     assert _rel(a_comp, a_plain) < 2e-5
-    a_cpu = O.waveglow_infer(synth.waveglow_state(cfg), cfg, mel, nf, ne, sigma=0.6)
-    assert _rel(a_comp, a_cpu) < 1e-3
-    assert _rel(a_plain, a_cpu) < 1e-3
 
 
 def test_waveglow_rejects_short_mel():
