@@ -40,6 +40,11 @@ def test_pure_host_entry_points(lib):
     assert lib.t2s_padded_rows(1024) == 1024 and lib.t2s_padded_rows(130) == 256
     assert lib.t2s_error_string(0) == b"ok"
     assert lib.t2s_error_string(-1) == b"invalid argument"
+    # gate-GEMM tile height by grid size: 256-row tiles above 128 workgroups, 128-row tiles (twice the fold slots) below
+    assert lib.t2s_wg_gate_fold_slots(8, 512, 2000) == 8          # 4 x 8 x 8 = 256 workgroups of 256-row tiles
+    assert lib.t2s_wg_gate_fold_slots(1, 512, 6400) == 16         # 4 x 25 = 100 workgroups -> 128-row tiles
+    assert lib.t2s_wg_gate_fold_slots(1, 512, 32000) == 8
+    assert lib.t2s_wg_gate_fold_slots(0, 512, 10) == -1
 
 
 def test_argument_validation_without_gpu(lib):
@@ -47,3 +52,21 @@ def test_argument_validation_without_gpu(lib):
     assert lib.t2s_wg_convinv(None, None, 1, 8, 0, 8, 10, None) == -1
     assert lib.t2s_small_logdet_inv(None, 4, 1.0, None, None, None) == -1
     assert lib.t2s_pack_conv_weight(None, None, 0, None, 4, 4, 1, 0, 0, 0, 256, 0, 32, None, None, None, 0, None) == -1
+    assert lib.t2s_wg_melwin_planes(None, 1, 80, 10, 4, 256, None, None, None) == -1
+    assert lib.t2s_wg_upsample_basis(None, None, 80, 1024, 256, 8, 0, 0, None, None, None) == -1
+    assert lib.t2s_wg_compose_cond(None, None, 1024, 1024, 32, 320, 10241, None, None, None, None) == -1
+
+
+def test_composed_conditioning_is_opt_in(monkeypatch):
+    """Host logic of the inverse flow's composed-conditioning path: off unless T2S_COND_COMPOSE=1, and
+    only for geometries where the upsampler's hop is a whole number of plane rows and the mel window fills whole 32-channel chunks."""
+    from text2speech_amd import synth
+    from text2speech_amd.glow import WaveGlow
+    m = WaveGlow(**synth.WAVEGLOW_SMALL)
+    eng = m._eng()
+    monkeypatch.delenv("T2S_COND_COMPOSE", raising=False)
+    assert eng.compose_geom() is None
+    monkeypatch.setenv("T2S_COND_COMPOSE", "1")
+    assert eng.compose_geom() == (32, 4, 320)          # hop 256 / n_group 8 phases, 1024 / 256 lags, 4 x 80 window channels
+    monkeypatch.setenv("T2S_COND_COMPOSE", "0")
+    assert eng.compose_geom() is None
