@@ -285,8 +285,9 @@ int t2s_taco_stop_check(const float* mel_gate_out, int B, int n_mel, int T_cap, 
  * whose contraction index is time.
  */
 
-/* training-mode forms of the two WN-layer entry points: also save tanh / sigmoid (T, G planes) for the
- * backward pass, and read the residual from R planes so every layer's input stays resident */
+/* training-mode forms of the two WN-layer entry points: also save the sigmoid values (G planes; the tanh planes T are optional,
+ * pass NULL: the backward pass rebuilds tanh as acts / sigmoid) for the backward pass, and read the residual from R planes so
+ * every layer's input stays resident */
 int t2s_wg_in_cond_gate_train(const void* A_hi, const void* A_lo, const float* bias, const void* X_hi, const void* X_lo,
                               const void* S_hi, const void* S_lo, void* acts_hi, void* acts_lo, void* T_hi, void* T_lo,
                               void* G_hi, void* G_lo, int B, int C, int n_cond, int taps, int dilation, int L, int Lp,
@@ -295,11 +296,12 @@ int t2s_wg_res_skip_train(const void* A_hi, const void* A_lo, const float* bias,
                           const void* acts_lo, const void* R_hi, const void* R_lo, void* X_hi, void* X_lo, float* skip,
                           int B, int C, int n_res, int skip_init, int L, int Lp, int halo, int Mpad, void* stream);
 
-/* d_pre = gate'(T, G) * (W_rs^T [d_x ; d_skip]):  data gradient of res_skip_layers[i] fused with the backward of
- * tanh*sigmoid (glow.py:33-40,164).  A = t2s_pack_transposed(W_rs); DX may be NULL (last layer: skip rows only).
+/* d_pre = gate'(acts, G) * (W_rs^T [d_x ; d_skip]):  data gradient of res_skip_layers[i] fused with the backward of
+ * tanh*sigmoid (glow.py:33-40,164), from the layer's saved gate output acts = tanh * sigmoid and G = sigmoid (tanh = acts / G).
+ * A = t2s_pack_transposed(W_rs); DX may be NULL (last layer: skip rows only).
  * DP planes have 2C channels (tanh half, then sigmoid half). */
 int t2s_wg_bwd_gate_dgrad(const void* A_hi, const void* A_lo, const float* zero_bias, const void* DX_hi,
-                          const void* DX_lo, const void* DS_hi, const void* DS_lo, const void* T_hi, const void* T_lo,
+                          const void* DX_lo, const void* DS_hi, const void* DS_lo, const void* acts_hi, const void* acts_lo,
                           const void* G_hi, const void* G_lo, void* DP_hi, void* DP_lo, int B, int C, int L, int Lp,
                           int halo, int Mpad, void* stream);
 

@@ -483,9 +483,11 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
                         const size_t o = obase + (size_t)t * 32;
                         *(u16x4*)(a.O_hi + o) = hi;
                         *(u16x4*)(a.O_lo + o) = lo;
-                        if (a.T_hi) {      // training: keep tanh / sigmoid for the backward pass
+                        if (a.T_hi) {      // optional: the tanh values (the backward pass rebuilds them as acts / sigmoid)
                             *(u16x4*)(a.T_hi + o) = thi;
                             *(u16x4*)(a.T_lo + o) = tlo;
+                        }
+                        if (a.G_hi) {      // training: keep the sigmoid values for the backward pass
                             *(u16x4*)(a.G_hi + o) = ghi;
                             *(u16x4*)(a.G_lo + o) = glo;
                         }
@@ -601,9 +603,11 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
             }
         }
     } else if (EPI == EPI_GATE_BWD) {
-        // acc = d_acts[c][t] (rows = acts channel c).  With the saved t = tanh(.), g = sigmoid(.):
+        // acc = d_acts[c][t] (rows = acts channel c).  With the saved a = tanh(.) * sigmoid(.) (the layer's gate output, which the
+        // weight gradients need anyway) and g = sigmoid(.), t = a / g:
         //   d_pre[c]     = d_acts * g * (1 - t^2)        (tanh half)
-        //   d_pre[C + c] = d_acts * t * g * (1 - g)      (sigmoid half)     -> planes with 2C channels
+        //   d_pre[C + c] = d_acts * a * (1 - g)          (sigmoid half: t * g * (1 - g))     -> planes with 2C channels
+        // g = 0 (pre-activation below -88) has a = 0 too and both products vanish whatever t is: t := 0 there.
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
             const int ch = mt * MT + wr * (MT / 2) + m * 16 + rq;
@@ -623,13 +627,14 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
                 u16x4 h1, l1, h2, l2;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float tv = join_bf16(th[e], tl[e]), gv = join_bf16(gh[e], gl[e]);
+                    const float av = join_bf16(th[e], tl[e]), gv = join_bf16(gh[e], gl[e]);
+                    const float tv = gv != 0.0f ? av / gv : 0.0f;
                     const float da = acc[m][n][e];
                     u16 h, l;
                     split_bf16(da * gv * (1.0f - tv * tv), h, l);
                     h1[e] = h;
                     l1[e] = l;
-                    split_bf16(da * tv * gv * (1.0f - gv), h, l);
+                    split_bf16(da * av * (1.0f - gv), h, l);
                     h2[e] = h;
                     l2[e] = l;
                 }

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
                 u16x4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
                 if (chv && cok[n]) {
                     const size_t o = obase + ((size_t)cb[n] * a.oc * a.Lp + (size_t)ct[n]) * 32;
-                    if (a.T_hi) {      // training: tanh and sigmoid are kept for the backward pass
+                    if (a.G_hi) {      // training: sigmoid (and optionally tanh) kept for the backward pass
                         u16x4 thi, tlo, ghi, glo;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -489,8 +489,10 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
                             ghi[e] = h;
                             glo[e] = l;
                         }
-                        pp_store8(a.T_hi + o, thi);
-                        pp_store8(a.T_lo + o, tlo);
+                        if (a.T_hi) {  // the backward pass rebuilds tanh as acts / sigmoid: these planes are optional
+                            pp_store8(a.T_hi + o, thi);
+                            pp_store8(a.T_lo + o, tlo);
+                        }
                         pp_store8(a.G_hi + o, ghi);
                         pp_store8(a.G_lo + o, glo);
                     } else {           // forward / infer: only the product is needed - one reciprocal for both

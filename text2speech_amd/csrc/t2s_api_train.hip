@@ -34,7 +34,7 @@ int t2s_wg_in_cond_gate_train(const void* A_hi, const void* A_lo, const float* b
                               void* G_hi, void* G_lo, int B, int C, int n_cond, int taps, int dilation, int L, int Lp,
                               int halo, int Mpad, void* stream) {
     if (!planes_ok(A_hi, A_lo) || !planes_ok(X_hi, X_lo) || !planes_ok(acts_hi, acts_lo) || !bias) return T2S_EINVAL;
-    if (!planes_ok(T_hi, T_lo) || !planes_ok(G_hi, G_lo)) return T2S_EINVAL;
+    if (!planes_ok(G_hi, G_lo) || ((T_hi || T_lo) && !planes_ok(T_hi, T_lo))) return T2S_EINVAL;      // tanh planes are optional
     if (n_cond > 0 && !planes_ok(S_hi, S_lo)) return T2S_EINVAL;
     if (B <= 0 || L <= 0 || C <= 0 || C % 4 || taps <= 0 || !(taps & 1) || dilation <= 0) return T2S_EINVAL;
     if ((taps / 2) * dilation > halo || Lp != t2s_plane_rows(L, halo)) return T2S_EINVAL;

@@ -6,8 +6,8 @@ waveglow/train.py:116-123 `outputs = model((mel, audio)); loss = criterion(outpu
 reference's training loop (criterion -> loss.backward() -> optimizer.step()) runs unchanged; every
 parameter's ``.grad`` is produced by libt2s_hip.so, not by eager PyTorch.
 
-Memory model (sized for 288 GB HBM3E): every WN layer's input, gate output, tanh and sigmoid stay
-resident as split-bf16 planes (~140 MB per layer, 13.4 GB per step at 8 x 16000) instead of being
+Memory model (sized for 288 GB HBM3E): every WN layer's input, gate output and sigmoid stay
+resident as split-bf16 planes (~105 MB per layer, 10.1 GB per step at 8 x 16000; tanh is rebuilt as gate output / sigmoid) instead of being
 recomputed.
 """
 import os
@@ -50,7 +50,7 @@ def _alloc_train(eng, B, L, dev):
     for k in range(m.n_flows):
         fl = []
         for i in range(nl):
-            fl.append(dict(X=pl(xc), A=pl(xc), T=pl(xc), G=pl(xc)))
+            fl.append(dict(X=pl(xc), A=pl(xc), G=pl(xc)))       # tanh is not kept: the backward rebuilds it as A / G
         st.layers.append(fl)
     st.skip = [torch.zeros(B, xc, Lp, 32, dtype=torch.float32, device=dev) for _ in range(m.n_flows)]
     st.wn_out = [None] * m.n_flows
@@ -174,7 +174,7 @@ def forward_train(eng, mel, audio):
             ly, sv = fl["layers"][i], lay[i]
             _lib.call("t2s_wg_in_cond_gate_train", _ptr(ly["A1h"]), _ptr(ly["A1l"]), _ptr(ly["b1"]), _ptr(sv["X"][0]),
                       _ptr(sv["X"][1]), _ptr(ts.S_planes[0]), _ptr(ts.S_planes[1]), _ptr(sv["A"][0]), _ptr(sv["A"][1]),
-                      _ptr(sv["T"][0]), _ptr(sv["T"][1]), _ptr(sv["G"][0]), _ptr(sv["G"][1]), B, C, g["n_cond"], ks, 2 ** i,
+                      None, None, _ptr(sv["G"][0]), _ptr(sv["G"][1]), B, C, g["n_cond"], ks, 2 ** i,
                       L, ts.Lp, g["halo"], g["Mpad1"], st)
             last = i == nl - 1
             nxt = None if last else lay[i + 1]["X"]
@@ -330,7 +330,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                 main_s.wait_event(ev_tdp_done)  # the side stream has transposed the previous layer's d_pre out of DP
             _lib.call("t2s_wg_bwd_gate_dgrad", _ptr(ts.A_rsT[0]), _ptr(ts.A_rsT[1]), _ptr(zb),
                       None if last else _ptr(ts.DX[0]), None if last else _ptr(ts.DX[1]), _ptr(ts.DS[0]), _ptr(ts.DS[1]),
-                      _ptr(sv["T"][0]), _ptr(sv["T"][1]), _ptr(sv["G"][0]), _ptr(sv["G"][1]), _ptr(ts.DP[0]), _ptr(ts.DP[1]),
+                      _ptr(sv["A"][0]), _ptr(sv["A"][1]), _ptr(sv["G"][0]), _ptr(sv["G"][1]), _ptr(ts.DP[0]), _ptr(ts.DP[1]),
                       B, C, L, Lp, halo, ts.Mc, st)
             ev_dp = torch.cuda.Event()
             ev_dp.record(main_s)
