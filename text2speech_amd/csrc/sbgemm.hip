@@ -12,6 +12,7 @@
 // Epilogues: plain (bias / activation, GemvArgs semantics) and the fused LSTMCell update (LstmCellArgs semantics,
 // reference tacotron.py:366-370,380-385): there the 16 rows of a workgroup are the four gates of four hidden
 // units, ordered so that one lane's four accumulators are (i, f, g, o) of one (unit, item).
+#include <stdlib.h>
 #include "t2s_common.h"
 #include "t2s_kernels.h"
 #include "tacotron_ops.h"
@@ -67,8 +68,9 @@ static __device__ __forceinline__ void sb_mma(const SbFrag& f, f32x4& acc0, f32x
 }
 
 // One workgroup's 16 rows x 32 items; partial sums of the 8 waves end in s_part[wave][half][reg][lane].
+template <int KW>
 static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow, bool row_ok, int item_base,
-                                               float (*s_part)[2][4][64], char*) {
+                                               float (*s_part)[2][4][64], char*, size_t, size_t) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, item0 = item_base + (lane & 15);
     const int nsteps = o.K >> 4;
@@ -106,88 +108,119 @@ static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow,
 // cross-wave reduction reuse each wave's first slot).  Depth is not the limit: 4 / 5 / 6 slots measure 17.98 / 18.37 / 18.54 us -
 // the launch moves 126 MB from L2 into 256 CUs (every workgroup re-reads the 32 input vectors: 2/3 of the bytes) at 13 TB/s.  Ablations at 4096 x 2560, B = 32 (tools/microbench/sbgemm_bench.py): 18.3 us =
 // 7.2 launch + prologue + epilogue, + 9.5 fill (52 GB/s per CU), + 4.1 MFMA of which 2.5 hide under the fill.
-#ifndef SB_R_SLOTS
-#define SB_R_SLOTS 4
-#endif
-constexpr int SB_R = SB_R_SLOTS;
-constexpr int SB_SLOT = 3 * 1024;
-constexpr int SB_RING_BYTES = 8 * SB_R * SB_SLOT;
+// KW = k values per step and fragment row.  KW = 16: a fragment row is 64 bytes - HALF a 128-byte line, the other half being the
+// next step's - and the launch issues one L2 request per half line (207 G requests/s chip-wide at B = 32, 77 % of what the 128 L2
+// channels accept).  KW = 32: a fragment row is one whole line (two MFMA sub-steps per fetched step), half the requests.  A wave-wide
+// DMA then covers 8 rows x 128 bytes; the eight 16-byte pieces of a row are XOR-permuted by (row & 7) on the SOURCE side so that
+// the sub-step's ds_read_b128 (16 rows, one piece each) spreads over the banks.
+template <int KW> struct SbCfg;
+template <> struct SbCfg<16> { static constexpr int R = 4, SLOT = 3 * 1024; };
+template <> struct SbCfg<32> { static constexpr int R = 3, SLOT = 6 * 1024; };
+template <int KW> constexpr int sb_ring_bytes() { return 8 * SbCfg<KW>::R * SbCfg<KW>::SLOT; }
 
 static __device__ __forceinline__ void sb_glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow, bool row_ok, int item_base,
-                                               float (*s_part)[2][4][64], char* ring) {
+template <int KW>
+static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow_of_r16, bool row_ok, int item_base,
+                                               float (*s_part)[2][4][64], char* ring, size_t grow_lo8, size_t grow_hi8) {
+    constexpr int SB_R = SbCfg<KW>::R, SB_SLOT = SbCfg<KW>::SLOT;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q = lane >> 4, r16 = lane & 15;
-    const int nsteps = o.K >> 4;
+    const int nsteps = o.K / KW;
     const int s0 = (wave * nsteps) >> 3, s1 = ((wave + 1) * nsteps) >> 3;
-    // every DMA reads valid memory: rows / items past the end are clamped here and zeroed after the fragment read
-    const size_t growc = row_ok ? grow : 0;
+    // every DMA reads valid memory: rows / items past the end are clamped by the caller / here and zeroed after the fragment read
     const bool v0 = item_base + r16 < o.items, v1 = item_base + 16 + r16 < o.items;
-    const size_t it0 = v0 ? item_base + r16 : o.items - 1, it1 = v1 ? item_base + 16 + r16 : o.items - 1;
     char* const my = ring + wave * (SB_R * SB_SLOT);
     int slot_in = 0;                                        // slot the next issue fills (wave-uniform)
+    // DMA lane roles.  KW = 16: row r16, piece q.  KW = 32: rows (lane >> 3) and (lane >> 3) + 8, piece (lane & 7) ^ (row & 7).
+    const int dr = KW == 16 ? r16 : (lane >> 3);
+    const int dp = KW == 16 ? q : ((lane & 7) ^ (dr & 7));  // (row + 8) & 7 == row & 7
+    const size_t ia0 = item_base + dr < o.items ? item_base + dr : o.items - 1;
+    const size_t ia1 = item_base + dr + 8 < o.items ? item_base + dr + 8 : o.items - 1;
+    const size_t ib0 = item_base + 16 + dr < o.items ? item_base + 16 + dr : o.items - 1;
+    const size_t ib1 = item_base + 24 + dr < o.items ? item_base + 24 + dr : o.items - 1;
     auto issue = [&](int st) {
-        const int k = st * 16;                              // wave-uniform: a K-step lies inside one operand segment
-        const float* wp = k < o.k1 ? o.W1 + growc * o.ld1 + k : o.W2 + growc * o.ld2 + (k - o.k1);
+        const int k = st * KW;                              // wave-uniform: a step lies inside one operand segment
+        const bool w1 = k < o.k1;
+        const float* wbase = w1 ? o.W1 + k : o.W2 + (k - o.k1);
+        const size_t wld = w1 ? o.ld1 : o.ld2;
         const float* xp;
         long sx;
         if (k < o.n0) { xp = o.x0 + k; sx = o.sx0; }
         else if (k < o.n0 + o.n1) { xp = o.x1 + (k - o.n0); sx = o.sx1; }
         else { xp = o.x2 + (k - o.n0 - o.n1); sx = o.sx2; }
         char* dst = my + slot_in * SB_SLOT;
-        sb_glds16(wp + q * 4, dst);
-        sb_glds16(xp + q * 4 + it0 * sx, dst + 1024);
-        sb_glds16(xp + q * 4 + it1 * sx, dst + 2048);
+        if constexpr (KW == 16) {
+            sb_glds16(wbase + grow_of_r16 * wld + dp * 4, dst);
+            sb_glds16(xp + dp * 4 + ia0 * sx, dst + 1024);
+            sb_glds16(xp + dp * 4 + ib0 * sx, dst + 2048);
+        } else {
+            sb_glds16(wbase + grow_lo8 * wld + dp * 4, dst);
+            sb_glds16(wbase + grow_hi8 * wld + dp * 4, dst + 1024);
+            sb_glds16(xp + dp * 4 + ia0 * sx, dst + 2048);
+            sb_glds16(xp + dp * 4 + ia1 * sx, dst + 3072);
+            sb_glds16(xp + dp * 4 + ib0 * sx, dst + 4096);
+            sb_glds16(xp + dp * 4 + ib1 * sx, dst + 5120);
+        }
         slot_in = slot_in + 1 == SB_R ? 0 : slot_in + 1;
     };
+    constexpr int NDMA = KW == 16 ? 3 : 6;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    // Every workgroup reads the SAME input vectors; walking K in the same order they would all ask the same L2 channels for
-    // the same lines at the same moment.  Each workgroup starts its waves' ranges at its own rotation (SB_ROT).
     const int nmine = s1 - s0;
-#ifdef T2S_SB_NO_ROT
-    const int rot = 0;
-#else
-    const int rot = nmine > 0 ? (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)nmine) : 0;
-#endif
-    auto step_of = [&](int i) { const int j = i + rot; return s0 + (j >= nmine ? j - nmine : j); };
-    int issued = 0;                                         // steps are counted 0 .. nmine - 1 in walking order
+    int issued = 0;                                         // steps are counted 0 .. nmine - 1
 #pragma unroll 1
-    for (int i = 0; i < SB_R - 1 && issued < nmine; ++i) issue(step_of(issued++));
+    for (int i = 0; i < SB_R - 1 && issued < nmine; ++i) issue(s0 + issued++);
     int slot_out = 0;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // fragment read offsets of this lane (row r16, logical piece q [+ 4 for the second sub-step])
+    const int rd0 = KW == 16 ? lane * 16 : (r16 >> 3) * 1024 + (r16 & 7) * 128 + ((q ^ (r16 & 7)) * 16);
+    const int rd1 = KW == 16 ? 0 : (r16 >> 3) * 1024 + (r16 & 7) * 128 + (((4 + q) ^ (r16 & 7)) * 16);
 #pragma unroll 1
     for (int s = 0; s < nmine; ++s) {
         // steps s .. issued - 1 are in flight; step s has landed once at most the issued - s - 1 newer ones are outstanding
-        if (issued - s == SB_R - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (SB_R - 2)) : "memory");
+        if (issued - s == SB_R - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (SB_R - 2)) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the last SB_R - 2 steps of the range drain
-        const char* src = my + slot_out * SB_SLOT + lane * 16;
-        f32x4 fa = *(const f32x4*)src;
-        f32x4 fb0 = *(const f32x4*)(src + 1024);
-        f32x4 fb1 = *(const f32x4*)(src + 2048);
+        const char* src = my + slot_out * SB_SLOT;
+        constexpr int OPB = KW == 16 ? 1024 : 2048;         // bytes per operand in a slot
+        f32x4 fa = *(const f32x4*)(src + rd0);
+        f32x4 fb0 = *(const f32x4*)(src + OPB + rd0);
+        f32x4 fb1 = *(const f32x4*)(src + 2 * OPB + rd0);
+        f32x4 ga = zero, gb0 = zero, gb1 = zero;
+        if constexpr (KW == 32) {
+            ga = *(const f32x4*)(src + rd1);
+            gb0 = *(const f32x4*)(src + OPB + rd1);
+            gb1 = *(const f32x4*)(src + 2 * OPB + rd1);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         slot_out = slot_out + 1 == SB_R ? 0 : slot_out + 1;
         // the slot read in the PREVIOUS iteration is free (its reads were waited for there): refill it
 #if !defined(SB_ABL) || !(SB_ABL & 1)
-        if (issued < nmine) issue(step_of(issued++));
+        if (issued < nmine) issue(s0 + issued++);
 #else
         if (issued < nmine) issued++;                      // timing-only ablation: no fill after the prologue (results are wrong)
 #endif
-        if (!row_ok) fa = zero;
-        if (!v0) fb0 = zero;
-        if (!v1) fb1 = zero;
+        if (!row_ok) { fa = zero; ga = zero; }
+        if (!v0) { fb0 = zero; gb0 = zero; }
+        if (!v1) { fb1 = zero; gb1 = zero; }
 #if !defined(SB_ABL) || !(SB_ABL & 2)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb0[j], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb1[j], acc1, 0, 0, 0);
         }
+        if constexpr (KW == 32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[j], gb0[j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[j], gb1[j], acc1, 0, 0, 0);
+            }
+        }
 #else
-        asm volatile("" ::"v"(fa), "v"(fb0), "v"(fb1));    // timing-only ablation: no MFMA
+        asm volatile("" ::"v"(fa), "v"(fb0), "v"(fb1), "v"(ga), "v"(gb0), "v"(gb1));    // timing-only ablation: no MFMA
 #endif
     }
     // this wave's slots are drained (every fragment read above was waited for): its partial sums go into its own first slot
@@ -203,6 +236,7 @@ static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow,
 
 // tile row r (0..15) of item it (0..31 within the group): D[row][col]: lane = (row/4)*16 + col%16, reg = row%4, half = col/16
 #ifdef T2S_SBGEMM_VGPR
+template <int KW>
 static __device__ __forceinline__ float sb_sum(float (*s_part)[2][4][64], const char*, int r, int it) {
     const int ln = (r >> 2) * 16 + (it & 15), half = it >> 4, reg = r & 3;
     float s = 0.f;
@@ -212,17 +246,19 @@ static __device__ __forceinline__ float sb_sum(float (*s_part)[2][4][64], const 
 }
 #define SB_DECL_PART __shared__ float s_part[8][2][4][64];
 #else
+template <int KW>
 static __device__ __forceinline__ float sb_sum(float (*)[2][4][64], const char* ring, int r, int it) {
     const int ln = (r >> 2) * 16 + (it & 15), half = it >> 4, reg = r & 3;
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) s += ((const float*)(ring + w * (SB_R * SB_SLOT)))[(half * 4 + reg) * 64 + ln];
+    for (int w = 0; w < 8; ++w) s += ((const float*)(ring + w * (SbCfg<KW>::R * SbCfg<KW>::SLOT)))[(half * 4 + reg) * 64 + ln];
     return s;
 }
 #define SB_DECL_PART float (*s_part)[2][4][64] = nullptr;
 #endif
 
 // ---- plain epilogue: GemvArgs semantics (no split_row / masks) -------------------------------------------------------
+template <int KW>
 __global__ __launch_bounds__(512) void sbgemm_plain_kernel(const GemvArgs a) {
     SB_DECL_PART
     extern __shared__ __attribute__((aligned(16))) char sb_ring[];
@@ -233,11 +269,13 @@ __global__ __launch_bounds__(512) void sbgemm_plain_kernel(const GemvArgs a) {
     o.K = a.n1 + a.n2 + a.n3; o.items = a.items;
     const int row0 = blockIdx.x * 16, item_base = blockIdx.y * 32;
     const int lrow = row0 + (threadIdx.x & 15);
-    sb_core(o, (size_t)lrow, lrow < a.rows, item_base, s_part, sb_ring);
+    auto clampr = [&](int r) { return (size_t)(r < a.rows ? r : a.rows - 1); };       // DMA sources stay inside the matrix
+    const int dr = (threadIdx.x & 63) >> 3;
+    sb_core<KW>(o, clampr(lrow), lrow < a.rows, item_base, s_part, sb_ring, clampr(row0 + dr), clampr(row0 + dr + 8));
     const int r = threadIdx.x & 15, it = threadIdx.x >> 4;          // 512 threads = 16 rows x 32 items
     const int row = row0 + r, item = item_base + it;
     if (row < a.rows && item < a.items) {
-        float y = sb_sum(s_part, sb_ring, r, it) + (a.bias1 ? a.bias1[row] : 0.f) + (a.bias2 ? a.bias2[row] : 0.f);
+        float y = sb_sum<KW>(s_part, sb_ring, r, it) + (a.bias1 ? a.bias1[row] : 0.f) + (a.bias2 ? a.bias2[row] : 0.f);
         if (a.act == ACT_RELU) y = fmaxf(y, 0.f);
         else if (a.act == ACT_TANH) y = tanhf(y);
         a.y[(size_t)item * a.sy_item + (size_t)row * a.sy_row] = y;
@@ -256,22 +294,37 @@ bool t2s_sbgemm_plain_ok(const GemvArgs& a) {
     return true;
 }
 
-hipError_t t2s_launch_sbgemm_plain(const GemvArgs& a, hipStream_t stream) {
-    dim3 grid((a.rows + 15) / 16, (a.items + 31) / 32);
+template <int KW, typename Args>
+static hipError_t sb_launch(void (*kern)(const Args), const Args& a, dim3 grid, hipStream_t stream) {
 #ifdef T2S_SBGEMM_VGPR
     constexpr int lds = 0;
 #else
-    constexpr int lds = SB_RING_BYTES;
-    static std::atomic<unsigned long long> attr_mask{0};
-    const hipError_t e = t2s_raise_lds_limit((const void*)sbgemm_plain_kernel, lds, attr_mask);
+    constexpr int lds = sb_ring_bytes<KW>();
+    static std::atomic<unsigned long long> attr_mask{0};         // one per (KW, Args) instantiation = per kernel
+    const hipError_t e = t2s_raise_lds_limit((const void*)kern, lds, attr_mask);
     if (e != hipSuccess) return e;
 #endif
-    hipLaunchKernelGGL(sbgemm_plain_kernel, grid, dim3(512), lds, stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a);
     return hipGetLastError();
+}
+// whole 128-byte lines per fragment row where every operand segment is a multiple of 32 (T2S_SB_STEP=16 forces the 64-byte form)
+static bool sb_wide_ok(int K, int k1, int n0, int n1, int n2) {
+    static const int force = getenv("T2S_SB_STEP") ? atoi(getenv("T2S_SB_STEP")) : 0;
+    if (force == 16) return false;
+    return !((K | k1 | n0 | n1 | n2) & 31);
+}
+
+hipError_t t2s_launch_sbgemm_plain(const GemvArgs& a, hipStream_t stream) {
+    dim3 grid((a.rows + 15) / 16, (a.items + 31) / 32);
+#ifndef T2S_SBGEMM_VGPR
+    if (sb_wide_ok(a.n1 + a.n2 + a.n3, a.k1, a.n1, a.n2, a.n3)) return sb_launch<32>(sbgemm_plain_kernel<32>, a, grid, stream);
+#endif
+    return sb_launch<16>(sbgemm_plain_kernel<16>, a, grid, stream);
 }
 
 // ---- fused LSTMCell epilogue: LstmCellArgs semantics ---------------------------------------------------------------
 // Workgroup = hidden units u0..u0+3; tile row r = unit*4 + gate  ->  weight row gate*H + u0 + unit.
+template <int KW>
 __global__ __launch_bounds__(512) void sbgemm_lstm_kernel(const LstmCellArgs a) {
     SB_DECL_PART
     extern __shared__ __attribute__((aligned(16))) char sb_ring[];
@@ -282,8 +335,9 @@ __global__ __launch_bounds__(512) void sbgemm_lstm_kernel(const LstmCellArgs a) 
     o.sx0 = a.sx1; o.sx1 = a.sx2; o.sx2 = a.H;
     o.K = K1 + a.H; o.items = a.B;
     const int u0 = blockIdx.x * 4, item_base = blockIdx.y * 32;
-    const int lr = threadIdx.x & 15;
-    sb_core(o, (size_t)(lr & 3) * a.H + u0 + (lr >> 2), true, item_base, s_part, sb_ring);
+    auto wrow = [&](int tr) { return (size_t)(tr & 3) * a.H + u0 + (tr >> 2); };       // tile row = unit * 4 + gate
+    const int dr = (threadIdx.x & 63) >> 3;
+    sb_core<KW>(o, wrow(threadIdx.x & 15), true, item_base, s_part, sb_ring, wrow(dr), wrow(dr + 8));
     if (threadIdx.x < 128) {
         const int ul = threadIdx.x & 3, it = threadIdx.x >> 2;
         const int item = item_base + it, u = u0 + ul;
@@ -291,7 +345,7 @@ __global__ __launch_bounds__(512) void sbgemm_lstm_kernel(const LstmCellArgs a) 
             float g[4];
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi)
-                g[gi] = sb_sum(s_part, sb_ring, ul * 4 + gi, it) + (a.b_ih[gi * a.H + u] + a.b_hh[gi * a.H + u]);
+                g[gi] = sb_sum<KW>(s_part, sb_ring, ul * 4 + gi, it) + (a.b_ih[gi * a.H + u] + a.b_hh[gi * a.H + u]);
             const size_t idx = (size_t)item * a.H + u;
             const float gi_ = sb_sigmoid(g[0]), gf = sb_sigmoid(g[1]), gg = tanhf(g[2]), go_ = sb_sigmoid(g[3]);
             const float c2 = gf * a.c[idx] + gi_ * gg;
@@ -321,14 +375,8 @@ bool t2s_sbgemm_lstm_ok(const LstmCellArgs& a) {
 
 hipError_t t2s_launch_sbgemm_lstm(const LstmCellArgs& a, hipStream_t stream) {
     dim3 grid(a.H / 4, (a.B + 31) / 32);
-#ifdef T2S_SBGEMM_VGPR
-    constexpr int lds = 0;
-#else
-    constexpr int lds = SB_RING_BYTES;
-    static std::atomic<unsigned long long> attr_mask{0};
-    const hipError_t e = t2s_raise_lds_limit((const void*)sbgemm_lstm_kernel, lds, attr_mask);
-    if (e != hipSuccess) return e;
+#ifndef T2S_SBGEMM_VGPR
+    if (sb_wide_ok(a.n1 + a.n2 + a.H, a.n1 + a.n2, a.n1, a.n2, a.H)) return sb_launch<32>(sbgemm_lstm_kernel<32>, a, grid, stream);
 #endif
-    hipLaunchKernelGGL(sbgemm_lstm_kernel, grid, dim3(512), lds, stream, a);
-    return hipGetLastError();
+    return sb_launch<16>(sbgemm_lstm_kernel<16>, a, grid, stream);
 }
