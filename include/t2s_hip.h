@@ -42,6 +42,7 @@ extern "C" {
 
 #define T2S_PERM_NONE 0
 #define T2S_PERM_GATE 1  /* rows o<C: tanh half, o>=C: sigmoid half, interleaved per 16 channels */
+#define T2S_PERM_PAIR8 2 /* table pack only: rows o < C_gate, per group of 32: packed row 16 m + 4 q + e = channel 8 q + 4 m + e */
 #define T2S_ACT_NONE 0
 #define T2S_ACT_RELU 1
 #define T2S_ACT_TANH 2
@@ -168,8 +169,10 @@ int t2s_wg_in_melwin_gate_fold(const void* A_hi, const void* A_lo, const void* A
                                const void* X_hi, const void* X_lo, const void* M_hi, const void* M_lo, void* acts_hi,
                                void* acts_lo, const void* fold_A, float* fold_acc, int fold_init, int B, int C, int K2,
                                int taps, int dilation, int L, int Lp, int halo, int Mpad, int P, int Fp, void* stream);
+/* pair8 = 1: the residual rows of A / bias were packed with perm = 2 (T2S_PERM_PAIR8: in every group of 32 channels packed row
+ * 16 m + 4 q + e holds channel 8 q + 4 m + e), which lets the epilogue touch x in 16-byte pieces; C % 32 == 0 */
 int t2s_wg_res_only(const void* A_hi, const void* A_lo, const float* bias, const void* acts_hi, const void* acts_lo,
-                    void* X_hi, void* X_lo, int B, int C, int L, int Lp, int halo, int Mpad, void* stream);
+                    void* X_hi, void* X_lo, int B, int C, int L, int Lp, int halo, int Mpad, int pair8, void* stream);
 /* WN.end output from the folded accumulators + affine coupling (forward or reverse) */
 int t2s_wg_end_fold_affine(const float* fold_acc, int nslots, const float* bes, int n_layers, const float* b_end,
                            float* z, float* log_s, int B, int n_group, int c_off, int n_half, int L, int reverse,

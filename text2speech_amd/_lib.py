@@ -42,7 +42,7 @@ SIGNATURES = {
     "t2s_wg_compose_cond": [c_vp, c_vp] + [c_int] * 4 + [c_long, c_vp, c_vp, c_vp, c_vp],
     "t2s_wg_melwin_planes": [c_vp] + [c_int] * 5 + [c_vp, c_vp, c_vp],
     "t2s_wg_in_melwin_gate_fold": [c_vp] * 13 + [c_int] * 12 + [c_vp],
-    "t2s_wg_res_only": [c_vp] * 7 + [c_int] * 6 + [c_vp],
+    "t2s_wg_res_only": [c_vp] * 7 + [c_int] * 7 + [c_vp],
     "t2s_wg_end_fold_affine": [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
     "t2s_wg_end_affine": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                           c_int, c_vp],

@@ -194,8 +194,34 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
     constexpr bool PREX = EPI == EPI_RESSKIP && MT == 128;
 #endif
     u16x4 pre_h[PREX ? MW : 1][PREX ? NWT : 1], pre_l[PREX ? MW : 1][PREX ? NWT : 1];
+    typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
     if constexpr (PREX) {
         const int tcol_p = lane & 15, rq_p = (lane >> 4) * 4;
+        if (a.pair8) {
+            // residual rows packed with PERM_PAIR8: the two m-tiles of a 32-channel group give this lane 8 consecutive channels of a
+            // plane row - ONE 16-byte request per plane (the identity order needs two 8-byte ones: a quarter line each)
+#pragma unroll
+            for (int m = 0; m < MW; m += 2) {
+                const int prow = mt * MT + wr * (MT / 2) + m * 16 + rq_p;
+                const int ch = (prow & ~31) + 2 * rq_p;
+                const bool is_res = ch < a.n_res && !a.res_init;
+                const size_t base = (((size_t)b * a.oc + ((is_res ? ch : 0) >> 5)) * a.Lp + a.halo) * 32 + ((is_res ? ch : 0) & 31);
+#pragma unroll
+                for (int n = 0; n < NWT; ++n) {
+                    const int t = t0 + wc * (NWT * 16) + n * 16 + tcol_p;
+                    const size_t ro = base + (size_t)(t < a.L ? t : 0) * 32;
+                    u16x8_t vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (is_res) {
+                        vh = *(const u16x8_t*)((a.R_hi ? a.R_hi : a.O_hi) + ro);
+                        vl = *(const u16x8_t*)((a.R_lo ? a.R_lo : a.O_lo) + ro);
+                    }
+                    pre_h[m][n] = (u16x4){vh[0], vh[1], vh[2], vh[3]};
+                    pre_h[m + 1][n] = (u16x4){vh[4], vh[5], vh[6], vh[7]};
+                    pre_l[m][n] = (u16x4){vl[0], vl[1], vl[2], vl[3]};
+                    pre_l[m + 1][n] = (u16x4){vl[4], vl[5], vl[6], vl[7]};
+                }
+            }
+        } else
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
             const int prow = mt * MT + wr * (MT / 2) + m * 16 + rq_p;
@@ -528,6 +554,37 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
                 }
             }
         }
+    } else if (EPI == EPI_RESSKIP && PREX && a.pair8) {
+        // t2s_wg_res_only with PERM_PAIR8 rows (residual rows only, values prefetched in front of the K loop): per m-tile pair and
+        // column one 16-byte store per plane
+      if constexpr (PREX) {
+#pragma unroll
+        for (int m = 0; m < MW; m += 2) {
+            const int prow = mt * MT + wr * (MT / 2) + m * 16 + rq;
+            const int ch = (prow & ~31) + 2 * rq;
+            if (ch >= a.n_res) continue;
+            const f32x4 b0 = *(const f32x4*)(a.bias + prow), b1 = *(const f32x4*)(a.bias + prow + 16);
+            const size_t base = (((size_t)b * a.oc + (ch >> 5)) * a.Lp + a.halo) * 32 + (ch & 31);
+#pragma unroll
+            for (int n = 0; n < NWT; ++n) {
+                const int t = t0 + wc * (NWT * 16) + n * 16 + tcol;
+                if (t >= a.L) continue;
+                u16x8_t hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u16 h, l;
+                    split_bf16(join_bf16(pre_h[m][n][e], pre_l[m][n][e]) + (acc[m][n][e] + b0[e]), h, l);
+                    hi[e] = h;
+                    lo[e] = l;
+                    split_bf16(join_bf16(pre_h[m + 1][n][e], pre_l[m + 1][n][e]) + (acc[m + 1][n][e] + b1[e]), h, l);
+                    hi[4 + e] = h;
+                    lo[4 + e] = l;
+                }
+                *(u16x8_t*)(a.O_hi + base + (size_t)t * 32) = hi;
+                *(u16x8_t*)(a.O_lo + base + (size_t)t * 32) = lo;
+            }
+        }
+      }
     } else if (EPI == EPI_RESSKIP) {
         // The residual / skip values this wave updates in place are requested in batches of m-tiles BEFORE any of them
         // is consumed: with load -> add -> store per tile (same arrays read and written, so hipcc keeps that order) the

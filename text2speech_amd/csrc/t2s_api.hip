@@ -293,7 +293,7 @@ int t2s_wg_in_melwin_gate_fold(const void* A_hi, const void* A_lo, const void* A
 }
 
 int t2s_wg_res_only(const void* A_hi, const void* A_lo, const float* bias, const void* acts_hi, const void* acts_lo,
-                    void* X_hi, void* X_lo, int B, int C, int L, int Lp, int halo, int Mpad, void* stream) {
+                    void* X_hi, void* X_lo, int B, int C, int L, int Lp, int halo, int Mpad, int pair8, void* stream) {
     if (!check_planes(A_hi, A_lo) || !check_planes(acts_hi, acts_lo) || !check_planes(X_hi, X_lo) || !bias) return T2S_EINVAL;
     if (B <= 0 || L <= 0 || C <= 0 || C % 4 || Lp != t2s_plane_rows(L, halo) || Mpad % 256 || Mpad < C || !aligned16(bias))
         return T2S_EINVAL;
@@ -307,6 +307,8 @@ int t2s_wg_res_only(const void* A_hi, const void* A_lo, const float* bias, const
     a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
     a.n_mtiles = cdiv(C, 128); a.n_ttiles = cdiv(L, 256);
     a.C = 0; a.n_res = C;
+    if (pair8 && C % 32) return T2S_EINVAL;
+    a.pair8 = pair8 ? 1 : 0;
     T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_RESSKIP, (hipStream_t)stream, 128));
     return T2S_OK;
 }

@@ -7,7 +7,7 @@ typedef unsigned short u16;
 
 enum { EPI_GATE = 0, EPI_RESSKIP = 1, EPI_BIAS_ACT = 2, EPI_GATE_BWD = 3 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
-enum { PERM_NONE = 0, PERM_GATE = 1 };
+enum { PERM_NONE = 0, PERM_GATE = 1, PERM_PAIR8 = 2 };
 
 struct ConvGemmArgs {
     const u16* A_hi;   // packed weights [nk][Mpad][32] bf16
@@ -38,6 +38,7 @@ struct ConvGemmArgs {
     u16* G_hi;
     u16* G_lo;
     int tc;            // chunks of the T/G planes
+    int pair8;         // RESSKIP: the residual rows were packed with PERM_PAIR8 (a lane's two m-tiles hold 8 consecutive channels)
     int res_init;      // RESSKIP: 1 = residual half stores (x = acc + bias), 0 = accumulates
     const u16* R_hi;   // RESSKIP: residual source planes (null: read the output planes, i.e. in place)
     const u16* R_lo;

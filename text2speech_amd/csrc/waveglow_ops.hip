@@ -86,6 +86,13 @@ static __device__ __forceinline__ int pack_dst_row(const PackJob& j, int o) {
         const int ch = gate ? o - (int)j.C_gate : o;
         return (ch >> 7) * 256 + ((ch >> 6) & 1) * 128 + (((ch >> 4) & 3) * 2 + gate) * 16 + (ch & 15);
     }
+    if (j.perm == PERM_PAIR8 && o < (int)j.C_gate) {
+        // rows o < C_gate (the residual half), in groups of 32 channels: packed row m * 16 + q * 4 + e holds channel 8 q + 4 m + e, so
+        // that the two 16-row MFMA tiles of a group give lane group q the 8 CONSECUTIVE channels 8 q .. 8 q + 7 of a plane row: one
+        // 16-byte access per plane where the identity order needs two 8-byte ones (a quarter of a 128-byte line per request)
+        const int w = o & 31;
+        return (o & ~31) + ((w >> 2) & 1) * 16 + (w >> 3) * 4 + (w & 3) + (int)j.row_off;
+    }
     return o + (int)j.row_off;
 }
 static __device__ __forceinline__ void pack_store2(const PackJob& j, int k, int p, float w0, float w1) {

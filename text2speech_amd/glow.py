@@ -155,9 +155,12 @@ class _Engine:
         return g
 
     # ------------------------------------------------------------------ weights
-    def pack_weights(self, device, force=True, flow_events=None):
+    def pack_weights(self, device, force=True, flow_events=None, res_pair8=False):
+        """res_pair8: pack the residual rows of every res/skip convolution in the 8-consecutive-channels order the folded no-grad
+        path's residual GEMM wants (t2s_wg_res_only(pair8 = 1)); the training path keeps the identity order."""
         m = self.m
-        key = tuple(p._version for p in m.parameters()) + (str(device),)
+        res_pair8 = bool(res_pair8) and self.geom()["C"] % 32 == 0 and os.environ.get("T2S_RES_PAIR8") != "0"
+        key = tuple(p._version for p in m.parameters()) + (str(device), res_pair8)
         if not force and self.packed is not None and self.packed_key == key:
             return self.packed
         g = self.geom()
@@ -206,9 +209,11 @@ class _Engine:
                               ly["s_in"]))
                 specs.append((t[4], t[5], None, None, ly["A1h"], ly["A1l"], None, 2 * C, g["n_cond"], 1, 1, C, g["Mpad1"],
                               ks * g["Cpad"], g["Spad"], ly["s_cond"]))
-                specs.append((t[6], t[7], t[8], None, ly["A2h"], ly["A2l"], ly["b2"], t[6].size(0), C, 1, 0, 0, ly["Mpad2"], 0,
-                              g["Cpad"], ly["s_rs"]))
-        ptr_key = tuple(0 if t is None else t.data_ptr() for t in srcs)
+                # residual rows (the first C of 2C; the last layer has none) optionally in the PERM_PAIR8 order
+                p8 = res_pair8 and i < nl - 1
+                specs.append((t[6], t[7], t[8], None, ly["A2h"], ly["A2l"], ly["b2"], t[6].size(0), C, 1, 2 if p8 else 0,
+                              C if p8 else 0, ly["Mpad2"], 0, g["Cpad"], ly["s_rs"]))
+        ptr_key = tuple(0 if t is None else t.data_ptr() for t in srcs) + (res_pair8,)
         jpf = 3 * nl                                   # jobs per flow: (in, cond, res_skip) x layers
         if self.packed.get("job_key") != ptr_key:
             rows, flow_rows, row_start = [], [], 0
@@ -265,6 +270,7 @@ class _Engine:
                 flow_events.append(ev)
         keep = srcs + [t for tup in fsrc for t in tup[:3]] + starts
         self.packed_key = key
+        self.packed["res_pair8"] = res_pair8
         self._keep = keep
         return self.packed
 
@@ -396,7 +402,7 @@ class _Engine:
                 if n_res:       # the last layer has no residual half, and its skip half lives in the fold
                     _lib.call("t2s_wg_res_only", _lib.ptr(ly["A2h"]), _lib.ptr(ly["A2l"]), _lib.ptr(ly["b2"]),
                               _lib.ptr(w["Ah"]), _lib.ptr(w["Al"]), _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), B, C, L, w["Lp"],
-                              g["halo"], ly["Mpad2"], st)
+                              g["halo"], ly["Mpad2"], 1 if self.packed.get("res_pair8") else 0, st)
             else:
                 _lib.call("t2s_wg_res_skip", _lib.ptr(ly["A2h"]), _lib.ptr(ly["A2l"]), _lib.ptr(ly["b2"]),
                           _lib.ptr(w["Ah"]), _lib.ptr(w["Al"]), _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), _lib.ptr(w["skip"]),
@@ -476,7 +482,7 @@ class _Engine:
         pack_events = []
         pack_s.wait_stream(main)
         with torch.cuda.stream(pack_s):
-            self.pack_weights(dev, force=True, flow_events=pack_events)
+            self.pack_weights(dev, force=True, flow_events=pack_events, res_pair8=self.use_fold)
         if side is not main:
             main.wait_event(ev_inputs)
         st = _lib.current_stream()
@@ -504,7 +510,7 @@ class _Engine:
         # reference glow.py:254-255: drop the last (kernel - stride) upsampled samples
         T = (frames - 1) * up.stride[0] + up.kernel_size[0] - (up.kernel_size[0] - up.stride[0])
         L = T // G
-        self.pack_weights(dev, force=False)
+        self.pack_weights(dev, force=False, res_pair8=self.use_fold)
         w = self.workspace(B, L, dev)
         st = _lib.current_stream()
         # Weights are packed once here, so the conditioning path can be composed with the upsampler (K = 640 -> 320 in the gate
