@@ -88,5 +88,14 @@ def test_normalize_reference_quirks_are_kept():
     assert normalize("12.5개") == "열두개"                # a decimal part in front of a count word is dropped (group 1 only)
     with pytest.raises(ValueError):
         normalize("+5")                                  # int('+') in the reference's digit loop
+    # inputs the reference itself rejects raise the same exception type here (recorded by tools/gen_golden_text.py)
+    raised = 0
+    for u in _golden()["unpinned"]:
+        kind = u["why"].split(":")[0]
+        if kind in ("ValueError", "SyntaxError", "IndexError"):
+            with pytest.raises({"ValueError": ValueError, "SyntaxError": SyntaxError, "IndexError": IndexError}[kind]):
+                normalize(u["text"])
+            raised += 1
+    assert raised >= 3
     # unpinned corner (nltk punkt absent upstream here): single-sentence quotes are re-quoted with ASCII apostrophes
     assert normalize('"저돌"(猪突) 입니다.') == "'저돌' 입니다."

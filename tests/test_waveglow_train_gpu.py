@@ -197,6 +197,17 @@ def test_adam_state_interop_and_cache_invalidation():
     back = torch.optim.Adam(ref, lr=1e-3)
     back.load_state_dict(copy.deepcopy(opt.state_dict()))
     assert int(back.state[ref[0]]["step"]) == 6
+    # ... and CONTINUES there: every parameter has a step tensor of its own (a shared one would advance once per parameter)
+    steps = [back.state[r]["step"] for r in ref]
+    assert len({id(s) for s in steps}) == len(steps)
+    before = [r.detach().clone() for r in ref]
+    back.step()
+    opt.step()
+    torch.cuda.synchronize()
+    assert all(int(back.state[r]["step"]) == 7 for r in ref) and opt.param_groups[0]["step"] == 7
+    assert any(not torch.equal(b, r.detach()) for b, r in zip(before, ref))
+    worst = max(_rel(p.detach(), r.detach()) for p, r in zip(params, ref))
+    assert worst < 1e-6, worst
     # (3) infer() after a step must see the stepped weights
     m.eval()
     gen = torch.Generator().manual_seed(1)

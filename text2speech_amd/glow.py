@@ -148,8 +148,12 @@ class _Engine:
         wn0 = m.WN[0]
         C, nl, ks = wn0.n_channels, wn0.n_layers, wn0.kernel_size
         n_cond = m.upsample.out_channels * m.n_group
+        # halo = the largest dilated tap offset, rounded up to a whole 32-row block: the channel-last weight-gradient GEMM
+        # (csrc/wgrad_cl.hip) walks whole 32-row K-blocks starting at row `halo` and shifts them by up to +-halo rows, which stays
+        # inside the plane only if halo % 32 == 0 (n_layers <= 5 gives 2^(nl-1) < 32)
+        halo = -(-((2 ** (nl - 1)) * (ks // 2)) // 32) * 32
         g = dict(C=C, nl=nl, ks=ks, n_cond=n_cond, Cpad=-(-C // 32) * 32, Spad=-(-n_cond // 32) * 32,
-                 halo=(2 ** (nl - 1)) * (ks // 2), Mpad1=-(-C // 128) * 256)
+                 halo=halo, Mpad1=-(-C // 128) * 256)
         g["nk1"] = ks * g["Cpad"] // 32 + g["Spad"] // 32
         g["nk2"] = g["Cpad"] // 32
         return g

@@ -92,7 +92,9 @@ def _alloc_train(eng, B, L, dev):
     st.zero_bias = torch.zeros(max(st.M2pad, st.Ms, 1024), dtype=torch.float32, device=dev)
     st.sw_scratch = torch.empty(_lib.load().t2s_small_wgrad_scratch(B, xc), dtype=torch.float32, device=dev)
     # channel-last weight-gradient GEMM (t2s_wgrad_cl): constant chunks and the per-layer operand tables (built on first use)
-    st.cl_ok = C % 32 == 0 and g["n_cond"] % 32 == 0 and not os.environ.get("T2S_WGRAD_TM")
+    # (its K-blocks are whole 32-row blocks shifted by up to +-halo rows: in bounds only when halo % 32 == 0, which geom() ensures)
+    st.cl_ok = C % 32 == 0 and g["n_cond"] % 32 == 0 and g["halo"] % 32 == 0 and not os.environ.get("T2S_WGRAD_TM")
+    assert not st.cl_ok or (st.k0 * 32 >= g["halo"] and st.k1 * 32 + g["halo"] <= Lp), "wgrad_cl K-blocks leave the plane"
     st.zero_plane = _bf(Lp, 32, dev=dev)
     st.ones_plane = _bf(Lp, 32, dev=dev)
     st.ones_plane[g["halo"]:g["halo"] + L, 0] = 1.0

@@ -25,6 +25,17 @@ class FusedAdam(torch.optim.Optimizer):
         for group in self.param_groups:
             group.pop("step", None)     # re-derived from the loaded per-parameter state on the next step()
 
+    def state_dict(self):
+        """torch.optim.Adam's layout with a step tensor OF ITS OWN per parameter.  Internally every parameter of a group points at
+        one shared host tensor (a step costs one fill_, not one per parameter); emitted as such, `torch.optim.Adam` loading the
+        dict would advance the shared counter once per parameter per step."""
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            s = st.get("step")
+            if s is not None:
+                st["step"] = torch.tensor(float(s.item() if torch.is_tensor(s) else s), dtype=torch.float32)
+        return sd
+
     @staticmethod
     def _loaded_step(group, state):
         """Step count of a group: torch.optim.Adam keeps it per parameter (tensor or int)."""

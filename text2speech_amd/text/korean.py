@@ -80,55 +80,45 @@ def _requote(m):
     return " ".join("'{}'".format(s) for s in _split_sentences(inner))
 
 
+def _name_integer(digits, names):
+    """Digit string -> numeral words, read in blocks of four decimal places (천 백 십 + unit digit, then 만 / 억 / 조 ...).
+
+    Every digit gets the power of ten it stands for, counted from the length of the VALUE (``str(int(digits))``) - the
+    reference derives its place names that way (text/korean.py:283-300), and so "007.5" names its digits three places too low.
+    A block is spoken only if its units place (power % 4 == 0) is inside the string; its name is ``_GROUP[power // 4]`` with the
+    list's own index rules (negative wraps, too large raises), which again is what the reference's table lookup does."""
+    top = len(str(int(digits))) - 1
+    powers = range(top, top - len(digits), -1)
+    blocks = {}
+    for ch, p in zip(digits, powers):
+        if ch != "0":
+            blocks.setdefault(p // 4, []).append(names[int(ch)] + _PLACE[p % 4])
+    lowest = powers[-1] if len(digits) else 0
+    return "".join("".join(blocks[b]) + _GROUP[b] for b in sorted(blocks, reverse=True) if 4 * b >= lowest)
+
+
 def number_to_korean(m, is_count=False):
-    """One number (a regex match) -> Korean words; ``is_count``: native numerals, the count word (group 2) is kept."""
-    if is_count:
-        num_str, unit = m.group(1), m.group(2)
-    else:
-        num_str, unit = m.group(), ""
-    num_str = num_str.replace(",", "")
-    value = ast.literal_eval(num_str)              # as the reference: rejects e.g. leading zeros
-    if value == 0:
-        return "영"
-    pieces = num_str.split(".")
-    if len(pieces) == 2:
-        digits, fraction = pieces
-    elif len(pieces) >= 3:
-        raise Exception(" [!] Wrong number format")
-    else:
-        digits, fraction = pieces[0], None
-    if is_count and fraction is not None:
-        raise Exception(" [!] `is_count` and float number does not fit each other")
-    n = int(digits)
-    if digits.startswith("-"):
-        n, digits = abs(n), str(abs(n))
-    size = len(str(n))
-    names = _NATIVE if is_count else _SINO
-    words, group = "", []
-    for i, d in enumerate(digits, start=1):
-        d = int(d)
-        if d != 0:
-            group += names[d]                      # character by character, as a list
-            group += _PLACE[(size - i) % 4]
-        if (size - i) % 4 == 0 and group:
-            words += "".join(group)
-            group = []
-            words += _GROUP[int((size - i) / 4)]
-    if is_count:
-        if words.startswith("한") and len(words) > 1:
-            words = words[1:]
-        if any(k in words for k in _NATIVE_TENS):
-            words = _NATIVE_TENS_RE.sub(lambda x: _NATIVE_TENS[x.group()], words)
-    if not is_count and words.startswith("일") and len(words) > 1:
+    """One number (a regex match) -> Korean words (reference text/korean.py:256-325).  ``is_count``: the number stands in front of a
+    count word (group 2, kept): native numerals, and only group 1 - sign, digits, commas - is read, so a decimal part is lost."""
+    literal = (m.group(1) if is_count else m.group()).replace(",", "")
+    unit = m.group(2) if is_count else ""
+    if ast.literal_eval(literal) == 0:              # literal_eval as the reference: a leading zero on an integer is a SyntaxError
+        return "영"                                 # (the count word is lost with it)
+    whole, dot, fraction = literal.partition(".")
+    sign = {"-": "마이너스 ", "+": "플러스 "}.get(whole[0], "")
+    if whole[0] == "+":
+        int("+")                                    # the reference converts the string character by character: ValueError
+    if whole[0] == "-":
+        whole = str(abs(int(whole)))
+    words = _name_integer(whole, _NATIVE if is_count else _SINO)
+    leading_one = "한" if is_count else "일"        # 일십 -> 십, 한백 -> 백, but a bare 일 / 한 stays
+    if len(words) > 1 and words.startswith(leading_one):
         words = words[1:]
-    if fraction is not None:
-        words += "쩜 "
-        words += re.sub(r"\d", lambda x: _DIGIT_NAMES[x.group()], fraction)
-    if num_str.startswith("+"):
-        words = "플러스 " + words
-    elif num_str.startswith("-"):
-        words = "마이너스 " + words
-    return words + unit
+    if is_count:
+        words = _NATIVE_TENS_RE.sub(lambda t: _NATIVE_TENS[t.group()], words)
+    if dot:
+        words += "쩜 " + "".join(_DIGIT_NAMES[d] for d in fraction)
+    return sign + words + unit
 
 
 def normalize_number(text):

@@ -62,6 +62,12 @@ INPUTS = [
     # mixed
     "2017년 9월 12일 오후 12시에 KTX를 타고 100km를 갔다", "JTBC 뉴스룸 8시", "코스피 2,400선 3.5% 상승",
     "LA에서 5명", "10% 20% 30%", "1,2,3", "3-4", "A4 용지 500장", "V3", "  앞뒤 공백 1개  ",
+    # number corners (round 3): trailing dot, zeros in front of a decimal point, every block name, zeros inside blocks, signs
+    # with count words, counts >= 100, a rejected literal (leading zero on an integer)
+    "3.", "7.0", "00.5", "05.5", "007.5", "00012345.5", "0000012.5", "10.05", "1000.001", "-0", "0.0", "-0.0",
+    "10001", "10010", "100100", "1000000", "10000000", "1000000000000", "10000000000000000", "100000000000000000000",
+    "99999999", "100020003", "9007199254740993", "110개", "111명", "1000명", "1234개", "10000개", "20000마리", "-3개", "-12.5개",
+    "1,234.5", "12,34", "3.14.15", "1.2개", "90살", "60세 70살 80명", "007", "1000000000000000000000000",
 ]
 
 

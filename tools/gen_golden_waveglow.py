@@ -101,6 +101,39 @@ def run_forward(name, cfg, batch, n_samples, seed, store_z=True, grads=False, gr
     print(name, "loss", out["loss"], "z std", float(z.std()))
 
 
+def run_train_full(name, cfg, batch, n_samples, seed, sample=2048):
+    """BASELINE configs[3] at the BENCHMARKED shape (8 x 16000, config.json defaults): loss and every parameter gradient of the
+    reference.  WaveGlow has no coupling between batch entries (no BatchNorm; the loss is a sum over entries divided by the
+    element count), so the batch gradient is the mean of the per-entry gradients: `batch` reference backward passes at B = 1
+    (a few GB each instead of ~40 GB at once), accumulated in f64."""
+    sd = synth.waveglow_state(cfg)
+    mel, audio = synth.waveglow_inputs(batch, n_samples, seed=seed)
+    m = build_ref(cfg, sd)
+    m.train()
+    named = dict(m.named_parameters())
+    names = sorted(named)
+    acc = {n: torch.zeros_like(named[n], dtype=torch.float64) for n in names}
+    loss_sum = 0.0
+    for b in range(batch):
+        m.zero_grad(set_to_none=True)
+        z, log_s, log_det = m((mel[b:b + 1], audio[b:b + 1]))
+        loss = ref_glow.WaveGlowLoss(1.0)((z, log_s, [d.clone() for d in log_det]))
+        loss.backward()
+        loss_sum += float(loss)
+        for n in names:
+            acc[n] += named[n].grad.double()
+        print("  entry", b, "loss", float(loss), flush=True)
+    out = {"loss": np.float64(loss_sum / batch), "all_names": np.array(names)}
+    out["all_gradsum"] = np.array([(acc[n] / batch).sum().item() for n in names], dtype=np.float64)
+    out["all_gradsq"] = np.array([((acc[n] / batch) ** 2).sum().item() for n in names], dtype=np.float64)
+    for key in grad_keys_full():
+        gflat = (acc[key] / batch).flatten()
+        step = max(1, gflat.numel() // sample)
+        out["grad::" + key] = gflat[::step].float().contiguous().numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "loss", out["loss"])
+
+
 def run_infer(name, cfg, batch, frames, seed, sigma):
     sd = synth.waveglow_state(cfg)
     gen = torch.Generator().manual_seed(seed)
@@ -127,7 +160,12 @@ def run_infer(name, cfg, batch, frames, seed, sigma):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also run the 512-channel 8x16000 config (~1 min)")
+    ap.add_argument("--train-full", action="store_true", help="ONLY the 8x16000 training-step fixture (8 reference backward passes)")
     args = ap.parse_args()
+    if args.train_full:
+        torch.set_num_threads(8)
+        run_train_full("waveglow_train_full_grads", synth.WAVEGLOW_DEFAULT, 8, 16000, seed=31)
+        sys.exit(0)
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     run_forward("waveglow_small_fwd", synth.WAVEGLOW_SMALL, 2, 4096, seed=31)
