@@ -208,6 +208,12 @@ int t2s_embed_planes(const long* ids, const float* emb, int B, int T, int E, int
                      void* X_lo, void* stream);
 /* [B][C][L] f32 -> planes */
 int t2s_f32_to_planes(const float* x, int B, int C, int L, int Lp, int halo, void* X_hi, void* X_lo, void* stream);
+/* Tacotron.parse_output (reference tacotron.py:67-76): mel[b][:, t] = mel_post[b][:, t] = 0 and gate[b][t] = 1e3 for
+ * t >= lengths[b], in place.  mel, mel_post: [B][n_mel][T] f32; gate: [B][T] f32; lengths: [B] int32 in device memory.
+ * The reference does this with .data.masked_fill_ AFTER the postnet has run, i.e. on the very tensor the postnet's first
+ * convolution saved for its backward pass: its weight gradient sees the masked mel (the training path re-derives that
+ * convolution's saved input planes from the masked tensor, text2speech_amd/tacotron/tacotron.py). */
+int t2s_taco_parse_output(float* mel, float* mel_post, float* gate, const int* lengths, int B, int n_mel, int T, void* stream);
 /* eval BatchNorm folded into the preceding conv: scale = gamma/sqrt(var+eps), bias' = (bias-mean)*scale+beta */
 int t2s_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, const float* conv_bias,
                 float eps, int C, float* scale, float* bias_out, void* stream);

@@ -18,10 +18,17 @@ import torch.nn.functional as F
 BN_EPS = 1e-5
 
 
-def _conv_bn(sd, prefix, x, training):
-    """ConvNorm + BatchNorm1d (reference tacotron.py:177-186 / modules.py:105-129)."""
+def _conv_bn(sd, prefix, x, training, x_saved=None):
+    """ConvNorm + BatchNorm1d (reference tacotron.py:177-186 / modules.py:105-129).  x_saved: what the reference's autograd
+    holds as this convolution's input when its backward runs, if that differs from x (see postnet)."""
     w, b = sd[prefix + ".0.conv.weight"], sd[prefix + ".0.conv.bias"]
-    y = F.conv1d(x, w, b, padding=(w.size(2) - 1) // 2)
+    pad = (w.size(2) - 1) // 2
+    if x_saved is None:
+        y = F.conv1d(x, w, b, padding=pad)
+    else:
+        # value and d/dx, d/dbias from conv(x, w); d/dw from x_saved: the second term is zero in value and carries only that
+        ghost = F.conv1d(x_saved.detach(), w, None, padding=pad)
+        y = F.conv1d(x, w.detach(), b, padding=pad) + (ghost - ghost.detach())
     if training:
         mean = y.mean(dim=(0, 2))
         var = y.var(dim=(0, 2), unbiased=False)
@@ -130,11 +137,13 @@ def decode_step(sd, hp, st, x, drop_a=None, drop_d=None):
     return mel, gate, st.w
 
 
-def postnet(sd, hp, x, training=False, masks=None):
-    """Postnet.forward (reference modules.py:131-137)."""
+def postnet(sd, hp, x, training=False, masks=None, x_saved=None):
+    """Postnet.forward (reference modules.py:131-137).  x_saved: the first convolution's input as the reference's backward
+    sees it - Tacotron.parse_output zeroes the padded frames of mel_outputs through ``.data.masked_fill_`` (tacotron.py:73)
+    AFTER the postnet ran, on the tensor that convolution saved, so its weight gradient is taken against the masked mel."""
     n = hp["postnet_n_convolutions"]
     for i in range(n):
-        x = _conv_bn(sd, f"postnet.convolutions.{i}", x, training)
+        x = _conv_bn(sd, f"postnet.convolutions.{i}", x, training, x_saved if i == 0 else None)
         if i < n - 1:
             x = torch.tanh(x)
         if training:
@@ -161,10 +170,13 @@ def tacotron_forward(sd, hp, text, text_lengths, mels, output_lengths, masks, tr
     mel_out = torch.stack(mel_out, 2)                         # [B, n_mel, T_out]
     gate_out = torch.stack(gate_out, 1)                       # [B, T_out]
     aligns = torch.stack(aligns, 1)                           # [B, T_out, T_in]
-    mel_post = mel_out + postnet(sd, hp, mel_out, training, masks)
+    pad = None
     if hp["mask_padding"] and output_lengths is not None:
         ids = torch.arange(T_out)
         pad = ~(ids[None, :] < output_lengths[:, None])
+    mel_post = mel_out + postnet(sd, hp, mel_out, training, masks,
+                                 None if pad is None else mel_out.masked_fill(pad.unsqueeze(1), 0.0))
+    if pad is not None:
         mel_out = mel_out.masked_fill(pad.unsqueeze(1), 0.0)
         mel_post = mel_post.masked_fill(pad.unsqueeze(1), 0.0)
         gate_out = gate_out.masked_fill(pad, 1e3)

@@ -289,6 +289,85 @@ def test_full_size_config_step_properties():
     assert losses[-1] < losses[0], losses
 
 
+def _reference_draw_order_masks(seed, B, T_in, T_out):
+    """The dropout draws of one reference training forward, regenerated from the seed in the order the reference makes them on
+    the global CPU RNG (tools/gen_golden_tacotron.py::full_size_masks)."""
+    bern = lambda shape, keep: torch.empty(*shape).bernoulli_(keep)
+    torch.manual_seed(seed)
+    enc_m = [bern((B, 512, T_in), 0.5) for _ in range(3)]
+    m1, m2 = bern((T_out + 1, B, 256), 0.5), bern((T_out + 1, B, 256), 0.5)
+    att_m, dec_m = [], []
+    for _ in range(T_out):
+        att_m.append(bern((B, 1024), 0.9))
+        dec_m.append(bern((B, 1024), 0.9))
+    post_m = [bern((B, 512 if i < 4 else 80, T_out), 0.5) for i in range(5)]
+    att_m, dec_m = torch.stack(att_m), torch.stack(dec_m)
+    w = lambda t: float((t.flatten().double() * (torch.arange(t.numel(), dtype=torch.float64) % 9973 + 1)).sum())
+    sums = [float(t.double().sum()) for t in enc_m] + [float(m1.double().sum()), float(m2.double().sum()),
+                                                      float(att_m.double().sum()), float(dec_m.double().sum())] + \
+        [float(t.double().sum()) for t in post_m] + [w(enc_m[0]), w(m1), w(att_m), w(dec_m), w(post_m[0]), w(post_m[4])]
+    u8 = lambda t: t.to(torch.uint8)
+    tm = {"enc": [u8(t) for t in enc_m], "att": u8(att_m), "dec": u8(dec_m), "post": [u8(t) for t in post_m]}
+    return tm, u8(torch.stack([m1, m2], 2)), np.array(sums, dtype=np.float64)
+
+
+def test_benchmarked_shape_b32_t800_vs_reference_golden(golden_dir):
+    """BASELINE configs[1] at the shape bench.py times (B=32, T_in 256, T_out 800, ragged as SURVEY.md 8d) against the
+    REFERENCE's own training step (tests/golden/tacotron_train_full.npz, tools/gen_golden_tacotron.py --train-full): the loss,
+    checksums and rows of the four outputs, the squared norm of every parameter gradient and strided samples of ten tensors.
+    The dropout masks are the reference's own draws, regenerated from the shipped seed (checked bit-count and weighted sums)."""
+    from text2speech_amd.tacotron import Tacotron, Tacotron2Loss
+    _lib.load()
+    g = np.load(os.path.join(golden_dir, "tacotron_train_full.npz"))
+    B, T_in, T_out = 32, 256, 800
+    tm, pm, sums = _reference_draw_order_masks(int(g["seed"]), B, T_in, T_out)
+    assert np.array_equal(sums, g["mask_sums"]), "the CPU RNG on this box does not reproduce the reference's dropout draws"
+    gen = torch.Generator().manual_seed(21)
+    text, in_len, mel_t, gate_t, out_len = _ragged(B, T_in, T_out, gen, din=lambda i: 4 * i, dout=lambda i: 12 * i)
+    m = Tacotron(HP, 80, num_speakers=2)
+    m.load_state_dict(synth.tacotron_state(), strict=True)
+    m = m.to(DEV).train()
+    x = (text.to(DEV), in_len.to(DEV), mel_t.to(DEV), int(in_len.max()), torch.zeros(B, device=DEV), out_len.to(DEV))
+    out = m(x, prenet_masks=pm, train_masks=tm)
+    loss = Tacotron2Loss()(out, (mel_t.to(DEV), gate_t.to(DEV)))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(g["loss"])) < 2e-4 * float(g["loss"]), (float(loss), float(g["loss"]))
+    for i, nm in enumerate(["mel", "mel_post", "gate", "align"]):
+        o = out[i].detach().double()
+        if nm == "gate":
+            o = torch.where(o == 1e3, torch.zeros_like(o), o)
+        sq = float((o ** 2).sum())
+        assert abs(sq - float(g[nm + "_sq"])) < 2e-3 * float(g[nm + "_sq"]), nm
+    rows = torch.stack([out[1][0, :, 0], out[1][0, :, 399], out[1][0, :, 799], out[1][31, :, 0], out[1][31, :, 427]])
+    assert _rel(rows, g["mel_rows"]) < 1e-3
+    arows = torch.stack([out[3][0, 10], out[3][0, 700], out[3][31, 400]])
+    assert _rel(arows, g["align_rows"]) < 1e-3
+    got = {n: p.grad.detach() for n, p in m.named_parameters() if p.grad is not None}
+    names = [str(n) for n in g["all_names"]]
+    assert sorted(names) == sorted(got)
+    worst_sq = []
+    for n, gq in zip(names, g["all_gradsq"]):
+        sq = float((got[n].double() ** 2).sum())
+        # conv biases in front of a batch-statistics BatchNorm: the true gradient is zero, both sides are rounding noise
+        if gq < 1e-9:
+            assert sq < 1e-8, (n, sq, gq)
+            continue
+        worst_sq.append((abs(sq - gq) / gq, n))
+    worst_sq.sort(reverse=True)
+    assert worst_sq[0][0] < 1e-2, worst_sq[:6]
+    worst = []
+    for key in g.files:
+        if key.startswith("grad::"):
+            name = key[len("grad::"):]
+            flat = got[name].flatten()
+            worst.append((_rel(flat[::max(1, flat.numel() // 4096)], g[key]), name))
+    worst.sort(reverse=True)
+    assert len(worst) == 10 and worst[0][0] < 5e-3, worst[:4]
+    print("B=32 T_out=800 step vs reference: loss %.6f / %.6f, worst |dsq|/sq %.2e (%s), worst sampled rel %.2e (%s)"
+          % (float(loss), float(g["loss"]), worst_sq[0][0], worst_sq[0][1], worst[0][0], worst[0][1]))
+
+
 def test_dropout_masks_fresh_per_call_and_reproducible():
     """Every training forward / inference draws NEW dropout masks (reference: F.dropout on the global RNG,
     modules.py:21, tacotron.py:193,368,383) and torch.manual_seed reproduces them."""

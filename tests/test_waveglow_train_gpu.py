@@ -95,6 +95,62 @@ def test_config_defaults_512ch_grads_vs_reference_golden(trained512, golden_dir)
     assert n_samples >= 100
 
 
+def test_benchmarked_shape_8x16000_vs_reference_golden(golden_dir):
+    """BASELINE configs[3] at the shape bench.py times (8 x 16000, config.json defaults; split-K of the weight-gradient GEMMs
+    = 7 / 21 slabs here against 4 at 2 x 4096): loss, the squared norm and the sum of EVERY one of the 938 parameter gradients,
+    and strided samples of one tensor of every kind in flows 0, 5, 11, against the reference's own gradients
+    (tests/golden/waveglow_train_full_grads.npz = eight reference backward passes at B = 1, averaged: tools/gen_golden_waveglow.py
+    --train-full)."""
+    from text2speech_amd.glow import WaveGlow, WaveGlowLoss
+    _lib.load()
+    g = np.load(os.path.join(golden_dir, "waveglow_train_full_grads.npz"))
+    cfg = synth.WAVEGLOW_DEFAULT
+    mel, audio = synth.waveglow_inputs(8, 16000, seed=31)
+    m = WaveGlow(**cfg)
+    m.load_state_dict(synth.waveglow_state(cfg))
+    m = m.to(DEV).train()
+    loss = WaveGlowLoss(1.0)(m((mel.to(DEV), audio.to(DEV))))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(g["loss"])) < 1e-4, (float(loss), float(g["loss"]))
+    got = {n: p.grad.detach() for n, p in m.named_parameters() if p.grad is not None}
+    names = [str(n) for n in g["all_names"]]
+    assert sorted(names) == sorted(got) and len(names) == 938
+    worst_sq = 0.0
+    for n, gq, gs in zip(names, g["all_gradsq"], g["all_gradsum"]):
+        gr = got[n].double()
+        sq = float((gr ** 2).sum())
+        worst_sq = max(worst_sq, abs(sq - gq) / gq)
+        assert abs(sq - gq) <= 5e-3 * gq + 1e-14, (n, sq, gq)
+        # the plain sum cancels: hold it to 2e-3 of the tensor's 1-norm scale sqrt(numel * sum of squares)
+        assert abs(float(gr.sum()) - gs) <= 2e-3 * (gr.numel() * gq) ** 0.5 + 1e-12, (n, float(gr.sum()), gs)
+    worst = 0.0
+    n_samples = 0
+    for key in g.files:
+        if not key.startswith("grad::"):
+            continue
+        name = key[len("grad::"):]
+        flat = got[name].flatten()
+        step = max(1, flat.numel() // 2048)
+        r = _rel(flat[::step], g[key])
+        worst = max(worst, r)
+        assert r < 2e-3, (name, r)
+        n_samples += 1
+    assert n_samples >= 100
+    print("8x16000 train step vs reference: worst |dsq|/sq %.2e, worst sampled rel %.2e" % (worst_sq, worst))
+
+
+def test_four_layer_wn_grads_vs_oracle():
+    """n_layers = 4: the largest dilated tap offset is 8 rows, less than the 32-row K-block of the channel-last weight-gradient
+    GEMM - the plane margin is rounded up to 32 rows (glow._Engine.geom) so that its shifted K-blocks stay inside the planes."""
+    cfg = dict(synth.WAVEGLOW_SMALL, WN_config=dict(n_layers=4, n_channels=64, kernel_size=3))
+    t = _train_once(cfg, 2, 2048, 35)
+    assert t["model"]._eng().geom()["halo"] == 32
+    assert abs(t["loss"] - t["loss_o"]) < 1e-4
+    worst = sorted(((_rel(t["got"][n], w), n) for n, w in t["want"].items()), reverse=True)
+    assert len(t["got"]) == t["n_params"] and worst[0][0] < 2e-3, worst[:6]
+
+
 def test_config_defaults_512ch_backward_is_bitwise_reproducible(trained512):
     from text2speech_amd.glow import WaveGlowLoss
     m = trained512["model"]

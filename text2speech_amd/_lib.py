@@ -53,6 +53,7 @@ SIGNATURES = {
     "t2s_transpose": [c_vp, c_vp, c_int, c_int, c_vp],
     "t2s_embed_planes": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
     "t2s_f32_to_planes": [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
+    "t2s_taco_parse_output": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "t2s_bn_fold": [c_vp, c_vp, c_vp, c_vp, c_vp, c_float, c_int, c_vp, c_vp, c_vp],
     "t2s_bn_train": [c_vp, c_vp, c_vp, c_float, c_int, c_vp, c_float, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp,
                      c_vp, c_vp, c_vp],

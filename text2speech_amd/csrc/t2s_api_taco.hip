@@ -65,6 +65,12 @@ int t2s_f32_to_planes(const float* x, int B, int C, int L, int Lp, int halo, voi
     return T2S_OK;
 }
 
+int t2s_taco_parse_output(float* mel, float* mel_post, float* gate, const int* lengths, int B, int n_mel, int T, void* stream) {
+    if (!mel || !mel_post || !gate || !lengths || B <= 0 || n_mel <= 0 || T <= 0 || B > 65535 || n_mel >= 65535) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_parse_output(mel, mel_post, gate, lengths, B, n_mel, T, (hipStream_t)stream));
+    return T2S_OK;
+}
+
 int t2s_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, const float* conv_bias,
                 float eps, int C, float* scale, float* bias_out, void* stream) {
     if (!gamma || !beta || !mean || !var || !scale || !bias_out || C <= 0) return T2S_EINVAL;

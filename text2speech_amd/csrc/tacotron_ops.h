@@ -84,6 +84,8 @@ hipError_t t2s_launch_embed_planes(const long* ids, const float* emb, int B, int
                                    unsigned short* X_hi, unsigned short* X_lo, hipStream_t stream);
 hipError_t t2s_launch_f32_to_planes(const float* x, int B, int C, int L, int Lp, int halo, unsigned short* X_hi,
                                     unsigned short* X_lo, hipStream_t stream);
+hipError_t t2s_launch_parse_output(float* mel, float* mel_post, float* gate, const int* lengths, int B, int n_mel, int T,
+                                   hipStream_t stream);
 hipError_t t2s_launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
                               const float* conv_bias, float eps, int C, float* scale, float* bias_out,
                               hipStream_t stream);

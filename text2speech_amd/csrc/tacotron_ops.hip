@@ -1183,6 +1183,27 @@ hipError_t t2s_launch_f32_to_planes(const float* x, int B, int C, int L, int Lp,
     return hipGetLastError();
 }
 
+// Tacotron.parse_output (reference tacotron.py:67-76): beyond each entry's output length the two mel tensors become 0 and the
+// gate energies 1e3, in place, one launch.  Row n_mel of the grid is the gate row.
+__global__ void parse_output_kernel(float* mel, float* mel_post, float* gate, const int* lengths, int n_mel, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (t >= T || t < lengths[b]) return;
+    if (c < n_mel) {
+        const size_t i = ((size_t)b * n_mel + c) * T + t;
+        mel[i] = 0.f;
+        mel_post[i] = 0.f;
+    } else {
+        gate[(size_t)b * T + t] = 1e3f;
+    }
+}
+hipError_t t2s_launch_parse_output(float* mel, float* mel_post, float* gate, const int* lengths, int B, int n_mel, int T,
+                                   hipStream_t stream) {
+    hipLaunchKernelGGL(parse_output_kernel, dim3((T + 255) / 256, n_mel + 1, B), dim3(256), 0, stream, mel, mel_post, gate,
+                       lengths, n_mel, T);
+    return hipGetLastError();
+}
+
 // eval-mode BatchNorm folded into the preceding conv: scale[o] = gamma/sqrt(var+eps),
 // bias'[o] = (bias[o] - mean[o]) * scale[o] + beta[o]      (tacotron.py:183-184, modules.py:105-129)
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* mean, const float* var,

@@ -492,6 +492,18 @@ class _TacoEngine:
         mel = proj[:, :, :n_mel].permute(1, 2, 0).contiguous()
         gate = proj[:, :, n_mel].permute(1, 0).contiguous()
         mel_post = mel + self.postnet(mel, train_masks, seed, save=save)
+        # Tacotron.parse_output (reference tacotron.py:67-76) here, in one launch.  The reference fills through `.data` AFTER the
+        # postnet has run, on the tensor the postnet's first convolution saved for backward: that convolution's weight gradient
+        # is taken against the MASKED mel.  Same here: its saved input planes are re-derived from the masked tensor.
+        if m.hparams["mask_padding"] and output_lengths is not None:
+            olen32 = output_lengths.to(device=dev, dtype=torch.int32).contiguous()
+            _lib.call("t2s_taco_parse_output", _lib.ptr(mel), _lib.ptr(mel_post), _lib.ptr(gate), _lib.ptr(olen32), B, n_mel, T_out,
+                      _lib.current_stream())
+            if save is not None and save.get("post_convs"):
+                s0 = save["post_convs"][0]
+                _lib.call("t2s_f32_to_planes", _lib.ptr(mel), B, n_mel, T_out, s0["Lp"], s0["halo"], _lib.ptr(s0["Xh"]),
+                          _lib.ptr(s0["Xl"]), _lib.current_stream())
+            self._keep_olen = olen32
         if save is not None:
             save.update(S=S, frames=frames, p1=p1, pre_all=pre_all, hc_all=hc_all, prenet_masks=mk, len32=len32, B=B, T_out=T_out,
                         n_mel=n_mel)
@@ -541,13 +553,13 @@ class Tacotron(nn.Module):
         self._check(text_inputs)
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .autograd import tacotron_forward_with_grad
-            out = tacotron_forward_with_grad(self, text_inputs, text_lengths.data, mels, output_lengths.data, prenet_masks,
-                                             train_masks)
-            return self.parse_output(out, output_lengths.data)
+            # parse_output (tacotron.py:49) has been applied by the engine: one HIP launch inside the forward, see there
+            return list(tacotron_forward_with_grad(self, text_inputs, text_lengths.data, mels, output_lengths.data, prenet_masks,
+                                                   train_masks))
         with torch.no_grad():
             out = self._eng().forward(text_inputs, text_lengths.data, mels, output_lengths.data, prenet_masks,
                                       train_masks=train_masks)
-        return self._as_module_dtype(self.parse_output(out, output_lengths.data))
+        return self._as_module_dtype(out)
 
     def inference(self, inputs, speaker_id=None, prenet_masks=None):
         """Autoregressive decode (reference tacotron.py:51-65)."""
@@ -569,6 +581,14 @@ class Tacotron(nn.Module):
     def parse_output(self, outputs, output_lengths=None):
         """Reference tacotron.py:67-76: zero mel / 1e3 gate beyond each output length."""
         if self.hparams["mask_padding"] and output_lengths is not None:
+            o0, o1, o2 = outputs[0].data, outputs[1].data, outputs[2].data
+            B, n_mel, T = o0.shape
+            if all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in (o0, o1, o2)) and o2.numel() == B * T \
+                    and int(output_lengths.numel()) == B:
+                olen32 = output_lengths.to(device=o0.device, dtype=torch.int32).contiguous()
+                _lib.call("t2s_taco_parse_output", _lib.ptr(o0), _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(olen32), B, n_mel, T,
+                          _lib.current_stream())
+                return outputs
             mask = ~get_mask_from_lengths(output_lengths.to(outputs[0].device))
             T = outputs[0].size(2)
             if mask.size(1) < T:

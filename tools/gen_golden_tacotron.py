@@ -143,11 +143,16 @@ def gen_forward_train(seed=13):
     for key in ["decoder.attention_rnn.weight_hh", "decoder.linear_projection.linear_layer.weight",
                 "decoder.attention_layer.location_layer.location_conv.conv.weight",
                 "encoder.lstm.weight_hh_l0_reverse", "encoder.convolutions.0.0.conv.weight",
-                "postnet.convolutions.4.0.conv.weight", "embedding.weight", "decoder.prenet.layers.0.linear_layer.weight"]:
+                "postnet.convolutions.4.0.conv.weight", "embedding.weight", "decoder.prenet.layers.0.linear_layer.weight",
+                # its saved input is zeroed on padded frames by parse_output's .data.masked_fill_ before backward runs
+                "postnet.convolutions.0.0.conv.weight"]:
         g = named[key].grad.detach().flatten()
         step = max(1, g.numel() // 16384)
         grads["grad::" + key] = g[::step].contiguous().numpy()
         grads["gradsq::" + key] = np.float64((g.double() ** 2).sum().item())
+    names = sorted(n for n, p_ in named.items() if p_.grad is not None)
+    grads["all_names"] = np.array(names)
+    grads["all_gradsq"] = np.array([(named[n].grad.double() ** 2).sum().item() for n in names], dtype=np.float64)
     np.savez_compressed(os.path.join(OUT, "tacotron_fwd_train.npz"), mel=out[0].detach().numpy(),
                         mel_post=out[1].detach().numpy(), gate=out[2].detach().numpy(), align=out[3].detach().numpy(),
                         loss=np.float64(loss.item()),
