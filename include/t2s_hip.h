@@ -139,6 +139,10 @@ typedef struct t2s_endfold_job {
 } t2s_endfold_job;
 /* jobs: DEVICE array, one per WN layer; run after the weight packing that produced `scale` */
 int t2s_wg_endfold_weights(const t2s_endfold_job* jobs, int n_jobs, int C, void* stream);
+/* Tile height (256 or 128 packed rows) the folded gate GEMM uses for this shape: 128 where 256-row tiles would leave at least
+ * half the chip without a workgroup (short utterances).  t2s_wg_gate_fold_slots follows it; t2s_wg_in_melwin_gate_fold (phase
+ * tiles, always 256 rows) returns T2S_EINVAL for shapes where this is 128. */
+int t2s_wg_gate_tile_rows(int B, int C, int L);
 /* t2s_wg_in_cond_gate plus fold_acc[slot][b][j][t] (+)= (W_end W_skip,i)[j] . acts[:, t] over the slot's channels; C % 16 == 0.
  * fold_acc holds t2s_wg_gate_fold_slots(B, C, L) slots of [B][8][L] floats: 2*ceil(C/128) with the 256-row tiles, 2*ceil(C/64) when
  * the shape takes 128-row tiles (a grid of 256-row tiles that would leave half of the CUs idle: short utterances at B = 1).
@@ -337,7 +341,11 @@ int t2s_wgrad_gemm_flat(const void* A_hi, const void* A_lo, const void* X_hi, co
  *   hi / lo  = device pointers to plane row 0 of that chunk for batch entry 0 (a dilated tap is a row offset folded into the
  *              pointer: the autograd of in_layers[i], glow.py:134-139, needs x shifted by (tap - 1) * dilation);
  *   bstride  = u16 elements between batch entries (0 for constants such as the all-ones bias chunk).
- * out = [nsplit][M][N] f32 slabs over K-blocks [k0, k1) of 32 plane rows of each of the B batch entries, as t2s_wgrad_gemm_flat.
+ * out = [nsplit][M][ldp] f32 slabs (ldp >= N floats per row; columns N .. ldp-1 are scratch) over K-blocks [k0, k1) of 32 plane
+ * rows of each of the B batch entries, as t2s_wgrad_gemm_flat.  ldp % 4 == 0 (and out 16-byte aligned) selects the ping-pong
+ * kernel, whose epilogue stores 16-byte pieces; any other ldp the round-2 lockstep kernel (also: env T2S_WGRAD_PP=0).
+ * Every K-block is a WHOLE block of 32 plane rows starting at row 32 k (+ the shift folded into the pointer): the caller makes
+ * sure rows [32 k0 - max shift, 32 k1 + max shift) exist in every plane (halo % 32 == 0 does, text2speech_amd/glow.py geom()).
  * Both tables live in device memory ([n_tiles * 8] entries).  Replaces 7 t2s_plane_transpose launches per WN layer. */
 typedef struct t2s_wgrad_chunk {
     const void* hi;
@@ -345,7 +353,7 @@ typedef struct t2s_wgrad_chunk {
     long bstride;
 } t2s_wgrad_chunk;
 int t2s_wgrad_cl(const t2s_wgrad_chunk* a_chunks, int n_a_chunks, const t2s_wgrad_chunk* b_chunks, int n_b_chunks, float* out,
-                 int B, int M, int N, int k0, int k1, int nsplit, void* stream);
+                 int B, int M, int N, int ldp, int k0, int k1, int nsplit, void* stream);
 
 int t2s_plane_transpose(const void* src_hi, const void* src_lo, int B, int src_chunks, int n_chunks, int Lp, int shift,
                         void* dst_hi, void* dst_lo, int Npad, int n_off, void* stream);
@@ -359,8 +367,10 @@ int t2s_weightnorm_scale(const float* v, const float* g, int O, int K, float* sc
 int t2s_wn_backward(const float* P, int nsplit, int Prows, int Pcols, int row_off, int col_off, int tap_stride,
                     int col_bias, const float* v, const float* g, int O, int Cin, int Kt, float* dv, float* dg,
                     float* db, int db_accum, void* stream);
-/* affine coupling backward + un-apply (glow.py:241-246); wn_out = (b ; log_s) [B][2nh][L], d_out gets (d_b ; d_log_s) */
-int t2s_wg_affine_backward(float* z, float* dz, const float* wn_out, const float* g_log_s, float* d_out, int B,
+/* affine coupling backward + un-apply (glow.py:241-246); wn_out = (b ; log_s) [B][2nh][L], d_out gets (d_b ; d_log_s).
+ * g_log_s = upstream gradient of this flow's log_s output: [B][nh][L], or - g_log_s_scalar != 0 - ONE float that stands for
+ * every element (WaveGlowLoss's gradient is the constant -1/N broadcast, glow.py:52-58), or NULL for none. */
+int t2s_wg_affine_backward(float* z, float* dz, const float* wn_out, const float* g_log_s, int g_log_s_scalar, float* d_out, int B,
                            int n_group, int c_off, int n_half, int L, void* stream);
 /* out[r][j] (or [j][r]) = sum_{b,t} P[b][r][t] * Q[b][q_off+j][t], rowsum[r] = sum P; P = planes (hi/lo, or f32).
  * scratch: t2s_small_wgrad_scratch(B, chunks) floats of partial sums (reduced in a fixed order: deterministic). */
@@ -471,9 +481,12 @@ typedef struct t2s_bn_bwd_args {
 } t2s_bn_bwd_args;
 /* training-mode BatchNorm1d backward fused with the backward of activation + dropout; dx as planes */
 int t2s_bn_bwd(const t2s_bn_bwd_args* a, void* stream);
-/* out[j] = sum_i in[i][j] ; out = a + b (+ c) */
+/* out[j] = sum_i in[i][j] ; out = a (+ b) (+ c): b and c optional, so it is also the stream-ordered copy of an f32 buffer */
 int t2s_sum_axis0(const float* in, int n0, int n, float* out, void* stream);
 int t2s_add3(const float* a, const float* b, const float* c, size_t n, float* out, void* stream);
+/* out[i] = (in ? in[i] : 1) * scalar[0] * mul, scalar in DEVICE memory: how a loss hands its saved gradient times the upstream
+ * gradient (a 0-dim device tensor in `loss.backward()`, waveglow/train.py:122) to the model's backward without an eager operator */
+int t2s_scale_by_scalar(const float* in, size_t n, const float* scalar, float mul, float* out, void* stream);
 /* planes -> f32 [B][C][L] (accumulate=1: +=) */
 int t2s_planes_to_f32(const void* X_hi, const void* X_lo, int B, int C, int L, int Lp, int halo, float* out,
                       int accumulate, void* stream);

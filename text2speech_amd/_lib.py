@@ -38,6 +38,7 @@ SIGNATURES = {
     "t2s_wg_endfold_weights": [c_vp, c_int, c_int, c_vp],
     "t2s_wg_in_cond_gate_fold": [c_vp] * 11 + [c_int] * 10 + [c_vp],
     "t2s_wg_gate_fold_slots": [c_int, c_int, c_int],
+    "t2s_wg_gate_tile_rows": [c_int, c_int, c_int],
     "t2s_wg_upsample_basis": [c_vp, c_vp] + [c_int] * 6 + [c_vp, c_vp, c_vp],
     "t2s_wg_compose_cond": [c_vp, c_vp] + [c_int] * 4 + [c_long, c_vp, c_vp, c_vp, c_vp],
     "t2s_wg_melwin_planes": [c_vp] + [c_int] * 5 + [c_vp, c_vp, c_vp],
@@ -79,6 +80,7 @@ SIGNATURES = {
                          c_vp],
     "t2s_sum_axis0": [c_vp, c_int, c_int, c_vp, c_vp],
     "t2s_add3": [c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp],
+    "t2s_scale_by_scalar": [c_vp, ctypes.c_size_t, c_vp, c_float, c_vp, c_vp],
     "t2s_planes_to_f32": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp],
     "t2s_wg_in_cond_gate_train": [c_vp] * 13 + [c_int] * 9 + [c_vp],
     "t2s_wg_res_skip_train": [c_vp] * 10 + [c_int] * 8 + [c_vp],
@@ -86,14 +88,14 @@ SIGNATURES = {
     "t2s_conv_accumulate": [c_vp] * 7 + [c_int] * 10 + [c_vp],
     "t2s_wgrad_gemm": [c_vp] * 6 + [c_int] * 9 + [c_vp],
     "t2s_wgrad_gemm_flat": [c_vp] * 6 + [c_int] * 9 + [c_vp],
-    "t2s_wgrad_cl": [c_vp, c_int, c_vp, c_int, c_vp] + [c_int] * 6 + [c_vp],
+    "t2s_wgrad_cl": [c_vp, c_int, c_vp, c_int, c_vp] + [c_int] * 7 + [c_vp],
     "t2s_plane_transpose": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp],
     "t2s_tm_ones_row": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
     "t2s_pack_transposed": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
     "t2s_weightnorm_scale": [c_vp, c_vp, c_int, c_int, c_vp, c_vp],
     "t2s_wn_backward": [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp,
                         c_vp, c_int, c_vp],
-    "t2s_wg_affine_backward": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
+    "t2s_wg_affine_backward": [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
     "t2s_small_wgrad_scratch": [c_int, c_int],
     "t2s_small_wgrad": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                         c_int, c_vp],

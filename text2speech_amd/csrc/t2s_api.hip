@@ -26,7 +26,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 extern "C" {
 
-int t2s_abi_version(void) { return 1; }
+int t2s_abi_version(void) { return 3; }
 
 const char* t2s_error_string(int code) {
     switch (code) {
@@ -197,6 +197,11 @@ static int gate_tile_rows(int B, int C, int L) {
     return (wg256 <= 128 && C % 64 == 0) ? 128 : 256;
 }
 
+int t2s_wg_gate_tile_rows(int B, int C, int L) {
+    if (B <= 0 || C <= 0 || L <= 0) return T2S_EINVAL;
+    return gate_tile_rows(B, C, L);
+}
+
 int t2s_wg_gate_fold_slots(int B, int C, int L) {
     if (B <= 0 || C <= 0 || L <= 0) return T2S_EINVAL;
     return gate_tile_rows(B, C, L) == 128 ? 2 * cdiv(C, 64) : 2 * cdiv(C, 128);
@@ -270,6 +275,8 @@ int t2s_wg_in_melwin_gate_fold(const void* A_hi, const void* A_lo, const void* A
     if (Mpad % 256 || Mpad < cdiv(C, 128) * 256 || !aligned16(bias) || P <= 0) return T2S_EINVAL;
     const int F = cdiv(L, P);
     if (Fp < F) return T2S_EINVAL;
+    // the phase tiles are 256 rows high: fold_acc must have been sized (t2s_wg_gate_fold_slots) for that tile height
+    if (gate_tile_rows(B, C, L) != 256) return T2S_EINVAL;
     ConvGemmArgs a;
     memset(&a, 0, sizeof(a));
     a.A_hi = (const u16*)A_hi; a.A_lo = (const u16*)A_lo;

@@ -265,8 +265,13 @@ int t2s_sum_axis0(const float* in, int n0, int n, float* out, void* stream) {
     T2S_CHECK_HIP(t2s_launch_sum_axis0(in, n0, n, out, (hipStream_t)stream));
     return T2S_OK;
 }
+int t2s_scale_by_scalar(const float* in, size_t n, const float* scalar, float mul, float* out, void* stream) {
+    if (!scalar || !out || n == 0) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_scale_by_scalar(in, n, scalar, mul, out, (hipStream_t)stream));
+    return T2S_OK;
+}
 int t2s_add3(const float* a, const float* b, const float* c, size_t n, float* out, void* stream) {
-    if (!a || !b || !out || n == 0) return T2S_EINVAL;
+    if (!a || !out || n == 0) return T2S_EINVAL;
     T2S_CHECK_HIP(t2s_launch_add3(a, b, c, n, out, (hipStream_t)stream));
     return T2S_OK;
 }

@@ -180,14 +180,15 @@ int t2s_wgrad_gemm_flat(const void* A_hi, const void* A_lo, const void* X_hi, co
 }
 
 int t2s_wgrad_cl(const t2s_wgrad_chunk* a_chunks, int n_a_chunks, const t2s_wgrad_chunk* b_chunks, int n_b_chunks, float* out,
-                 int B, int M, int N, int k0, int k1, int nsplit, void* stream) {
+                 int B, int M, int N, int ldp, int k0, int k1, int nsplit, void* stream) {
     static_assert(sizeof(t2s_wgrad_chunk) == sizeof(WgradChunk), "t2s_wgrad_chunk layout");
     if (!a_chunks || !b_chunks || !out || B <= 0 || M <= 0 || N <= 0 || k0 < 0 || k0 >= k1 || nsplit < 1) return T2S_EINVAL;
+    if (ldp < N || (ldp % 4 == 0 && !al16(out))) return T2S_EINVAL;
     const int n_mtiles = cdiv(M, 256), n_ntiles = cdiv(N, 256);
     if (n_a_chunks != n_mtiles * 8 || n_b_chunks != n_ntiles * 8 || nsplit > B * (k1 - k0)) return T2S_EINVAL;
     WgradClArgs a;
     a.a_chunks = (const WgradChunk*)a_chunks; a.b_chunks = (const WgradChunk*)b_chunks; a.P = out;
-    a.M = M; a.N = N; a.n_mtiles = n_mtiles; a.n_ntiles = n_ntiles; a.B = B; a.k0 = k0; a.k1 = k1;
+    a.M = M; a.N = N; a.ldp = ldp; a.n_mtiles = n_mtiles; a.n_ntiles = n_ntiles; a.B = B; a.k0 = k0; a.k1 = k1;
     a.nslab = nsplit; a.kchunk = cdiv(B * (k1 - k0), nsplit);
     if ((long)a.kchunk * (nsplit - 1) >= (long)B * (k1 - k0)) return T2S_EINVAL;      // every slab must own >= 1 K-block
     T2S_CHECK_HIP(t2s_launch_wgrad_cl(a, (hipStream_t)stream));
@@ -241,11 +242,12 @@ int t2s_wn_backward(const float* P, int nsplit, int Prows, int Pcols, int row_of
     return T2S_OK;
 }
 
-int t2s_wg_affine_backward(float* z, float* dz, const float* wn_out, const float* g_log_s, float* d_out, int B,
+int t2s_wg_affine_backward(float* z, float* dz, const float* wn_out, const float* g_log_s, int g_log_s_scalar, float* d_out, int B,
                            int n_group, int c_off, int n_half, int L, void* stream) {
     if (!z || !dz || !wn_out || !d_out || B <= 0 || L <= 0 || n_half <= 0 || c_off < 0 || c_off + 2 * n_half > n_group)
         return T2S_EINVAL;
-    T2S_CHECK_HIP(t2s_launch_affine_backward(z, dz, wn_out, g_log_s, d_out, B, n_group, c_off, n_half, L, (hipStream_t)stream));
+    T2S_CHECK_HIP(t2s_launch_affine_backward(z, dz, wn_out, g_log_s, g_log_s_scalar, d_out, B, n_group, c_off, n_half, L,
+                                             (hipStream_t)stream));
     return T2S_OK;
 }
 

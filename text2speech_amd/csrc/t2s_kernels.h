@@ -75,8 +75,8 @@ struct WgradChunk {            // one 32-channel chunk of an operand; mirrors t2
 struct WgradClArgs {
     const WgradChunk* a_chunks;    // [n_mtiles * 8]  M side (output rows)
     const WgradChunk* b_chunks;    // [n_ntiles * 8]  N side (output columns)
-    float* P;                      // [nslab][M][N]
-    int M, N, n_mtiles, n_ntiles;
+    float* P;                      // [nslab][M][ldp]
+    int M, N, ldp, n_mtiles, n_ntiles;   // ldp >= N: floats per output row (a multiple of 4 selects the ping-pong kernel)
     int B, k0, k1;                 // K-blocks of 32 plane rows [k0, k1) of every batch entry
     int nslab, kchunk;             // slab s covers flattened (batch, block) steps [s * kchunk, (s + 1) * kchunk)
 };

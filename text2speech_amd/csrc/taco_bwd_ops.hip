@@ -509,7 +509,17 @@ hipError_t t2s_launch_sum_axis0(const float* in, int n0, int n, float* out, hipS
 // out = a + b (+ c)
 __global__ void add3_kernel(const float* a, const float* b, const float* c, size_t n, float* out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = a[i] + b[i] + (c ? c[i] : 0.f);
+    if (i < n) out[i] = a[i] + (b ? b[i] : 0.f) + (c ? c[i] : 0.f);
+}
+// out[i] = (in ? in[i] : 1) * scalar[0] * mul: the hand-off of an upstream gradient that lives in device memory (a loss
+// Function's backward: d loss / d z = saved gradient x upstream scalar) without a host read or an eager operator
+__global__ void scale_by_scalar_kernel(const float* in, size_t n, const float* scalar, float mul, float* out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (in ? in[i] : 1.f) * scalar[0] * mul;
+}
+hipError_t t2s_launch_scale_by_scalar(const float* in, size_t n, const float* scalar, float mul, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, n, scalar, mul, out);
+    return hipGetLastError();
 }
 hipError_t t2s_launch_add3(const float* a, const float* b, const float* c, size_t n, float* out, hipStream_t stream) {
     hipLaunchKernelGGL(add3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, b, c, n, out);

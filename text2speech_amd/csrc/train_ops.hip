@@ -169,8 +169,8 @@ hipError_t t2s_launch_wn_backward(const WnBwdArgs& a, hipStream_t stream) {
 //   a1 = (a1' - b) / exp(ls);  d_b = d_a1';  d_ls = d_a1' * a1 * exp(ls) + g_ls;  d_a1 = d_a1' * exp(ls)
 // z / dz: [B][G][L], channel c_off + nh + i; wn_out [B][2nh][L] = (b ; ls) saved by the forward;
 // d_out [B][2nh][L] receives (d_b ; d_ls).
-__global__ void affine_backward_kernel(float* z, float* dz, const float* wn_out, const float* g_ls, float* d_out, int G,
-                                       int c_off, int nh, int L) {
+__global__ void affine_backward_kernel(float* z, float* dz, const float* wn_out, const float* g_ls, int g_ls_scalar, float* d_out,
+                                       int G, int c_off, int nh, int L) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y, b = blockIdx.z;
     if (t >= L) return;
@@ -183,12 +183,13 @@ __global__ void affine_backward_kernel(float* z, float* dz, const float* wn_out,
     z[zi] = a1;
     dz[zi] = d * e;
     d_out[((size_t)b * 2 * nh + i) * L + t] = d;
-    d_out[((size_t)b * 2 * nh + nh + i) * L + t] = d * a1 * e + (g_ls ? g_ls[((size_t)b * nh + i) * L + t] : 0.f);
+    d_out[((size_t)b * 2 * nh + nh + i) * L + t] =
+        d * a1 * e + (g_ls ? (g_ls_scalar ? g_ls[0] : g_ls[((size_t)b * nh + i) * L + t]) : 0.f);
 }
-hipError_t t2s_launch_affine_backward(float* z, float* dz, const float* wn_out, const float* g_ls, float* d_out, int B,
-                                      int G, int c_off, int nh, int L, hipStream_t stream) {
+hipError_t t2s_launch_affine_backward(float* z, float* dz, const float* wn_out, const float* g_ls, int g_ls_scalar, float* d_out,
+                                      int B, int G, int c_off, int nh, int L, hipStream_t stream) {
     hipLaunchKernelGGL(affine_backward_kernel, dim3((L + 255) / 256, nh, B), dim3(256), 0, stream, z, dz, wn_out, g_ls,
-                       d_out, G, c_off, nh, L);
+                       g_ls_scalar, d_out, G, c_off, nh, L);
     return hipGetLastError();
 }
 
@@ -361,9 +362,9 @@ hipError_t t2s_launch_convinv_wgrad(const float* dz, const float* zin, const flo
 // b, the gathers of four frames are in flight together).
 template <int CI>
 __global__ __launch_bounds__(256) void upsample_wgrad_kernel(const u16* __restrict__ D_hi, const u16* __restrict__ D_lo,
-                                                             const float* __restrict__ mel, int B, int M, int F, int ksize,
+                                                             const float* __restrict__ mel, int B, int M, int F, int FT, int ksize,
                                                              int stride, int G, int L, int Lp, int halo, float* dW) {
-    extern __shared__ float s_mel[];         // [CI][F] of the current batch entry
+    extern __shared__ float s_mel[];         // [CI][FT]: a slice of FT frames of the current batch entry
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int co = blockIdx.y;
     const int ci0 = blockIdx.z * CI;
@@ -372,21 +373,24 @@ __global__ __launch_bounds__(256) void upsample_wgrad_kernel(const u16* __restri
 #pragma unroll
     for (int c = 0; c < CI; ++c) acc[c] = 0.f;
     const bool kv = k < ksize;
-    for (int b = 0; b < B; ++b) {
+    // (b, frame) ascending, the frames staged FT at a time: any segment length, the same summation order for every FT
+    for (int b = 0; b < B; ++b)
+      for (int fb = 0; fb < F; fb += FT) {
+        const int fn = min(FT, F - fb);
         __syncthreads();
-        for (int i = threadIdx.x; i < CI * F; i += 256) {
-            const int c = i / F, f = i - c * F;
-            s_mel[i] = ci0 + c < M ? mel[((size_t)b * M + ci0 + c) * F + f] : 0.f;
+        for (int i = threadIdx.x; i < CI * fn; i += 256) {
+            const int c = i / fn, f = i - c * fn;
+            s_mel[c * FT + f] = ci0 + c < M ? mel[((size_t)b * M + ci0 + c) * F + fb + f] : 0.f;
         }
         __syncthreads();
-        for (int f0 = 0; f0 < F; f0 += 4) {
+        for (int f0 = 0; f0 < fn; f0 += 4) {
             float d[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int f = f0 + u;
+                const int f = fb + f0 + u;
                 const int s = stride * f + k;
                 const int t = s / G, g = s - t * G;
-                const bool ok = kv && f < F && t < L;
+                const bool ok = kv && f0 + u < fn && t < L;
                 const int ch = co * G + g;
                 const size_t idx = (((size_t)b * nchunks + (ch >> 5)) * Lp + halo + (ok ? t : 0)) * 32 + (ch & 31);
                 const u16 h = D_hi[idx], l = D_lo[idx];          // unconditional: row halo + 0 always exists
@@ -394,12 +398,12 @@ __global__ __launch_bounds__(256) void upsample_wgrad_kernel(const u16* __restri
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (f0 + u >= F) break;
+                if (f0 + u >= fn) break;
 #pragma unroll
-                for (int c = 0; c < CI; ++c) acc[c] += s_mel[c * F + f0 + u] * d[u];
+                for (int c = 0; c < CI; ++c) acc[c] += s_mel[c * FT + f0 + u] * d[u];
             }
         }
-    }
+      }
     if (kv) {
 #pragma unroll
         for (int c = 0; c < CI; ++c)
@@ -409,9 +413,9 @@ __global__ __launch_bounds__(256) void upsample_wgrad_kernel(const u16* __restri
 hipError_t t2s_launch_upsample_wgrad(const u16* D_hi, const u16* D_lo, const float* mel, int B, int M, int F, int ksize,
                                      int stride, int G, int L, int Lp, int halo, float* dW, hipStream_t stream) {
     constexpr int CI = 20;
-    if ((size_t)CI * F * sizeof(float) > 60 * 1024) return hipErrorInvalidValue;
+    const int FT = F < 512 ? (F + 3) / 4 * 4 : 512;        // frames staged per pass: 40 KB of LDS at most, any F
     hipLaunchKernelGGL(upsample_wgrad_kernel<CI>, dim3((ksize + 255) / 256, M, (M + CI - 1) / CI), dim3(256),
-                       (size_t)CI * F * sizeof(float), stream, D_hi, D_lo, mel, B, M, F, ksize, stride, G, L, Lp, halo, dW);
+                       (size_t)CI * FT * sizeof(float), stream, D_hi, D_lo, mel, B, M, F, FT, ksize, stride, G, L, Lp, halo, dW);
     return hipGetLastError();
 }
 

@@ -25,6 +25,10 @@
 #include "t2s_common.h"
 #include "t2s_kernels.h"
 
+#include <stdlib.h>
+
+#include <type_traits>
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -43,6 +47,19 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* lds_addr) {
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_addr));
     const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_addr + 4 * 64));      // rows + 4
+    const s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// The same operand through inline assembly (the ping-pong kernel).  hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of
+// every __builtin_amdgcn_ds_read_tr16_b64 while an LDS-DMA is outstanding (it cannot tell that the read does not alias the
+// DMA's destination), which drains the fill the schedule keeps in flight; an asm statement is invisible to that pass.  The
+// caller waits (s_waitcnt lgkmcnt(0)) before the first use.  `addr` = LDS byte address, OFF = immediate byte offset (< 65280).
+template <int OFF>
+__device__ __forceinline__ bf16x8 tr_frag_asm(unsigned addr) {
+    s16x4 lo4, hi4;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo4) : "v"(addr), "n"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi4) : "v"(addr), "n"(OFF + 4 * 64));
     const s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
@@ -155,7 +172,7 @@ __global__ __launch_bounds__(512) void wgrad_cl_kernel(const WgradClArgs a) {
     }
 
     // ---- epilogue: C/D map of mfma 16x16: col = lane & 15 (n), row = 4 * (lane >> 4) + reg (m) ----
-    float* P = a.P + (size_t)slab * a.M * a.N;
+    float* P = a.P + (size_t)slab * a.M * a.ldp;
     const int ncol = lane & 15, mrow = (lane >> 4) * 4;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
@@ -166,14 +183,295 @@ __global__ __launch_bounds__(512) void wgrad_cl_kernel(const WgradClArgs a) {
             if (nn >= a.N) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (mm + e < a.M) P[(size_t)(mm + e) * a.N + nn] = acc[m][n][e];
+                if (mm + e < a.M) P[(size_t)(mm + e) * a.ldp + nn] = acc[m][n][e];
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The same GEMM on the ping-pong schedule of csrc/gate_gemm_pp.hip (round 3; the kernel above is the round-2 lockstep loop,
+// T2S_WGRAD_PP=0).  What carries over unchanged: the 256 x 256 tile, 32-step K-blocks, the LDS image and its half-row swap, the
+// DMA pieces, split-bf16 products.  What changes:
+//  * waves 0-3 / 4-7 form two groups (one wave of each on every SIMD) that run one barrier apart: in every barrier interval one
+//    wave of a SIMD issues its 24 MFMAs while its partner reads LDS (transposed 8-byte reads) and issues the fill;
+//  * a wave's 128 x 64 block is 64 rows from each 128-row half of the A tile (chunks 4h + 2 wr, + 1) and 32 columns from each
+//    half of the B tile (chunk 4h + wc): a K-step is four phases, each consuming one (A half, B half) pair, and every 8 KB
+//    half-plane of LDS is read in exactly one phase (16 / 8 / 16 / 0 ds_read_b64_tr_b16 pairs per phase);
+//  * the fill is one half-tile (hi + lo = 2 DMA instructions per wave) per phase, issued five phases ahead of its first read
+//    and retired by a counted s_waitcnt vmcnt(6) three phases later - never drained inside the loop (raw s_barrier, no
+//    __syncthreads()); the source pointers are running per-thread pointers (one add per issue; a batch boundary is a
+//    different addend, selected by a wave-uniform flag) instead of table lookups and 64-bit multiplies per K-step;
+//  * the MFMA operands are swapped (B fragment as the matrix-A operand), so a lane's four accumulator registers are four
+//    CONSECUTIVE COLUMNS of one output row: the epilogue is 32 16-byte stores per lane instead of 128 4-byte ones (the slab's
+//    leading dimension ldp is a multiple of 4 floats for that).
+// Phase table of K-step ks (LDS buffer ks & 1), as csrc/gate_gemm_pp.hip:
+//      p  reads                     MFMAs (x3)                      stages
+//      0  A half 0, B half 0        acc[0..3][0..1]                 B half 1 of K-step ks+1
+//      1  B half 1                  acc[0..3][2..3]                 A half 1 of K-step ks+1
+//      2  A half 1                  acc[4..7][2..3]                 A half 0 of K-step ks+2
+//      3  -                         acc[4..7][0..1]                 B half 0 of K-step ks+2
+#ifdef T2S_GEMM_STAMPS
+__device__ unsigned long long t2s_wgpp_stamps[1024 * 8];
+#define WG_STAMP(i) if (tid == 0) t2s_wgpp_stamps[(blockIdx.x & 1023) * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#define WG_RSTAMP(i) if (tid == 0) t2s_wgpp_stamps[(blockIdx.x & 1023) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();
+extern "C" int t2s_debug_read_wgpp_stamps(unsigned long long* host_out, int n_words) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(t2s_wgpp_stamps), sizeof(unsigned long long) * n_words);
+}
+#else
+#define WG_STAMP(i)
+#define WG_RSTAMP(i)
+#endif
+
+__global__ __launch_bounds__(512) void wgrad_cl_pp_kernel(const WgradClArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2;          // group (SIMD partners are wave w and w + 4) = which 64 rows of each A half
+    const int wc = wave & 3;           // which 32 columns of each B half
+    WG_STAMP(0)
+    WG_RSTAMP(4)
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int mt = logical % a.n_mtiles;
+    const int rest = logical / a.n_mtiles;
+    const int nt = rest % a.n_ntiles;
+    const int slab = rest / a.n_ntiles;
+    const int kper = a.k1 - a.k0;
+    const int kf0 = slab * a.kchunk;
+    int nk = min(a.kchunk, a.B * kper - kf0);
+    if (nk < 0) nk = 0;
+
+    // ---- running DMA sources.  Piece of this thread in a half-plane (4 chunks x 32 rows x 64 B): chunk tid >> 7, row
+    // (tid >> 2) & 31, 16-byte slot tid & 3 holding the logical slot with the 32-byte half swapped on rows 8..15, 24..31 ----
+    const int row = (tid >> 2) & 31, slot = tid & 3;
+    const int lslot = (((slot >> 1) ^ ((row >> 3) & 1)) << 1) | (slot & 1);
+    const int bb0 = kf0 / kper, kk0 = kf0 - bb0 * kper;          // first K-block of the slab: batch entry, block inside it
+    const long thr_b = ((long)row * 32 + lslot * 8) * 2 + (long)(a.k0 + kk0) * 2048;
+    const int step_b = 2048;                                      // one K-block = 32 rows x 64 B of a chunk
+    const char *pAh[2], *pAl[2], *pBh[2], *pBl[2];
+    int jA[2], jB[2];                                             // addend across a batch boundary (last block -> block k0 of b + 1)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const WgradChunk ca = a.a_chunks[mt * 8 + 4 * h + (tid >> 7)];
+        const WgradChunk cb = a.b_chunks[nt * 8 + 4 * h + (tid >> 7)];
+        pAh[h] = (const char*)ca.hi + (long)bb0 * ca.bstride * 2 + thr_b;
+        pAl[h] = (const char*)ca.lo + (long)bb0 * ca.bstride * 2 + thr_b;
+        pBh[h] = (const char*)cb.hi + (long)bb0 * cb.bstride * 2 + thr_b;
+        pBl[h] = (const char*)cb.lo + (long)bb0 * cb.bstride * 2 + thr_b;
+        jA[h] = (int)(ca.bstride * 2 - (long)(kper - 1) * step_b);
+        jB[h] = (int)(cb.bstride * 2 - (long)(kper - 1) * step_b);
+    }
+    char* const lds_wave = smem + wave * 1024;                    // + lane * 16 is implicit in the DMA
+    // `edge`: the K-block being staged is the last one of its batch entry (wave-uniform)
+    auto stage_a = [&](int ks, int h, bool edge) {
+        char* dst = lds_wave + (ks & 1) * WG_STAGE + h * 8192;
+        wg_glds16(pAh[h], dst);
+        wg_glds16(pAl[h], dst + WG_PLANE);
+        const int adv = edge ? jA[h] : step_b;
+        pAh[h] += adv;
+        pAl[h] += adv;
+    };
+    auto stage_b = [&](int ks, int h, bool edge) {
+        char* dst = lds_wave + (ks & 1) * WG_STAGE + 2 * WG_PLANE + h * 8192;
+        wg_glds16(pBh[h], dst);
+        wg_glds16(pBl[h], dst + WG_PLANE);
+        const int adv = edge ? jB[h] : step_b;
+        pBh[h] += adv;
+        pBl[h] += adv;
+    };
+
+    // ---- transposed fragment addresses (as the lockstep kernel): lane group g = lane >> 4 owns k = 8g .. 8g+7; lane 4q + p of
+    // the group supplies block row q, columns 4p .. 4p+3; 16-channel half c16 of a chunk sits in 32-byte half c16 ^ (g & 1) ----
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int tr_base = (8 * g + qq) * 64 + pp * 8;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // per-lane read bases for the two 16-channel halves of a chunk; everything else is an immediate offset:
+    // A: + h * 8192 + (mm >> 1) * 2048 (+ WG_PLANE for lo);  B: + h * 8192 (+ WG_PLANE for lo)
+    const unsigned a_base[2] = {lds0 + wr * 4096 + tr_base + (0 ^ (g & 1)) * 32, lds0 + wr * 4096 + tr_base + (1 ^ (g & 1)) * 32};
+    const unsigned b_base[2] = {lds0 + 2 * WG_PLANE + wc * 2048 + tr_base + (0 ^ (g & 1)) * 32,
+                                lds0 + 2 * WG_PLANE + wc * 2048 + tr_base + (1 ^ (g & 1)) * 32};
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 afh[4], afl[4], b0h[2], b0l[2], b1h[2], b1l[2];
+
+    // position inside the batch entry of K-steps ks + 1 and ks + 2 (scalars)
+    int r0 = kk0;
+    auto next_r = [&](int r) { return r + 1 == kper ? 0 : r + 1; };
+    // ---- prologue: K-step 0 whole, A half 0 / B half 0 of K-step 1 ----
+    if (nk > 0) {
+        const bool e0 = r0 == kper - 1;
+        stage_a(0, 0, e0);
+        stage_b(0, 0, e0);
+        stage_b(0, 1, e0);
+        stage_a(0, 1, e0);
+    }
+    int r1 = next_r(r0);               // K-step ks + 1
+    int r2 = next_r(r1);               // K-step ks + 2
+    if (nk > 1) {
+        const bool e1 = r1 == kper - 1;
+        stage_a(1, 0, e1);
+        stage_b(1, 0, e1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind group 0
+
+    // swapped operands: D[i][j] = sum_k Bfrag[i][k] * Afrag[j][k]  ->  lane holds columns n = 4 (lane >> 4) + e of row m = lane & 15
+#define WG_MFMA(ACC, AH, AL, BH, BL)                                             \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BH, AL, ACC, 0, 0, 0);         \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BL, AH, ACC, 0, 0, 0);         \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BH, AH, ACC, 0, 0, 0);
+
+    auto kstep = [&](int ks, auto main_tag) {
+        constexpr bool MAIN = decltype(main_tag)::value;
+        const unsigned sbo = (ks & 1) * WG_STAGE;
+        const unsigned ab0 = a_base[0] + sbo, ab1 = a_base[1] + sbo, bb0_ = b_base[0] + sbo, bb1_ = b_base[1] + sbo;
+        const bool e1 = r1 == kper - 1, e2 = r2 == kper - 1;
+        // ------------------------------------------------ phase 0: A half 0 x B half 0
+        b0h[0] = tr_frag_asm<0>(bb0_);
+        b0l[0] = tr_frag_asm<WG_PLANE>(bb0_);
+        b0h[1] = tr_frag_asm<0>(bb1_);
+        b0l[1] = tr_frag_asm<WG_PLANE>(bb1_);
+        afh[0] = tr_frag_asm<0>(ab0);
+        afl[0] = tr_frag_asm<WG_PLANE>(ab0);
+        afh[1] = tr_frag_asm<0>(ab1);
+        afl[1] = tr_frag_asm<WG_PLANE>(ab1);
+        afh[2] = tr_frag_asm<2048>(ab0);
+        afl[2] = tr_frag_asm<WG_PLANE + 2048>(ab0);
+        afh[3] = tr_frag_asm<2048>(ab1);
+        afl[3] = tr_frag_asm<WG_PLANE + 2048>(ab1);
+        if (MAIN || ks + 1 < nk) stage_b(ks + 1, 1, e1);
+        if (MAIN) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { WG_MFMA(acc[m][n], afh[m], afl[m], b0h[n], b0l[n]) }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ------------------------------------------------ phase 1: A half 0 x B half 1
+        b1h[0] = tr_frag_asm<8192>(bb0_);
+        b1l[0] = tr_frag_asm<8192 + WG_PLANE>(bb0_);
+        b1h[1] = tr_frag_asm<8192>(bb1_);
+        b1l[1] = tr_frag_asm<8192 + WG_PLANE>(bb1_);
+        if (MAIN || ks + 1 < nk) stage_a(ks + 1, 1, e1);
+        if (MAIN) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { WG_MFMA(acc[m][2 + n], afh[m], afl[m], b1h[n], b1l[n]) }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ------------------------------------------------ phase 2: A half 1 x B half 1
+        afh[0] = tr_frag_asm<8192>(ab0);
+        afl[0] = tr_frag_asm<8192 + WG_PLANE>(ab0);
+        afh[1] = tr_frag_asm<8192>(ab1);
+        afl[1] = tr_frag_asm<8192 + WG_PLANE>(ab1);
+        afh[2] = tr_frag_asm<8192 + 2048>(ab0);
+        afl[2] = tr_frag_asm<8192 + WG_PLANE + 2048>(ab0);
+        afh[3] = tr_frag_asm<8192 + 2048>(ab1);
+        afl[3] = tr_frag_asm<8192 + WG_PLANE + 2048>(ab1);
+        if (MAIN || ks + 2 < nk) stage_a(ks + 2, 0, e2);
+        if (MAIN) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { WG_MFMA(acc[4 + m][2 + n], afh[m], afl[m], b1h[n], b1l[n]) }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ------------------------------------------------ phase 3: A half 1 x B half 0 (fragments still in registers)
+        if (MAIN || ks + 2 < nk) stage_b(ks + 2, 0, e2);
+        if (MAIN) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { WG_MFMA(acc[4 + m][n], afh[m], afl[m], b0h[n], b0l[n]) }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        r1 = r2;
+        r2 = next_r(r2);
+    };
+
+    int ks = 0;
+    WG_STAMP(1)
+    for (; ks + 2 < nk; ++ks) kstep(ks, std::true_type{});
+    for (; ks < nk; ++ks) kstep(ks, std::false_type{});
+    if (wr == 0) __builtin_amdgcn_s_barrier();          // matches group 1's extra barrier in front of the loop
+    WG_STAMP(2)
+#undef WG_MFMA
+
+    // ---- epilogue.  D map with the operands swapped: row (n) = 4 * (lane >> 4) + reg, col (m) = lane & 15.
+    // m-tile m: output rows (m >> 2) * 128 + wr * 64 + (m & 3) * 16;  n-tile n: output columns (n >> 1) * 128 + wc * 32 + (n & 1) * 16
+    float* P = a.P + (size_t)slab * a.M * a.ldp;
+    const int mlane = lane & 15, ncol4 = (lane >> 4) * 4;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int mm = mt * 256 + (m >> 2) * 128 + wr * 64 + (m & 3) * 16 + mlane;
+        if (mm >= a.M) continue;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int nn = nt * 256 + (n >> 1) * 128 + wc * 32 + (n & 1) * 16 + ncol4;
+            if (nn < a.ldp) *(f32x4*)(P + (size_t)mm * a.ldp + nn) = acc[m][n];
+        }
+    }
+#ifdef T2S_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    WG_STAMP(3)
+    WG_RSTAMP(5)
 }
 
 hipError_t t2s_launch_wgrad_cl(const WgradClArgs& a, hipStream_t stream) {
     const int nwg = a.n_mtiles * a.n_ntiles * a.nslab;
     constexpr int lds = 2 * WG_STAGE;
+    static const int pp = getenv("T2S_WGRAD_PP") ? atoi(getenv("T2S_WGRAD_PP")) : 1;
+    if (pp && a.ldp % 4 == 0) {
+        static std::atomic<unsigned long long> attr_mask_pp{0};
+        const hipError_t e = t2s_raise_lds_limit((const void*)wgrad_cl_pp_kernel, lds, attr_mask_pp);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(wgrad_cl_pp_kernel, dim3(nwg), dim3(512), lds, stream, a);
+        return hipGetLastError();
+    }
     static std::atomic<unsigned long long> attr_mask{0};
     const hipError_t e = t2s_raise_lds_limit((const void*)wgrad_cl_kernel, lds, attr_mask);
     if (e != hipSuccess) return e;

@@ -24,12 +24,20 @@ from . import _lib
 
 class _WaveGlowLossFn(torch.autograd.Function):
     """loss = (sum z^2 / (2 sigma^2) - sum_k sum log_s_k - sum_k log_det_k) / numel(z) in one fused HIP pass
-    (csrc/loss_ops.hip); d/dz = z / (sigma^2 N) comes out of the same pass, d/dlog_s = d/dlog_det = -1/N."""
+    (csrc/loss_ops.hip); d/dz = z / (sigma^2 N) comes out of the same pass, d/dlog_s = d/dlog_det = -1/N.  No eager operator
+    in forward or backward: the upstream gradient (a 0-dim device tensor) is applied by t2s_scale_by_scalar."""
 
     @staticmethod
     def forward(ctx, sigma, n_flows, z, *rest):
         log_s = [t.detach().to(torch.float32).contiguous() for t in rest[:n_flows]]
-        log_det = torch.stack([t.detach().to(torch.float32).reshape(()) for t in rest[n_flows:]])
+        dets = [t.detach() for t in rest[n_flows:]]
+        # the model hands out log_det_W as the n_flows elements of ONE device array (views): use it in place
+        d0 = dets[0]
+        if all(t.dtype == torch.float32 and t.dim() == 0 and t.untyped_storage().data_ptr() == d0.untyped_storage().data_ptr()
+               and t.storage_offset() == d0.storage_offset() + k for k, t in enumerate(dets)):
+            log_det = d0.as_strided((n_flows,), (1,))
+        else:
+            log_det = torch.stack([t.to(torch.float32).reshape(()) for t in dets])
         zc = z.detach().to(torch.float32).contiguous()
         dev = zc.device
         d_z = torch.empty_like(zc) if z.requires_grad else None
@@ -42,15 +50,21 @@ class _WaveGlowLossFn(torch.autograd.Function):
         ctx.d_z, ctx.n_flows, ctx.inv_n = d_z, n_flows, 1.0 / zc.numel()
         ctx.meta = [(t.shape, t.requires_grad) for t in rest]
         ctx.z_shape = z.shape
-        return out[0].clone()
+        return out.view(())
 
     @staticmethod
     def backward(ctx, g):
-        gz = None if ctx.d_z is None else (ctx.d_z * g).view(ctx.z_shape)
-        outs = []
-        for shape, need in ctx.meta:
-            # the constant -1/N times the upstream gradient, broadcast (a view, no kernel per flow)
-            outs.append((-(g * ctx.inv_n)).expand(shape) if need else None)
+        g32 = g.detach().to(torch.float32).contiguous()
+        st = _lib.current_stream()
+        gz = None
+        if ctx.d_z is not None:
+            gz = torch.empty_like(ctx.d_z)
+            _lib.call("t2s_scale_by_scalar", _lib.ptr(ctx.d_z), gz.numel(), _lib.ptr(g32), 1.0, _lib.ptr(gz), st)
+            gz = gz.view(ctx.z_shape)
+        # the constant -1/N times the upstream gradient: ONE device float, broadcast to every log_s / log_det (views, no kernel)
+        neg = torch.empty(1, dtype=torch.float32, device=g32.device)
+        _lib.call("t2s_scale_by_scalar", None, 1, _lib.ptr(g32), -ctx.inv_n, _lib.ptr(neg), st)
+        outs = [neg.view(()).expand(shape) if need else None for shape, need in ctx.meta]
         return (None, None, gz, *outs)
 
 
@@ -524,7 +538,7 @@ class _Engine:
         cg = self.compose_geom()
         C = self.geom()["C"]
         ph = None
-        if cg is not None and -(-C // 128) * -(-L // 256) * B > 128:
+        if cg is not None and _lib.load().t2s_wg_gate_tile_rows(B, C, L) == 256:      # the library's own tile-height decision
             P, nlag, K2 = cg
             self.compose_cond(dev)
             Fp = -(-frames // 256) * 256

@@ -82,8 +82,13 @@ def _alloc_train(eng, B, L, dev):
             ns -= 1
         return ns
     st.ks2, st.ks1 = nsplit(2 * C, st.N2), nsplit(2 * C, st.N1)
-    st.P2 = torch.empty(st.ks2, 2 * C, st.N2, dtype=torch.float32, device=dev)
-    st.P1 = torch.empty(st.ks1, 2 * C, st.N1, dtype=torch.float32, device=dev)
+    # (its K-blocks are whole 32-row blocks shifted by up to +-halo rows: in bounds only when halo % 32 == 0, which geom() ensures)
+    st.cl_ok = C % 32 == 0 and g["n_cond"] % 32 == 0 and g["halo"] % 32 == 0 and not os.environ.get("T2S_WGRAD_TM")
+    assert not st.cl_ok or (st.k0 * 32 >= g["halo"] and st.k1 * 32 + g["halo"] <= Lp), "wgrad_cl K-blocks leave the plane"
+    # floats per slab row: a multiple of 4 so that the channel-last kernel's epilogue stores whole 16-byte pieces
+    st.ld2, st.ld1 = (-(-st.N2 // 4) * 4, -(-st.N1 // 4) * 4) if st.cl_ok else (st.N2, st.N1)
+    st.P2 = torch.empty(st.ks2, 2 * C, st.ld2, dtype=torch.float32, device=dev)
+    st.P1 = torch.empty(st.ks1, 2 * C, st.ld1, dtype=torch.float32, device=dev)
     st.Mc = _lib.padded_rows(C)
     st.Ms = _lib.padded_rows(g["n_cond"])
     st.A_rsT = (_bf(2 * C // 32, st.Mc, 32, dev=dev), _bf(2 * C // 32, st.Mc, 32, dev=dev))
@@ -92,9 +97,6 @@ def _alloc_train(eng, B, L, dev):
     st.zero_bias = torch.zeros(max(st.M2pad, st.Ms, 1024), dtype=torch.float32, device=dev)
     st.sw_scratch = torch.empty(_lib.load().t2s_small_wgrad_scratch(B, xc), dtype=torch.float32, device=dev)
     # channel-last weight-gradient GEMM (t2s_wgrad_cl): constant chunks and the per-layer operand tables (built on first use)
-    # (its K-blocks are whole 32-row blocks shifted by up to +-halo rows: in bounds only when halo % 32 == 0, which geom() ensures)
-    st.cl_ok = C % 32 == 0 and g["n_cond"] % 32 == 0 and g["halo"] % 32 == 0 and not os.environ.get("T2S_WGRAD_TM")
-    assert not st.cl_ok or (st.k0 * 32 >= g["halo"] and st.k1 * 32 + g["halo"] <= Lp), "wgrad_cl K-blocks leave the plane"
     st.zero_plane = _bf(Lp, 32, dev=dev)
     st.ones_plane = _bf(Lp, 32, dev=dev)
     st.ones_plane[g["halo"]:g["halo"] + L, 0] = 1.0
@@ -206,10 +208,17 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
     st = _lib.current_stream()
     grads = {}
     zb = ts.zero_bias
-    dz = torch.zeros(B, G, L, dtype=torch.float32, device=dev) if gz is None else gz.to(torch.float32).contiguous().clone()
-    zw = ts.z_final.clone()
-    if g_log_det is not None:
-        g_log_det = g_log_det.to(torch.float32).contiguous()
+    # working copies (both are updated in place flow by flow), made by t2s_add3: no eager operator inside the step
+    dz = torch.empty(B, G, L, dtype=torch.float32, device=dev)
+    if gz is None:
+        _lib.call("t2s_scale_by_scalar", _ptr(ts.z_final), dz.numel(), _ptr(ts.zero_bias), 0.0, _ptr(dz), st)
+    else:
+        gz = gz.to(torch.float32).contiguous()
+        _lib.call("t2s_add3", _ptr(gz), None, None, dz.numel(), _ptr(dz), st)
+    zw = torch.empty_like(ts.z_final)
+    _lib.call("t2s_add3", _ptr(ts.z_final), None, None, zw.numel(), _ptr(zw), st)
+    # upstream gradients of the n_flows log_det_W outputs: 0-dim device tensors (or None)
+    g_log_det = [None if t is None else t.detach().to(torch.float32).contiguous() for t in g_log_det]
     xc, sc = g["Cpad"] // 32, g["Spad"] // 32
     # Two streams.  Per layer the weight-gradient work (seven HBM-bound plane transposes, two weight-gradient GEMMs, three
     # weight-norm reductions) never feeds the data-gradient chain (gate backward -> W_in^T / W_cond^T accumulate), so it runs
@@ -296,10 +305,15 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         bucket = _Bucket(list(wn.parameters()) + list(m.convinv[k].parameters()))
         # ---- affine coupling backward, un-apply (a1 restored in zw) ----
         d_out = new(B, nj, L)
-        gls = None if g_log_s[k] is None else g_log_s[k].to(torch.float32).contiguous()
+        gls, gls_scalar = g_log_s[k], 0
+        if gls is not None:
+            if all(s_ == 0 for s_ in gls.stride()) and gls.dtype == torch.float32:
+                gls_scalar = 1          # a broadcast scalar (WaveGlowLoss): ONE float stands for every element, nothing to expand
+            else:
+                gls = gls.to(torch.float32).contiguous()
         keep.append(gls)
-        _lib.call("t2s_wg_affine_backward", _ptr(zw), _ptr(dz), _ptr(ts.wn_out[k]), _ptr(gls), _ptr(d_out), B, G, c_off,
-                  n_half, L, st)
+        _lib.call("t2s_wg_affine_backward", _ptr(zw), _ptr(dz), _ptr(ts.wn_out[k]), _ptr(gls), gls_scalar, _ptr(d_out), B, G,
+                  c_off, n_half, L, st)
         # ---- WN.end: weight / bias gradient, and d_skip = W_end^T d_out as planes ----
         w_end = _f32c(wn.end.weight)
         dW_end = bucket.take(*wn.end.weight.shape)
@@ -341,7 +355,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             d = 2 ** i
             if cl:
                 ta1, tb1, ta2, tb2 = _cl_tables(ts, (k, i), sv, last, xc, sc, ks, d, dev)
-                _lib.call("t2s_wgrad_cl", _ptr(ta1), ta1.size(0), _ptr(tb1), tb1.size(0), _ptr(ts.P1), B, rows2, ts.N1,
+                _lib.call("t2s_wgrad_cl", _ptr(ta1), ta1.size(0), _ptr(tb1), tb1.size(0), _ptr(ts.P1), B, rows2, ts.N1, ts.ld1,
                           ts.k0, ts.k1, ts.ks1, st2)
                 ev_tdrs = torch.cuda.Event()        # DX / DS have been read: the chain may update DX in place
                 ev_tdrs.record(side_s)
@@ -357,11 +371,11 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                           _ptr(ts.TM_act[1]), ts.N1pad, 0, st2)
                 _lib.call("t2s_wgrad_gemm_flat", _ptr(ts.TM_drs[0]), _ptr(ts.TM_drs[1]), _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]),
                           _ptr(zb), _ptr(ts.P1), B, rows2, ts.N1, Mrs, ts.N1pad, nt, ts.k0, ts.k1, ts.ks1, st2)
-            wn_grads(conv_rs, ts.P1, ts.ks1, rows2, ts.N1, 0, 0, C, rows2, C, 1, stream=st2)
+            wn_grads(conv_rs, ts.P1, ts.ks1, rows2, ts.ld1, 0, 0, C, rows2, C, 1, stream=st2)
             # 3. dW_in, dW_cond = d_pre . [x taps | spect | 1]^T                                             [side]
             side_s.wait_event(ev_dp)
             if cl:
-                _lib.call("t2s_wgrad_cl", _ptr(ta2), ta2.size(0), _ptr(tb2), tb2.size(0), _ptr(ts.P2), B, 2 * C, ts.N2,
+                _lib.call("t2s_wgrad_cl", _ptr(ta2), ta2.size(0), _ptr(tb2), tb2.size(0), _ptr(ts.P2), B, 2 * C, ts.N2, ts.ld2,
                           ts.k0, ts.k1, ts.ks2, st2)
                 ev_tdp_done = torch.cuda.Event()    # d_pre has been read: the next layer's gate backward may overwrite DP
                 ev_tdp_done.record(side_s)
@@ -375,8 +389,8 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                               _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), ts.N2pad, tap * C, st2)
                 _lib.call("t2s_wgrad_gemm_flat", _ptr(ts.TM_dp[0]), _ptr(ts.TM_dp[1]), _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]),
                           _ptr(zb), _ptr(ts.P2), B, 2 * C, ts.N2, ts.M2pad, ts.N2pad, nt, ts.k0, ts.k1, ts.ks2, st2)
-            wn_grads(conv_in, ts.P2, ts.ks2, 2 * C, ts.N2, 0, C, ts.N2 - 1, 2 * C, C, ks, stream=st2)
-            wn_grads(conv_c, ts.P2, ts.ks2, 2 * C, ts.N2, ks * C, 0, ts.N2 - 1, 2 * C, n_cond, 1, stream=st2)
+            wn_grads(conv_in, ts.P2, ts.ks2, 2 * C, ts.ld2, 0, C, ts.N2 - 1, 2 * C, C, ks, stream=st2)
+            wn_grads(conv_c, ts.P2, ts.ks2, 2 * C, ts.ld2, ks * C, 0, ts.N2 - 1, 2 * C, n_cond, 1, stream=st2)
             # 4. dx (+)= W_in^T (*) d_pre ;  d_spect += W_cond^T d_pre                                       [main]
             v_in, s_in = scale_of(conv_in, pk["s_in"])
             _lib.call("t2s_pack_transposed", _ptr(v_in), _ptr(s_in), 2 * C, C, ks, 1, 2 * C, ts.Mc, 0, _ptr(ts.A_inT[0]),
@@ -408,7 +422,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         _lib.call("t2s_transpose", _ptr(Wk), _ptr(WT), n_rem, n_rem, st)
         _lib.call("t2s_wg_convinv", _ptr(zw), _ptr(Winv), B, G, c_off, n_rem, L, st)          # zw <- flow input
         dW = bucket.take(*m.convinv[k].conv.weight.shape)
-        gp = None if g_log_det is None else _lib.c_vp(g_log_det.data_ptr() + 4 * k)
+        gp = _ptr(g_log_det[k])
         _lib.call("t2s_wg_convinv_wgrad", _ptr(dz), _ptr(zw), _ptr(Winv), gp, float(B * L), B, G, c_off, n_rem, L, _ptr(dW), st)
         _lib.call("t2s_wg_convinv", _ptr(dz), _ptr(WT), B, G, c_off, n_rem, L, st)            # dz <- W^T dz
         grads[id(m.convinv[k].conv.weight)] = dW
@@ -441,13 +455,15 @@ class _WaveGlowFn(torch.autograd.Function):
         ctx.ts = ts
         ctx.n = len(log_s_list)
         ctx.params = params
-        return (z, *log_s_list, log_det)
+        # log_det_W as n_flows 0-dim views of one device array: an indexing node per flow on the caller's side would cost a
+        # zero-fill, a scatter and an add per flow in autograd's backward
+        return (z, *log_s_list, *log_det.unbind(0))
 
     @staticmethod
     def backward(ctx, gz, *rest):
         n = ctx.n
         g_log_s = list(rest[:n])
-        g_log_det = rest[n]
+        g_log_det = list(rest[n:2 * n])
         eng = ctx.model._eng()
         with torch.no_grad():
             grads = backward_train(eng, ctx.ts, gz, g_log_s, g_log_det)
@@ -462,7 +478,4 @@ def waveglow_forward_with_grad(model, mel, audio):
     params = [p for p in model.parameters()]
     outs = _WaveGlowFn.apply(model, mel, audio, *params)
     n = model.n_flows
-    z = outs[0]
-    log_s_list = list(outs[1:1 + n])
-    log_det = outs[1 + n]
-    return z, log_s_list, [log_det[k] for k in range(n)]
+    return outs[0], list(outs[1:1 + n]), list(outs[1 + n:1 + 2 * n])
