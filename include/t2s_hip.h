@@ -346,6 +346,9 @@ int t2s_wgrad_gemm_flat(const void* A_hi, const void* A_lo, const void* X_hi, co
  * kernel, whose epilogue stores 16-byte pieces; any other ldp the round-2 lockstep kernel (also: env T2S_WGRAD_PP=0).
  * Every K-block is a WHOLE block of 32 plane rows starting at row 32 k (+ the shift folded into the pointer): the caller makes
  * sure rows [32 k0 - max shift, 32 k1 + max shift) exist in every plane (halo % 32 == 0 does, text2speech_amd/glow.py geom()).
+ * bias_cols != 0 (ping-pong kernel only, ldp >= N + 4): columns N .. N+3 of every slab also receive four partial sums of the
+ * M-side operand's rows over the slab's K range - the bias gradient of a convolution, db[m] = sum_t d_out[m][t], without an
+ * all-ones column in the N-side table (t2s_wn_backward adds them: n_bias_cols = 4).
  * Both tables live in device memory ([n_tiles * 8] entries).  Replaces 7 t2s_plane_transpose launches per WN layer. */
 typedef struct t2s_wgrad_chunk {
     const void* hi;
@@ -353,7 +356,7 @@ typedef struct t2s_wgrad_chunk {
     long bstride;
 } t2s_wgrad_chunk;
 int t2s_wgrad_cl(const t2s_wgrad_chunk* a_chunks, int n_a_chunks, const t2s_wgrad_chunk* b_chunks, int n_b_chunks, float* out,
-                 int B, int M, int N, int ldp, int k0, int k1, int nsplit, void* stream);
+                 int B, int M, int N, int ldp, int k0, int k1, int nsplit, int bias_cols, void* stream);
 
 int t2s_plane_transpose(const void* src_hi, const void* src_lo, int B, int src_chunks, int n_chunks, int Lp, int shift,
                         void* dst_hi, void* dst_lo, int Npad, int n_off, void* stream);
@@ -363,9 +366,10 @@ int t2s_pack_transposed(const float* v, const float* scale, int O, int Cin, int 
                         int koff, void* A_hi, void* A_lo, void* stream);
 /* per-row scale g/|v| of a weight-normed conv (what the forward pack applied), for t2s_pack_transposed */
 int t2s_weightnorm_scale(const float* v, const float* g, int O, int K, float* scale, void* stream);
-/* reduce split-K slabs P[nsplit][Prows][Pcols] and apply weight_norm's backward (g NULL: plain weight) */
+/* reduce split-K slabs P[nsplit][Prows][Pcols] and apply weight_norm's backward (g NULL: plain weight); the bias gradient is
+ * the sum over slabs of columns col_bias .. col_bias + n_bias_cols - 1 (n_bias_cols >= 1) */
 int t2s_wn_backward(const float* P, int nsplit, int Prows, int Pcols, int row_off, int col_off, int tap_stride,
-                    int col_bias, const float* v, const float* g, int O, int Cin, int Kt, float* dv, float* dg,
+                    int col_bias, int n_bias_cols, const float* v, const float* g, int O, int Cin, int Kt, float* dv, float* dg,
                     float* db, int db_accum, void* stream);
 /* affine coupling backward + un-apply (glow.py:241-246); wn_out = (b ; log_s) [B][2nh][L], d_out gets (d_b ; d_log_s).
  * g_log_s = upstream gradient of this flow's log_s output: [B][nh][L], or - g_log_s_scalar != 0 - ONE float that stands for

@@ -88,12 +88,12 @@ SIGNATURES = {
     "t2s_conv_accumulate": [c_vp] * 7 + [c_int] * 10 + [c_vp],
     "t2s_wgrad_gemm": [c_vp] * 6 + [c_int] * 9 + [c_vp],
     "t2s_wgrad_gemm_flat": [c_vp] * 6 + [c_int] * 9 + [c_vp],
-    "t2s_wgrad_cl": [c_vp, c_int, c_vp, c_int, c_vp] + [c_int] * 7 + [c_vp],
+    "t2s_wgrad_cl": [c_vp, c_int, c_vp, c_int, c_vp] + [c_int] * 8 + [c_vp],
     "t2s_plane_transpose": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp],
     "t2s_tm_ones_row": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
     "t2s_pack_transposed": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
     "t2s_weightnorm_scale": [c_vp, c_vp, c_int, c_int, c_vp, c_vp],
-    "t2s_wn_backward": [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp,
+    "t2s_wn_backward": [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp,
                         c_vp, c_int, c_vp],
     "t2s_wg_affine_backward": [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
     "t2s_small_wgrad_scratch": [c_int, c_int],

@@ -180,16 +180,17 @@ int t2s_wgrad_gemm_flat(const void* A_hi, const void* A_lo, const void* X_hi, co
 }
 
 int t2s_wgrad_cl(const t2s_wgrad_chunk* a_chunks, int n_a_chunks, const t2s_wgrad_chunk* b_chunks, int n_b_chunks, float* out,
-                 int B, int M, int N, int ldp, int k0, int k1, int nsplit, void* stream) {
+                 int B, int M, int N, int ldp, int k0, int k1, int nsplit, int bias_cols, void* stream) {
     static_assert(sizeof(t2s_wgrad_chunk) == sizeof(WgradChunk), "t2s_wgrad_chunk layout");
     if (!a_chunks || !b_chunks || !out || B <= 0 || M <= 0 || N <= 0 || k0 < 0 || k0 >= k1 || nsplit < 1) return T2S_EINVAL;
-    if (ldp < N || (ldp % 4 == 0 && !al16(out))) return T2S_EINVAL;
+    if (ldp < N || (ldp % 4 == 0 && !al16(out)) || (bias_cols && (ldp % 4 || ldp < N + 4))) return T2S_EINVAL;
     const int n_mtiles = cdiv(M, 256), n_ntiles = cdiv(N, 256);
     if (n_a_chunks != n_mtiles * 8 || n_b_chunks != n_ntiles * 8 || nsplit > B * (k1 - k0)) return T2S_EINVAL;
     WgradClArgs a;
     a.a_chunks = (const WgradChunk*)a_chunks; a.b_chunks = (const WgradChunk*)b_chunks; a.P = out;
     a.M = M; a.N = N; a.ldp = ldp; a.n_mtiles = n_mtiles; a.n_ntiles = n_ntiles; a.B = B; a.k0 = k0; a.k1 = k1;
     a.nslab = nsplit; a.kchunk = cdiv(B * (k1 - k0), nsplit);
+    a.bias_cols = bias_cols ? 1 : 0;
     if ((long)a.kchunk * (nsplit - 1) >= (long)B * (k1 - k0)) return T2S_EINVAL;      // every slab must own >= 1 K-block
     T2S_CHECK_HIP(t2s_launch_wgrad_cl(a, (hipStream_t)stream));
     return T2S_OK;
@@ -229,15 +230,16 @@ int t2s_weightnorm_scale(const float* v, const float* g, int O, int K, float* sc
 }
 
 int t2s_wn_backward(const float* P, int nsplit, int Prows, int Pcols, int row_off, int col_off, int tap_stride,
-                    int col_bias, const float* v, const float* g, int O, int Cin, int Kt, float* dv, float* dg,
+                    int col_bias, int n_bias_cols, const float* v, const float* g, int O, int Cin, int Kt, float* dv, float* dg,
                     float* db, int db_accum, void* stream) {
     if (!P || !v || !dv || (g && !dg) || nsplit <= 0 || O <= 0 || Cin <= 0 || Kt <= 0) return T2S_EINVAL;
-    if (row_off + O > Prows || col_off + (Kt - 1) * tap_stride + Cin > Pcols || (db && col_bias >= Pcols)) return T2S_EINVAL;
+    if (n_bias_cols < 1) n_bias_cols = 1;
+    if (row_off + O > Prows || col_off + (Kt - 1) * tap_stride + Cin > Pcols || (db && col_bias + n_bias_cols > Pcols)) return T2S_EINVAL;
     if ((size_t)Cin * Kt * sizeof(float) > 48 * 1024) return T2S_EINVAL;
     WnBwdArgs a;
     a.P = P; a.v = v; a.g = g; a.dv = dv; a.dg = dg; a.db = db;
     a.nsplit = nsplit; a.Prows = Prows; a.Pcols = Pcols; a.row_off = row_off; a.col_off = col_off;
-    a.tap_stride = tap_stride; a.col_bias = col_bias; a.O = O; a.Cin = Cin; a.Kt = Kt; a.db_accum = db_accum;
+    a.tap_stride = tap_stride; a.col_bias = col_bias; a.n_bias_cols = n_bias_cols; a.O = O; a.Cin = Cin; a.Kt = Kt; a.db_accum = db_accum;
     T2S_CHECK_HIP(t2s_launch_wn_backward(a, (hipStream_t)stream));
     return T2S_OK;
 }

@@ -79,6 +79,7 @@ struct WgradClArgs {
     int M, N, ldp, n_mtiles, n_ntiles;   // ldp >= N: floats per output row (a multiple of 4 selects the ping-pong kernel)
     int B, k0, k1;                 // K-blocks of 32 plane rows [k0, k1) of every batch entry
     int nslab, kchunk;             // slab s covers flattened (batch, block) steps [s * kchunk, (s + 1) * kchunk)
+    int bias_cols;                 // 1: also write the row sums of the M-side operand (4 partial sums) to columns N .. N+3
 };
 hipError_t t2s_launch_wgrad_cl(const WgradClArgs& a, hipStream_t stream);
 

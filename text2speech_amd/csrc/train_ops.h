@@ -16,6 +16,7 @@ struct WnBwdArgs {
     int row_off, col_off, tap_stride, col_bias;
     int O, Cin, Kt;
     int db_accum;
+    int n_bias_cols;       // the bias gradient is the sum of this many columns starting at col_bias (>= 1)
 };
 
 struct SmallWgradArgs {

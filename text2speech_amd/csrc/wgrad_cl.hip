@@ -64,6 +64,18 @@ __device__ __forceinline__ bf16x8 tr_frag_asm(unsigned addr) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// sum of the 8 bf16 values of a fragment, added to acc (4 v_dot2c_f32_bf16 against (1, 1): exact products, f32 accumulate)
+__device__ __forceinline__ float frag_sum(bf16x8 v, float acc) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const bf16x2_t one = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bf16x2_t p = {v[2 * i], v[2 * i + 1]};
+        acc = __builtin_amdgcn_fdot2_f32_bf16(p, one, acc, false);
+    }
+    return acc;
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(512) void wgrad_cl_kernel(const WgradClArgs a) {
@@ -205,6 +217,11 @@ __global__ __launch_bounds__(512) void wgrad_cl_kernel(const WgradClArgs a) {
 //  * the MFMA operands are swapped (B fragment as the matrix-A operand), so a lane's four accumulator registers are four
 //    CONSECUTIVE COLUMNS of one output row: the epilogue is 32 16-byte stores per lane instead of 128 4-byte ones (the slab's
 //    leading dimension ldp is a multiple of 4 floats for that).
+//  * bias_cols (the res/skip weight gradient, N = C exactly two tiles wide): the bias gradient is the row sum of the A operand
+//    over K.  As an extra all-ones output column it would open a third column of tiles for one column (+50 % workgroups); here
+//    the workgroups of tile column 0 sum their A fragments on the VALU (v_dot2c_f32_bf16 against (1, 1), issued in the shadow of
+//    the MFMAs): the four waves that share a block of A rows take the K-steps in turn (ks % 4 == wc), so each adds 32 VALU
+//    instructions to one K-step in four, and write four partial sums to columns N .. N+3 of the slab (wn_backward adds them).
 // Phase table of K-step ks (LDS buffer ks & 1), as csrc/gate_gemm_pp.hip:
 //      p  reads                     MFMAs (x3)                      stages
 //      0  A half 0, B half 0        acc[0..3][0..1]                 B half 1 of K-step ks+1
@@ -301,6 +318,10 @@ __global__ __launch_bounds__(512) void wgrad_cl_pp_kernel(const WgradClArgs a) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 afh[4], afl[4], b0h[2], b0l[2], b1h[2], b1l[2];
+    const bool bias_wg = a.bias_cols && nt == 0;
+    float rs[8];                        // row sums of this wave's 8 A tiles over its share of the K-steps (bias_wg only)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) rs[m] = 0.f;
 
     // position inside the batch entry of K-steps ks + 1 and ks + 2 (scalars)
     int r0 = kk0;
@@ -383,6 +404,10 @@ __global__ __launch_bounds__(512) void wgrad_cl_pp_kernel(const WgradClArgs a) {
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n) { WG_MFMA(acc[m][2 + n], afh[m], afl[m], b1h[n], b1l[n]) }
+        if (bias_wg && (ks & 3) == wc) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) rs[m] = frag_sum(afl[m], frag_sum(afh[m], rs[m]));
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -424,6 +449,10 @@ __global__ __launch_bounds__(512) void wgrad_cl_pp_kernel(const WgradClArgs a) {
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n) { WG_MFMA(acc[4 + m][n], afh[m], afl[m], b0h[n], b0l[n]) }
+        if (bias_wg && (ks & 3) == wc) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) rs[4 + m] = frag_sum(afl[m], frag_sum(afh[m], rs[4 + m]));
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -454,6 +483,16 @@ __global__ __launch_bounds__(512) void wgrad_cl_pp_kernel(const WgradClArgs a) {
             if (nn < a.ldp) *(f32x4*)(P + (size_t)mm * a.ldp + nn) = acc[m][n];
         }
     }
+    if (bias_wg) {       // lane l holds the sum over k-group l >> 4 of row l & 15: fold the four groups, lanes 0-15 store
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            float v = rs[m];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int mm = mt * 256 + (m >> 2) * 128 + wr * 64 + (m & 3) * 16 + mlane;
+            if (lane < 16 && mm < a.M) P[(size_t)mm * a.ldp + a.N + wc] = v;
+        }
+    }
 #ifdef T2S_GEMM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -465,6 +504,7 @@ hipError_t t2s_launch_wgrad_cl(const WgradClArgs& a, hipStream_t stream) {
     const int nwg = a.n_mtiles * a.n_ntiles * a.nslab;
     constexpr int lds = 2 * WG_STAGE;
     static const int pp = getenv("T2S_WGRAD_PP") ? atoi(getenv("T2S_WGRAD_PP")) : 1;
+    if (a.bias_cols && !(pp && a.ldp % 4 == 0 && a.ldp >= a.N + 4)) return hipErrorInvalidValue;    // only the ping-pong kernel has it
     if (pp && a.ldp % 4 == 0) {
         static std::atomic<unsigned long long> attr_mask_pp{0};
         const hipError_t e = t2s_raise_lds_limit((const void*)wgrad_cl_pp_kernel, lds, attr_mask_pp);

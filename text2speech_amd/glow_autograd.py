@@ -81,12 +81,20 @@ def _alloc_train(eng, B, L, dev):
         while ns > 1 and -(-ksteps // ns) * (ns - 1) >= ksteps:      # every slab owns at least one K-step
             ns -= 1
         return ns
-    st.ks2, st.ks1 = nsplit(2 * C, st.N2), nsplit(2 * C, st.N1)
     # (its K-blocks are whole 32-row blocks shifted by up to +-halo rows: in bounds only when halo % 32 == 0, which geom() ensures)
     st.cl_ok = C % 32 == 0 and g["n_cond"] % 32 == 0 and g["halo"] % 32 == 0 and not os.environ.get("T2S_WGRAD_TM")
     assert not st.cl_ok or (st.k0 * 32 >= g["halo"] and st.k1 * 32 + g["halo"] <= Lp), "wgrad_cl K-blocks leave the plane"
+    # res/skip weight gradient: N = C + 1 with the bias as an all-ones column would open another column of 256-wide tiles for
+    # that one column whenever C % 256 == 0; the ping-pong kernel computes the bias gradient as row sums instead (bias_cols:
+    # four partial-sum columns C .. C+3) and the GEMM is exactly C wide
+    st.bias_cols = 1 if (st.cl_ok and C % 256 == 0 and os.environ.get("T2S_WGRAD_PP", "1") != "0"
+                         and os.environ.get("T2S_WGRAD_BIAS_COL") != "ones") else 0
+    st.N1g = C if st.bias_cols else st.N1                  # columns of the GEMM proper
+    st.ks2, st.ks1 = nsplit(2 * C, st.N2), nsplit(2 * C, st.N1g)
+    # the last layer of a flow has no residual rows (M = C): twice the slabs of half the height, the same slab buffer
+    st.ks1_last = nsplit(C, st.N1g) if st.cl_ok and nsplit(C, st.N1g) * C <= st.ks1 * 2 * C else st.ks1
     # floats per slab row: a multiple of 4 so that the channel-last kernel's epilogue stores whole 16-byte pieces
-    st.ld2, st.ld1 = (-(-st.N2 // 4) * 4, -(-st.N1 // 4) * 4) if st.cl_ok else (st.N2, st.N1)
+    st.ld2, st.ld1 = (-(-st.N2 // 4) * 4, -(-(st.N1g + 4 * st.bias_cols) // 4) * 4) if st.cl_ok else (st.N2, st.N1)
     st.P2 = torch.empty(st.ks2, 2 * C, st.ld2, dtype=torch.float32, device=dev)
     st.P1 = torch.empty(st.ks1, 2 * C, st.ld1, dtype=torch.float32, device=dev)
     st.Mc = _lib.padded_rows(C)
@@ -129,7 +137,7 @@ def _cl_tables(ts, key, lay_sv, last, xc, sc, ks, d, dev):
         return t
     ones = [[ts.ones_plane.data_ptr(), ts.zero_plane.data_ptr(), 0]]
     a1 = ([] if last else _chunk_rows(ts.DX, xc)) + _chunk_rows(ts.DS, xc)            # [d_x ; d_skip]
-    b1 = _chunk_rows(lay_sv["A"], xc) + ones                                            # [acts | 1]
+    b1 = _chunk_rows(lay_sv["A"], xc) + ([] if ts.bias_cols else ones)                  # [acts | 1] (or the kernel's row sums)
     a2 = _chunk_rows(ts.DP, 2 * xc)                                                     # d_pre (tanh half, sigmoid half)
     b2 = []
     for tap in range(ks):
@@ -272,7 +280,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
 
     bucket = None
 
-    def wn_grads(conv, P, nsplit, Prows, Pcols, col_off, tap_stride, col_bias, O, Cin, Kt, with_bias=True, stream=None):
+    def wn_grads(conv, P, nsplit, Prows, Pcols, col_off, tap_stride, col_bias, O, Cin, Kt, with_bias=True, stream=None, nb=1):
         v, gg = _vg(conv)
         v32 = _f32c(v)
         g32 = None if gg is None else _f32c(gg)
@@ -280,7 +288,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         dg = None if gg is None else bucket.take(*gg.shape)
         db = bucket.take(O) if with_bias else None
         keep.extend([v32, g32])
-        _lib.call("t2s_wn_backward", _ptr(P), nsplit, Prows, Pcols, 0, col_off, tap_stride, col_bias, _ptr(v32), _ptr(g32), O,
+        _lib.call("t2s_wn_backward", _ptr(P), nsplit, Prows, Pcols, 0, col_off, tap_stride, col_bias, nb, _ptr(v32), _ptr(g32), O,
                   Cin, Kt, _ptr(dv), _ptr(dg), _ptr(db), 0, st if stream is None else stream)
         if gg is None:
             grads[id(conv.weight)] = dv
@@ -355,8 +363,9 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             d = 2 ** i
             if cl:
                 ta1, tb1, ta2, tb2 = _cl_tables(ts, (k, i), sv, last, xc, sc, ks, d, dev)
-                _lib.call("t2s_wgrad_cl", _ptr(ta1), ta1.size(0), _ptr(tb1), tb1.size(0), _ptr(ts.P1), B, rows2, ts.N1, ts.ld1,
-                          ts.k0, ts.k1, ts.ks1, st2)
+                ks1 = ts.ks1_last if last else ts.ks1
+                _lib.call("t2s_wgrad_cl", _ptr(ta1), ta1.size(0), _ptr(tb1), tb1.size(0), _ptr(ts.P1), B, rows2, ts.N1g, ts.ld1,
+                          ts.k0, ts.k1, ks1, ts.bias_cols, st2)
                 ev_tdrs = torch.cuda.Event()        # DX / DS have been read: the chain may update DX in place
                 ev_tdrs.record(side_s)
             else:
@@ -371,12 +380,13 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                           _ptr(ts.TM_act[1]), ts.N1pad, 0, st2)
                 _lib.call("t2s_wgrad_gemm_flat", _ptr(ts.TM_drs[0]), _ptr(ts.TM_drs[1]), _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]),
                           _ptr(zb), _ptr(ts.P1), B, rows2, ts.N1, Mrs, ts.N1pad, nt, ts.k0, ts.k1, ts.ks1, st2)
-            wn_grads(conv_rs, ts.P1, ts.ks1, rows2, ts.ld1, 0, 0, C, rows2, C, 1, stream=st2)
+            wn_grads(conv_rs, ts.P1, (ts.ks1_last if last else ts.ks1) if cl else ts.ks1, rows2, ts.ld1, 0, 0, C, rows2, C, 1,
+                     stream=st2, nb=4 if ts.bias_cols and cl else 1)
             # 3. dW_in, dW_cond = d_pre . [x taps | spect | 1]^T                                             [side]
             side_s.wait_event(ev_dp)
             if cl:
                 _lib.call("t2s_wgrad_cl", _ptr(ta2), ta2.size(0), _ptr(tb2), tb2.size(0), _ptr(ts.P2), B, 2 * C, ts.N2, ts.ld2,
-                          ts.k0, ts.k1, ts.ks2, st2)
+                          ts.k0, ts.k1, ts.ks2, 0, st2)
                 ev_tdp_done = torch.cuda.Event()    # d_pre has been read: the next layer's gate backward may overwrite DP
                 ev_tdp_done.record(side_s)
             else:

@@ -123,7 +123,7 @@ class _Bwd:
         w = _f32(param)
         dW = self.new(*param.shape)
         db = None if bias_param is None else self.new(O)
-        _lib.call("t2s_wn_backward", _p(P), ks, M4, N, row_off, col_off, tap_stride, N - 1, _p(w), None, O, Cin, Kt, _p(dW), None,
+        _lib.call("t2s_wn_backward", _p(P), ks, M4, N, row_off, col_off, tap_stride, N - 1, 1, _p(w), None, O, Cin, Kt, _p(dW), None,
                   _p(db), 0, self.st)
         self.grads[id(param)] = dW
         if bias_param is not None:
@@ -242,7 +242,7 @@ class _Bwd:
         lp, gl = dec.linear_projection.linear_layer, dec.gate_layer.linear_layer
         # rows [0, n_mel) -> linear_projection, row n_mel -> gate_layer
         dWp, dbp = self.new(n_mel + 1, DE), self.new(n_mel + 1)
-        _lib.call("t2s_wn_backward", _p(Pp), ks, M4, N, 0, 0, 0, N - 1, _p(w_proj), None, n_mel + 1, DE, 1, _p(dWp), None, _p(dbp),
+        _lib.call("t2s_wn_backward", _p(Pp), ks, M4, N, 0, 0, 0, N - 1, 1, _p(w_proj), None, n_mel + 1, DE, 1, _p(dWp), None, _p(dbp),
                   0, st)
         self.grads[id(lp.weight)], self.grads[id(lp.bias)] = dWp[:n_mel].contiguous(), dbp[:n_mel].contiguous()
         self.grads[id(gl.weight)], self.grads[id(gl.bias)] = dWp[n_mel:].contiguous(), dbp[n_mel:].contiguous()
@@ -283,7 +283,7 @@ class _Bwd:
             for b in range(B):
                 Pm_, ks_, M4_, N_ = self.items_wgrad(T, [(_p(align, b * T_cap * T_in), T_in, T_in, 0, 0)],
                                                      [(_p(dctx_all, b * E), B * E, E, 0, 0)], T_in, E)
-                _lib.call("t2s_wn_backward", _p(Pm_), ks_, M4_, N_, 0, 0, 0, N_ - 1, _p(memory), None, T_in, E, 1,
+                _lib.call("t2s_wn_backward", _p(Pm_), ks_, M4_, N_, 0, 0, 0, N_ - 1, 1, _p(memory), None, T_in, E, 1,
                           _p(d_memory, b * T_in * E), None, None, 0, st)
             self.keep.append(dctx_all)
         self.keep += [dw_buf, df_buf, dq_part]
