@@ -312,16 +312,19 @@ int t2s_wg_res_skip_train(const void* A_hi, const void* A_lo, const float* bias,
 /* d_pre = gate'(acts, G) * (W_rs^T [d_x ; d_skip]):  data gradient of res_skip_layers[i] fused with the backward of
  * tanh*sigmoid (glow.py:33-40,164), from the layer's saved gate output acts = tanh * sigmoid and G = sigmoid (tanh = acts / G).
  * A = t2s_pack_transposed(W_rs); DX may be NULL (last layer: skip rows only).
- * DP planes have 2C channels (tanh half, then sigmoid half). */
+ * DP planes have 2C channels (tanh half, then sigmoid half).  dp_bchunks: 32-channel chunks between batch entries of the DP
+ * planes (0 = 2C/32): DP may be a slice of a wider plane set - the training path keeps the d_pre of all layers of a flow side
+ * by side so that the conditioning gradient is ONE K-concatenated GEMM per flow. */
 int t2s_wg_bwd_gate_dgrad(const void* A_hi, const void* A_lo, const float* zero_bias, const void* DX_hi,
                           const void* DX_lo, const void* DS_hi, const void* DS_lo, const void* acts_hi, const void* acts_lo,
-                          const void* G_hi, const void* G_lo, void* DP_hi, void* DP_lo, int B, int C, int L, int Lp,
+                          const void* G_hi, const void* G_lo, void* DP_hi, void* DP_lo, int dp_bchunks, int B, int C, int L, int Lp,
                           int halo, int Mpad, void* stream);
 
 /* O (+)= conv(X) with packed (transposed) weights: data gradients of in_layers[i] (dilated, taps mirrored) and
- * cond_layers[i].  init=1 stores, init=0 accumulates into the O planes. */
+ * cond_layers[i].  init=1 stores, init=0 accumulates into the O planes.  x_bchunks: chunks between batch entries of the X
+ * planes (0 = Cin/32; X may be a slice of a wider plane set, see t2s_wg_bwd_gate_dgrad). */
 int t2s_conv_accumulate(const void* A_hi, const void* A_lo, const float* zero_bias, const void* X_hi, const void* X_lo,
-                        void* O_hi, void* O_lo, int B, int Cin, int Cout, int taps, int dilation, int init, int L, int Lp,
+                        int x_bchunks, void* O_hi, void* O_lo, int B, int Cin, int Cout, int taps, int dilation, int init, int L, int Lp,
                         int halo, int Mpad, void* stream);
 
 /* out[b*ksplit + s][m][n] = sum over time chunks [k0,k1) (split s of ksplit) of A_tm[b][t][m] * X_tm[b][t][n]:

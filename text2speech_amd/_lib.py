@@ -84,8 +84,8 @@ SIGNATURES = {
     "t2s_planes_to_f32": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp],
     "t2s_wg_in_cond_gate_train": [c_vp] * 13 + [c_int] * 9 + [c_vp],
     "t2s_wg_res_skip_train": [c_vp] * 10 + [c_int] * 8 + [c_vp],
-    "t2s_wg_bwd_gate_dgrad": [c_vp] * 13 + [c_int] * 6 + [c_vp],
-    "t2s_conv_accumulate": [c_vp] * 7 + [c_int] * 10 + [c_vp],
+    "t2s_wg_bwd_gate_dgrad": [c_vp] * 13 + [c_int] * 7 + [c_vp],
+    "t2s_conv_accumulate": [c_vp] * 5 + [c_int] + [c_vp] * 2 + [c_int] * 10 + [c_vp],
     "t2s_wgrad_gemm": [c_vp] * 6 + [c_int] * 9 + [c_vp],
     "t2s_wgrad_gemm_flat": [c_vp] * 6 + [c_int] * 9 + [c_vp],
     "t2s_wgrad_cl": [c_vp, c_int, c_vp, c_int, c_vp] + [c_int] * 8 + [c_vp],

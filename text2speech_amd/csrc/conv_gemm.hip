@@ -116,8 +116,9 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
     A_lo += (size_t)kbeg * a.Mpad * 64;
     const size_t a_kstride = (size_t)a.Mpad * 64;
     const size_t x_cstride = (size_t)a.Lp * 64;            // bytes per 32-channel chunk
-    const char* X_hi = (const char*)a.X_hi + (((size_t)b * a.xc + kbeg) * a.Lp + a.halo + t0) * 64 + thr_off;
-    const char* X_lo = (const char*)a.X_lo + (((size_t)b * a.xc + kbeg) * a.Lp + a.halo + t0) * 64 + thr_off;
+    const int xbs = a.xbs ? a.xbs : a.xc;            // batch stride of the X planes in chunks
+    const char* X_hi = (const char*)a.X_hi + (((size_t)b * xbs + kbeg) * a.Lp + a.halo + t0) * 64 + thr_off;
+    const char* X_lo = (const char*)a.X_lo + (((size_t)b * xbs + kbeg) * a.Lp + a.halo + t0) * 64 + thr_off;
     const char* S_hi = (const char*)a.S_hi + ((size_t)b * a.sc * a.Lp + a.halo + t0) * 64 + thr_off;
     const char* S_lo = (const char*)a.S_lo + ((size_t)b * a.sc * a.Lp + a.halo + t0) * 64 + thr_off;
     char* lds_wave = smem + wave * 1024;                   // + lane*16 is implicit in the DMA
@@ -365,8 +366,8 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
     const int n_units = (T2S_TILE_N + 2 * d + 15) >> 4;    // 16-row units of the extended tile
     const int unit_off = (lane >> 2) * 64 + (((lane & 3) ^ swz4((lane >> 4) & 3)) * 16);
     // extended-tile sources without the workgroup-wide DMA thread offset
-    const char* Xe_hi = (const char*)a.X_hi + (((size_t)b * xc) * a.Lp + a.halo + t0 - d) * 64 + unit_off;
-    const char* Xe_lo = (const char*)a.X_lo + (((size_t)b * xc) * a.Lp + a.halo + t0 - d) * 64 + unit_off;
+    const char* Xe_hi = (const char*)a.X_hi + (((size_t)b * xbs) * a.Lp + a.halo + t0 - d) * 64 + unit_off;
+    const char* Xe_lo = (const char*)a.X_lo + (((size_t)b * xbs) * a.Lp + a.halo + t0 - d) * 64 + unit_off;
     auto issue_a = [&](int kidx, int buf) {
         char* dst = lds_wave + buf * AR;
         const char* ah = A_hi + (size_t)kidx * a_kstride;

@@ -151,14 +151,14 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
             int t = a.ph_P * f + phi;
             t = t < a.L ? t : a.L - 1;
             const int fm = f < a.ph_Fp ? f : a.ph_Fp - 1;
-            Xb[h] = (const char*)a.X_hi + (((size_t)bb * a.xc) * a.Lp + a.halo + t) * 64 + inrow;
+            Xb[h] = (const char*)a.X_hi + (((size_t)bb * (a.xbs ? a.xbs : a.xc)) * a.Lp + a.halo + t) * 64 + inrow;
             Sb[h] = (const char*)a.S_hi + (((size_t)bb * a.sc) * a.ph_Fp + fm) * 64 + inrow;
         }
         const long ph_off = (long)phi * (long)a.sc * (long)a_kstride;
         a2d_hi = ((const char*)a.A2_hi + ph_off) - (const char*)a.A_hi;
         a2d_lo = ((const char*)a.A2_lo + ph_off) - (const char*)a.A_lo;
     } else {
-        Xb[0] = (const char*)a.X_hi + (((size_t)b * a.xc) * a.Lp + a.halo + t0) * 64 + thr_off;
+        Xb[0] = (const char*)a.X_hi + (((size_t)b * (a.xbs ? a.xbs : a.xc)) * a.Lp + a.halo + t0) * 64 + thr_off;
         Sb[0] = (const char*)a.S_hi + ((size_t)b * a.sc * a.Lp + a.halo + t0) * 64 + thr_off;
         Xb[1] = Xb[0] + PP_HALF;
         Sb[1] = Sb[0] + PP_HALF;

@@ -80,13 +80,14 @@ int t2s_wg_res_skip_train(const void* A_hi, const void* A_lo, const float* bias,
 
 int t2s_wg_bwd_gate_dgrad(const void* A_hi, const void* A_lo, const float* zero_bias, const void* DX_hi,
                           const void* DX_lo, const void* DS_hi, const void* DS_lo, const void* T_hi, const void* T_lo,
-                          const void* G_hi, const void* G_lo, void* DP_hi, void* DP_lo, int B, int C, int L, int Lp,
+                          const void* G_hi, const void* G_lo, void* DP_hi, void* DP_lo, int dp_bchunks, int B, int C, int L, int Lp,
                           int halo, int Mpad, void* stream) {
     if (!planes_ok(A_hi, A_lo) || !planes_ok(DS_hi, DS_lo) || !planes_ok(T_hi, T_lo) || !planes_ok(G_hi, G_lo) ||
         !planes_ok(DP_hi, DP_lo) || !zero_bias)
         return T2S_EINVAL;
     if (DX_hi && !planes_ok(DX_hi, DX_lo)) return T2S_EINVAL;
     if (B <= 0 || L <= 0 || C <= 0 || C % 32 || Lp != t2s_plane_rows(L, halo) || Mpad % 256 || Mpad < C) return T2S_EINVAL;
+    if (dp_bchunks != 0 && dp_bchunks < 2 * (C / 32)) return T2S_EINVAL;
     ConvGemmArgs a;
     memset(&a, 0, sizeof(a));
     a.A_hi = (const u16*)A_hi; a.A_lo = (const u16*)A_lo;
@@ -99,7 +100,7 @@ int t2s_wg_bwd_gate_dgrad(const void* A_hi, const void* A_lo, const float* zero_
     }
     a.bias = zero_bias; a.O_hi = (u16*)DP_hi; a.O_lo = (u16*)DP_lo;
     a.T_hi = (u16*)T_hi; a.T_lo = (u16*)T_lo; a.G_hi = (u16*)G_hi; a.G_lo = (u16*)G_lo;
-    a.oc = 2 * cc; a.tc = cc;
+    a.oc = dp_bchunks ? dp_bchunks : 2 * cc; a.tc = cc;      // oc = batch stride of the output planes (a slice of a wider set)
     a.taps = 1; a.dil = 1; a.nk_x = a.xc; a.nk = a.xc + a.sc;
     a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
     a.n_ttiles = cdiv(L, 256);
@@ -112,17 +113,18 @@ int t2s_wg_bwd_gate_dgrad(const void* A_hi, const void* A_lo, const float* zero_
 }
 
 int t2s_conv_accumulate(const void* A_hi, const void* A_lo, const float* zero_bias, const void* X_hi, const void* X_lo,
-                        void* O_hi, void* O_lo, int B, int Cin, int Cout, int taps, int dilation, int init, int L, int Lp,
+                        int x_bchunks, void* O_hi, void* O_lo, int B, int Cin, int Cout, int taps, int dilation, int init, int L, int Lp,
                         int halo, int Mpad, void* stream) {
     if (!planes_ok(A_hi, A_lo) || !planes_ok(X_hi, X_lo) || !planes_ok(O_hi, O_lo) || !zero_bias) return T2S_EINVAL;
     if (B <= 0 || L <= 0 || Cin <= 0 || Cout <= 0 || Cout % 4 || taps <= 0 || !(taps & 1) || dilation <= 0) return T2S_EINVAL;
     if ((taps / 2) * dilation > halo || Lp != t2s_plane_rows(L, halo) || Mpad % 256 || Mpad < Cout) return T2S_EINVAL;
+    if (x_bchunks != 0 && x_bchunks < cdiv(Cin, 32)) return T2S_EINVAL;
     ConvGemmArgs a;
     memset(&a, 0, sizeof(a));
     a.A_hi = (const u16*)A_hi; a.A_lo = (const u16*)A_lo;
     a.X_hi = (const u16*)X_hi; a.X_lo = (const u16*)X_lo;
     a.bias = zero_bias; a.O_hi = (u16*)O_hi; a.O_lo = (u16*)O_lo;
-    a.xc = cdiv(Cin, 32); a.sc = 0; a.oc = cdiv(Cout, 32);
+    a.xc = cdiv(Cin, 32); a.sc = 0; a.oc = cdiv(Cout, 32); a.xbs = x_bchunks;
     a.taps = taps; a.dil = dilation; a.nk_x = taps * a.xc; a.nk = a.nk_x;
     a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
     a.n_ttiles = cdiv(L, 256);

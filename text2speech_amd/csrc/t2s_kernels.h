@@ -24,6 +24,7 @@ struct ConvGemmArgs {
     int nk;            // total K-steps = taps*xc + sc
     int nk_x;          // taps*xc
     int xc, sc, oc;    // 32-channel chunks of X, S and the output
+    int xbs;           // chunks between batch entries of the X planes (0: xc) - X may be a slice of a wider plane set
     int taps, dil;
     int Mpad, Lp, halo, L, B;
     int n_mtiles, n_ttiles;

@@ -58,7 +58,12 @@ def _alloc_train(eng, B, L, dev):
     nt = Lp // 32
     st.nt = nt
     st.DX, st.DS = pl(xc), pl(xc)
-    st.DP = pl(2 * xc)
+    # d_pre of ALL layers of a flow side by side (layer i = chunks [2 xc i, 2 xc (i + 1)) of every batch entry; 0.6 GB at
+    # 8 x 16000): the conditioning gradient d_spect += sum_i W_cond,i^T d_pre_i is then ONE GEMM per flow with K = n_layers * 2C
+    # instead of one 192-workgroup GEMM and one read-modify-write of d_spect per layer, and a layer's d_pre stays valid until the
+    # flow ends (the weight-gradient stream may lag behind the data-gradient chain)
+    st.DP = pl(nl * 2 * xc)
+    st.dp_chunks = nl * 2 * xc
     st.DSp = pl(sc)
     st.N2 = 3 * C + g["n_cond"] + 1
     st.N2pad = -(-st.N2 // 256) * 256
@@ -101,7 +106,7 @@ def _alloc_train(eng, B, L, dev):
     st.Ms = _lib.padded_rows(g["n_cond"])
     st.A_rsT = (_bf(2 * C // 32, st.Mc, 32, dev=dev), _bf(2 * C // 32, st.Mc, 32, dev=dev))
     st.A_inT = (_bf(g["ks"] * 2 * C // 32, st.Mc, 32, dev=dev), _bf(g["ks"] * 2 * C // 32, st.Mc, 32, dev=dev))
-    st.A_cT = (_bf(2 * C // 32, st.Ms, 32, dev=dev), _bf(2 * C // 32, st.Ms, 32, dev=dev))
+    st.A_cT = (_bf(nl * 2 * C // 32, st.Ms, 32, dev=dev), _bf(nl * 2 * C // 32, st.Ms, 32, dev=dev))      # K = (layer, channel)
     st.zero_bias = torch.zeros(max(st.M2pad, st.Ms, 1024), dtype=torch.float32, device=dev)
     st.sw_scratch = torch.empty(_lib.load().t2s_small_wgrad_scratch(B, xc), dtype=torch.float32, device=dev)
     # channel-last weight-gradient GEMM (t2s_wgrad_cl): constant chunks and the per-layer operand tables (built on first use)
@@ -113,12 +118,12 @@ def _alloc_train(eng, B, L, dev):
     return st
 
 
-def _chunk_rows(pair, n_chunks, shift=0):
-    """t2s_wgrad_chunk rows of the first n_chunks 32-channel chunks of a (hi, lo) plane pair [B, chunks, Lp, 32], rows shifted by
+def _chunk_rows(pair, n_chunks, shift=0, first=0):
+    """t2s_wgrad_chunk rows of chunks [first, first + n_chunks) of a (hi, lo) plane pair [B, chunks, Lp, 32], rows shifted by
     `shift` (a dilated tap)."""
     hi, lo = pair
     Bc, nch, Lp, _ = hi.shape
-    return [[hi.data_ptr() + 2 * (c * Lp + shift) * 32, lo.data_ptr() + 2 * (c * Lp + shift) * 32, nch * Lp * 32]
+    return [[hi.data_ptr() + 2 * ((first + c) * Lp + shift) * 32, lo.data_ptr() + 2 * ((first + c) * Lp + shift) * 32, nch * Lp * 32]
             for c in range(n_chunks)]
 
 
@@ -129,7 +134,7 @@ def _chunk_table(ts, rows, dev):
     return torch.tensor(rows, dtype=torch.int64).to(dev)
 
 
-def _cl_tables(ts, key, lay_sv, last, xc, sc, ks, d, dev):
+def _cl_tables(ts, key, lay_sv, last, xc, sc, ks, d, dev, layer):
     """Operand tables of the two weight-gradient GEMMs of one WN layer (the buffers they point at are allocated once per shape,
     so the tables are built once)."""
     t = ts.cl_tables.get(key)
@@ -138,7 +143,7 @@ def _cl_tables(ts, key, lay_sv, last, xc, sc, ks, d, dev):
     ones = [[ts.ones_plane.data_ptr(), ts.zero_plane.data_ptr(), 0]]
     a1 = ([] if last else _chunk_rows(ts.DX, xc)) + _chunk_rows(ts.DS, xc)            # [d_x ; d_skip]
     b1 = _chunk_rows(lay_sv["A"], xc) + ([] if ts.bias_cols else ones)                  # [acts | 1] (or the kernel's row sums)
-    a2 = _chunk_rows(ts.DP, 2 * xc)                                                     # d_pre (tanh half, sigmoid half)
+    a2 = _chunk_rows(ts.DP, 2 * xc, first=layer * 2 * xc)                               # d_pre (tanh half, sigmoid half)
     b2 = []
     for tap in range(ks):
         b2 += _chunk_rows(lay_sv["X"], xc, (tap - ks // 2) * d)                         # x shifted by the dilated tap
@@ -230,9 +235,9 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
     xc, sc = g["Cpad"] // 32, g["Spad"] // 32
     # Two streams.  Per layer the weight-gradient work (seven HBM-bound plane transposes, two weight-gradient GEMMs, three
     # weight-norm reductions) never feeds the data-gradient chain (gate backward -> W_in^T / W_cond^T accumulate), so it runs
-    # on a side stream; events guard the three d-plane buffers the two share (DX / DS: transposed before the chain updates
-    # them in place; DP: transposed before the next layer's gate backward overwrites it).  The time-major planes and the
-    # split-K slabs belong to the side stream alone.
+    # on a side stream; events guard the d-plane buffers the two share (DX / DS: read by the weight-gradient GEMM before the
+    # chain updates DX in place; every layer has its own slice of the flow-wide d_pre planes, which the next flow reuses only
+    # after the two streams have joined).  The split-K slabs belong to the side stream alone.
     main_s = torch.cuda.current_stream(dev)
     two = not os.environ.get("T2S_WG_BWD_ONE_STREAM")
     side_s = getattr(eng, "bwd_side_stream", None)
@@ -242,7 +247,6 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         side_s = main_s
     st2 = _lib.c_vp(side_s.cuda_stream)
     side_s.wait_stream(main_s)
-    ev_dx_ready, ev_tdp_done = None, None
     cl = ts.cl_ok       # weight-gradient GEMMs straight from the channel-last planes (no time-major copies)
     if not cl:
         # conditioning rows + the ones row of the in/cond weight-gradient GEMM are the same for every layer
@@ -251,6 +255,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         _lib.call("t2s_tm_ones_row", _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), B, Lp, halo, L, ts.N2pad, ts.N2 - 1, st2)
         _lib.call("t2s_tm_ones_row", _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]), B, Lp, halo, L, ts.N1pad, C, st2)
     dsp_init = 1
+    per_layer_cond = bool(os.environ.get("T2S_WCOND_PER_LAYER"))
     keep = []
 
     def new(*shape):
@@ -350,11 +355,12 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                       _ptr(ts.A_rsT[1]), st)
             ev_in = torch.cuda.Event()          # DX / DS of this layer are final (last written on the main stream)
             ev_in.record(main_s)
-            if ev_tdp_done is not None:
-                main_s.wait_event(ev_tdp_done)  # the side stream has transposed the previous layer's d_pre out of DP
+            # this layer's slice of the flow-wide d_pre planes (bytes from the start of each plane)
+            dp_off = 2 * i * 2 * xc * Lp * 32
+            dp_h, dp_l = _lib.c_vp(ts.DP[0].data_ptr() + dp_off), _lib.c_vp(ts.DP[1].data_ptr() + dp_off)
             _lib.call("t2s_wg_bwd_gate_dgrad", _ptr(ts.A_rsT[0]), _ptr(ts.A_rsT[1]), _ptr(zb),
                       None if last else _ptr(ts.DX[0]), None if last else _ptr(ts.DX[1]), _ptr(ts.DS[0]), _ptr(ts.DS[1]),
-                      _ptr(sv["A"][0]), _ptr(sv["A"][1]), _ptr(sv["G"][0]), _ptr(sv["G"][1]), _ptr(ts.DP[0]), _ptr(ts.DP[1]),
+                      _ptr(sv["A"][0]), _ptr(sv["A"][1]), _ptr(sv["G"][0]), _ptr(sv["G"][1]), dp_h, dp_l, ts.dp_chunks,
                       B, C, L, Lp, halo, ts.Mc, st)
             ev_dp = torch.cuda.Event()
             ev_dp.record(main_s)
@@ -362,7 +368,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             side_s.wait_event(ev_in)
             d = 2 ** i
             if cl:
-                ta1, tb1, ta2, tb2 = _cl_tables(ts, (k, i), sv, last, xc, sc, ks, d, dev)
+                ta1, tb1, ta2, tb2 = _cl_tables(ts, (k, i), sv, last, xc, sc, ks, d, dev, i)
                 ks1 = ts.ks1_last if last else ts.ks1
                 _lib.call("t2s_wgrad_cl", _ptr(ta1), ta1.size(0), _ptr(tb1), tb1.size(0), _ptr(ts.P1), B, rows2, ts.N1g, ts.ld1,
                           ts.k0, ts.k1, ks1, ts.bias_cols, st2)
@@ -387,13 +393,9 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             if cl:
                 _lib.call("t2s_wgrad_cl", _ptr(ta2), ta2.size(0), _ptr(tb2), tb2.size(0), _ptr(ts.P2), B, 2 * C, ts.N2, ts.ld2,
                           ts.k0, ts.k1, ts.ks2, 0, st2)
-                ev_tdp_done = torch.cuda.Event()    # d_pre has been read: the next layer's gate backward may overwrite DP
-                ev_tdp_done.record(side_s)
             else:
-                _lib.call("t2s_plane_transpose", _ptr(ts.DP[0]), _ptr(ts.DP[1]), B, 2 * xc, 2 * xc, Lp, 0, _ptr(ts.TM_dp[0]),
+                _lib.call("t2s_plane_transpose", dp_h, dp_l, B, ts.dp_chunks, 2 * xc, Lp, 0, _ptr(ts.TM_dp[0]),
                           _ptr(ts.TM_dp[1]), ts.M2pad, 0, st2)
-                ev_tdp_done = torch.cuda.Event()
-                ev_tdp_done.record(side_s)
                 for tap in range(ks):
                     _lib.call("t2s_plane_transpose", _ptr(sv["X"][0]), _ptr(sv["X"][1]), B, xc, xc, Lp, (tap - ks // 2) * d,
                               _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), ts.N2pad, tap * C, st2)
@@ -406,13 +408,22 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             _lib.call("t2s_pack_transposed", _ptr(v_in), _ptr(s_in), 2 * C, C, ks, 1, 2 * C, ts.Mc, 0, _ptr(ts.A_inT[0]),
                       _ptr(ts.A_inT[1]), st)
             main_s.wait_event(ev_tdrs)
-            _lib.call("t2s_conv_accumulate", _ptr(ts.A_inT[0]), _ptr(ts.A_inT[1]), _ptr(zb), _ptr(ts.DP[0]), _ptr(ts.DP[1]),
+            _lib.call("t2s_conv_accumulate", _ptr(ts.A_inT[0]), _ptr(ts.A_inT[1]), _ptr(zb), dp_h, dp_l, ts.dp_chunks,
                       _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, 2 * C, C, ks, d, 1 if last else 0, L, Lp, halo, ts.Mc, st)
+            # W_cond,i^T goes into K-chunks [2 xc i, 2 xc (i + 1)) of the flow's conditioning-gradient GEMM
             v_c, s_c = scale_of(conv_c, pk["s_cond"])
-            _lib.call("t2s_pack_transposed", _ptr(v_c), _ptr(s_c), 2 * C, n_cond, 1, 0, 2 * C, ts.Ms, 0, _ptr(ts.A_cT[0]),
+            _lib.call("t2s_pack_transposed", _ptr(v_c), _ptr(s_c), 2 * C, n_cond, 1, 0, 2 * C, ts.Ms, i * 2 * C, _ptr(ts.A_cT[0]),
                       _ptr(ts.A_cT[1]), st)
-            _lib.call("t2s_conv_accumulate", _ptr(ts.A_cT[0]), _ptr(ts.A_cT[1]), _ptr(zb), _ptr(ts.DP[0]), _ptr(ts.DP[1]),
-                      _ptr(ts.DSp[0]), _ptr(ts.DSp[1]), B, 2 * C, n_cond, 1, 1, dsp_init, L, Lp, halo, ts.Ms, st)
+            if per_layer_cond:          # A/B switch (T2S_WCOND_PER_LAYER=1): the round-2 form, one accumulate per layer
+                a_off = 2 * i * 2 * xc * ts.Ms * 32
+                _lib.call("t2s_conv_accumulate", _lib.c_vp(ts.A_cT[0].data_ptr() + a_off), _lib.c_vp(ts.A_cT[1].data_ptr() + a_off),
+                          _ptr(zb), dp_h, dp_l, ts.dp_chunks, _ptr(ts.DSp[0]), _ptr(ts.DSp[1]), B, 2 * C, n_cond, 1, 1, dsp_init,
+                          L, Lp, halo, ts.Ms, st)
+                dsp_init = 0
+        # d_spect (+)= [W_cond,0^T | ... | W_cond,nl-1^T] [d_pre_0 ; ... ; d_pre_nl-1]: one GEMM per flow, K = nl * 2C       [main]
+        if not per_layer_cond:
+            _lib.call("t2s_conv_accumulate", _ptr(ts.A_cT[0]), _ptr(ts.A_cT[1]), _ptr(zb), _ptr(ts.DP[0]), _ptr(ts.DP[1]), 0,
+                      _ptr(ts.DSp[0]), _ptr(ts.DSp[1]), B, nl * 2 * C, n_cond, 1, 1, dsp_init, L, Lp, halo, ts.Ms, st)
             dsp_init = 0
         # ---- WN.start ----
         dW_eff = new(C, n_half)

@@ -58,7 +58,7 @@ def encoder_backward(bw, d_memory):
     dgp = (bw.bf(B, M // 32, Lp, 32), bw.bf(B, M // 32, Lp, 32))
     _lib.call("t2s_rows_to_planes", _p(dgx), B, T, M, Lp, halo, _p(dgp[0]), _p(dgp[1]), st)
     dx = (bw.bf(B, icc, Lp, 32), bw.bf(B, icc, Lp, 32))
-    _lib.call("t2s_conv_accumulate", _p(At[0]), _p(At[1]), _p(bw.zero_bias), _p(dgp[0]), _p(dgp[1]), _p(dx[0]), _p(dx[1]), B, M,
+    _lib.call("t2s_conv_accumulate", _p(At[0]), _p(At[1]), _p(bw.zero_bias), _p(dgp[0]), _p(dgp[1]), 0, _p(dx[0]), _p(dx[1]), B, M,
               Cin, 1, 1, 1, T, Lp, halo, Mi, st)
     # ---- conv + BatchNorm stack, then the embedding ----
     d_emb_in = bw.conv_bn_stack_backward(sv["enc_convs"], dout_planes=dx)
