@@ -179,7 +179,7 @@ int t2s_wg_res_only(const void* A_hi, const void* A_lo, const float* bias, const
                     void* X_hi, void* X_lo, int B, int C, int L, int Lp, int halo, int Mpad, int pair8, void* stream);
 /* WN.end output from the folded accumulators + affine coupling (forward or reverse) */
 int t2s_wg_end_fold_affine(const float* fold_acc, int nslots, const float* bes, int n_layers, const float* b_end,
-                           float* z, float* log_s, int B, int n_group, int c_off, int n_half, int L, int reverse,
+                           float* z, float* log_s, float* wn_out, int B, int n_group, int c_off, int n_half, int L, int reverse,
                            void* stream);
 
 /* Generic split-bf16 conv1d-as-GEMM with bias + activation epilogue:
@@ -309,16 +309,39 @@ int t2s_wg_res_skip_train(const void* A_hi, const void* A_lo, const float* bias,
                           const void* acts_lo, const void* R_hi, const void* R_lo, void* X_hi, void* X_lo, float* skip,
                           int B, int C, int n_res, int skip_init, int L, int Lp, int halo, int Mpad, void* stream);
 
+/* Training forward on the no-grad forward's kernels (round 3).  The skip path only ever feeds WN.end (glow.py:172-175), so the
+ * training forward folds it into the gate GEMM's epilogue exactly as the no-grad forward does (t2s_wg_in_cond_gate_fold) and
+ * never forms the skip sum; the backward pass, which needs it once per flow for WN.end's weight gradient, rebuilds it with
+ * t2s_wg_skip_sum from the saved gate outputs.  What training adds to the forward is only what it saves:
+ *   t2s_wg_in_cond_gate_fold_train = t2s_wg_in_cond_gate_fold + the sigmoid planes G (tanh is rebuilt as acts / G) + act_bchunks:
+ *     32-channel chunks between batch entries of the acts / G planes (0 = C/32), so that the gate outputs of all layers of a flow
+ *     can sit side by side in one plane set;
+ *   t2s_wg_res_only_train = t2s_wg_res_only reading the layer input from R and writing the next layer's input to X (both are kept);
+ *   t2s_wg_end_fold_affine(wn_out != NULL) also stores (b ; log_s) for the coupling's backward.
+ * t2s_wg_skip_sum: skip[b][c][t] = bias[c] + sum_k A[k][c] * acts[b][k][t] over n_k_chunks * 32 K channels - with A the skip rows
+ * of a flow's res_skip weights packed one after the other along K (t2s_pack_conv_weight, koff = layer * C) and acts the flow-wide
+ * planes, this is sum_i (W_skip,i acts_i + b_skip,i): f32 planes [B][C/32][Lp][32] as t2s_wg_res_skip_train writes them. */
+int t2s_wg_in_cond_gate_fold_train(const void* A_hi, const void* A_lo, const float* bias, const void* X_hi, const void* X_lo,
+                                   const void* S_hi, const void* S_lo, void* acts_hi, void* acts_lo, void* G_hi, void* G_lo,
+                                   int act_bchunks, const void* fold_A, float* fold_acc, int fold_init, int B, int C, int n_cond,
+                                   int taps, int dilation, int L, int Lp, int halo, int Mpad, void* stream);
+int t2s_wg_res_only_train(const void* A_hi, const void* A_lo, const float* bias, const void* acts_hi, const void* acts_lo,
+                          int act_bchunks, const void* R_hi, const void* R_lo, void* X_hi, void* X_lo, int B, int C, int L, int Lp,
+                          int halo, int Mpad, int pair8, void* stream);
+int t2s_wg_skip_sum(const void* A_hi, const void* A_lo, const float* bias, const void* acts_hi, const void* acts_lo,
+                    int n_k_chunks, int act_bchunks, float* skip, int B, int C, int L, int Lp, int halo, int Mpad, void* stream);
+
 /* d_pre = gate'(acts, G) * (W_rs^T [d_x ; d_skip]):  data gradient of res_skip_layers[i] fused with the backward of
  * tanh*sigmoid (glow.py:33-40,164), from the layer's saved gate output acts = tanh * sigmoid and G = sigmoid (tanh = acts / G).
  * A = t2s_pack_transposed(W_rs); DX may be NULL (last layer: skip rows only).
  * DP planes have 2C channels (tanh half, then sigmoid half).  dp_bchunks: 32-channel chunks between batch entries of the DP
  * planes (0 = 2C/32): DP may be a slice of a wider plane set - the training path keeps the d_pre of all layers of a flow side
- * by side so that the conditioning gradient is ONE K-concatenated GEMM per flow. */
+ * by side so that the conditioning gradient is ONE K-concatenated GEMM per flow.  tg_bchunks: the same for the acts / G planes
+ * (0 = C/32): the training forward keeps the gate outputs of a flow's layers side by side too (t2s_wg_skip_sum). */
 int t2s_wg_bwd_gate_dgrad(const void* A_hi, const void* A_lo, const float* zero_bias, const void* DX_hi,
                           const void* DX_lo, const void* DS_hi, const void* DS_lo, const void* acts_hi, const void* acts_lo,
-                          const void* G_hi, const void* G_lo, void* DP_hi, void* DP_lo, int dp_bchunks, int B, int C, int L, int Lp,
-                          int halo, int Mpad, void* stream);
+                          const void* G_hi, const void* G_lo, int tg_bchunks, void* DP_hi, void* DP_lo, int dp_bchunks, int B, int C,
+                          int L, int Lp, int halo, int Mpad, void* stream);
 
 /* O (+)= conv(X) with packed (transposed) weights: data gradients of in_layers[i] (dilated, taps mirrored) and
  * cond_layers[i].  init=1 stores, init=0 accumulates into the O planes.  x_bchunks: chunks between batch entries of the X

@@ -44,7 +44,7 @@ SIGNATURES = {
     "t2s_wg_melwin_planes": [c_vp] + [c_int] * 5 + [c_vp, c_vp, c_vp],
     "t2s_wg_in_melwin_gate_fold": [c_vp] * 13 + [c_int] * 12 + [c_vp],
     "t2s_wg_res_only": [c_vp] * 7 + [c_int] * 7 + [c_vp],
-    "t2s_wg_end_fold_affine": [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
+    "t2s_wg_end_fold_affine": [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
     "t2s_wg_end_affine": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                           c_int, c_vp],
     "t2s_conv_bias_act": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
@@ -84,7 +84,10 @@ SIGNATURES = {
     "t2s_planes_to_f32": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp],
     "t2s_wg_in_cond_gate_train": [c_vp] * 13 + [c_int] * 9 + [c_vp],
     "t2s_wg_res_skip_train": [c_vp] * 10 + [c_int] * 8 + [c_vp],
-    "t2s_wg_bwd_gate_dgrad": [c_vp] * 13 + [c_int] * 7 + [c_vp],
+    "t2s_wg_bwd_gate_dgrad": [c_vp] * 11 + [c_int] + [c_vp] * 2 + [c_int] * 7 + [c_vp],
+    "t2s_wg_in_cond_gate_fold_train": [c_vp] * 11 + [c_int] + [c_vp] * 2 + [c_int] * 10 + [c_vp],
+    "t2s_wg_res_only_train": [c_vp] * 5 + [c_int] + [c_vp] * 4 + [c_int] * 7 + [c_vp],
+    "t2s_wg_skip_sum": [c_vp] * 5 + [c_int] * 2 + [c_vp] + [c_int] * 6 + [c_vp],
     "t2s_conv_accumulate": [c_vp] * 5 + [c_int] + [c_vp] * 2 + [c_int] * 10 + [c_vp],
     "t2s_wgrad_gemm": [c_vp] * 6 + [c_int] * 9 + [c_vp],
     "t2s_wgrad_gemm_flat": [c_vp] * 6 + [c_int] * 9 + [c_vp],

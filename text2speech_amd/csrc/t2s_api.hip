@@ -321,11 +321,11 @@ int t2s_wg_res_only(const void* A_hi, const void* A_lo, const float* bias, const
 }
 
 int t2s_wg_end_fold_affine(const float* fold_acc, int nslots, const float* bes, int n_layers, const float* b_end,
-                           float* z, float* log_s, int B, int n_group, int c_off, int n_half, int L, int reverse,
+                           float* z, float* log_s, float* wn_out, int B, int n_group, int c_off, int n_half, int L, int reverse,
                            void* stream) {
     if (!fold_acc || !bes || !b_end || !z || nslots <= 0 || n_layers <= 0) return T2S_EINVAL;
     if (B <= 0 || L <= 0 || n_half <= 0 || n_half > 4 || c_off < 0 || c_off + 2 * n_half > n_group) return T2S_EINVAL;
-    T2S_CHECK_HIP(t2s_launch_end_fold_affine(fold_acc, nslots, bes, n_layers, b_end, z, log_s, B, n_group, c_off, n_half,
+    T2S_CHECK_HIP(t2s_launch_end_fold_affine(fold_acc, nslots, bes, n_layers, b_end, z, log_s, wn_out, B, n_group, c_off, n_half,
                                              L, reverse, (hipStream_t)stream));
     return T2S_OK;
 }

@@ -56,6 +56,85 @@ int t2s_wg_in_cond_gate_train(const void* A_hi, const void* A_lo, const float* b
     return T2S_OK;
 }
 
+// gate GEMM tile height: the library's own decision (csrc/t2s_api.hip)
+extern "C" int t2s_wg_gate_tile_rows(int B, int C, int L);
+
+int t2s_wg_in_cond_gate_fold_train(const void* A_hi, const void* A_lo, const float* bias, const void* X_hi, const void* X_lo,
+                                   const void* S_hi, const void* S_lo, void* acts_hi, void* acts_lo, void* G_hi, void* G_lo,
+                                   int act_bchunks, const void* fold_A, float* fold_acc, int fold_init, int B, int C, int n_cond,
+                                   int taps, int dilation, int L, int Lp, int halo, int Mpad, void* stream) {
+    if (!planes_ok(A_hi, A_lo) || !planes_ok(X_hi, X_lo) || !planes_ok(acts_hi, acts_lo) || !planes_ok(G_hi, G_lo) || !bias)
+        return T2S_EINVAL;
+    if (!fold_A || !fold_acc || !al16(fold_A) || C % 16) return T2S_EINVAL;
+    if (n_cond > 0 && !planes_ok(S_hi, S_lo)) return T2S_EINVAL;
+    if (B <= 0 || L <= 0 || C <= 0 || taps <= 0 || !(taps & 1) || dilation <= 0) return T2S_EINVAL;
+    if ((taps / 2) * dilation > halo || Lp != t2s_plane_rows(L, halo)) return T2S_EINVAL;
+    if (Mpad % 256 || Mpad < cdiv(C, 128) * 256 || !al16(bias)) return T2S_EINVAL;
+    if (act_bchunks != 0 && act_bchunks < cdiv(C, 32)) return T2S_EINVAL;
+    ConvGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A_hi = (const u16*)A_hi; a.A_lo = (const u16*)A_lo;
+    a.X_hi = (const u16*)X_hi; a.X_lo = (const u16*)X_lo;
+    a.S_hi = (const u16*)S_hi; a.S_lo = (const u16*)S_lo;
+    a.bias = bias; a.O_hi = (u16*)acts_hi; a.O_lo = (u16*)acts_lo;
+    a.G_hi = (u16*)G_hi; a.G_lo = (u16*)G_lo;
+    a.fold_A = (const u16*)fold_A; a.fold_acc = fold_acc; a.fold_init = fold_init;
+    a.xc = cdiv(C, 32); a.sc = cdiv(n_cond, 32);
+    a.oc = act_bchunks ? act_bchunks : cdiv(C, 32); a.tc = a.oc;      // oc = batch stride of the acts / sigmoid planes
+    a.taps = taps; a.dil = dilation;
+    a.nk_x = taps * a.xc; a.nk = a.nk_x + a.sc;
+    a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
+    const int rows = t2s_wg_gate_tile_rows(B, C, L);          // fold_acc holds t2s_wg_gate_fold_slots(B, C, L) slots
+    a.n_mtiles = cdiv(C, rows / 2); a.n_ttiles = cdiv(L, 256);
+    a.C = C;
+    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_GATE, (hipStream_t)stream, rows));
+    return T2S_OK;
+}
+
+int t2s_wg_res_only_train(const void* A_hi, const void* A_lo, const float* bias, const void* acts_hi, const void* acts_lo,
+                          int act_bchunks, const void* R_hi, const void* R_lo, void* X_hi, void* X_lo, int B, int C, int L, int Lp,
+                          int halo, int Mpad, int pair8, void* stream) {
+    if (!planes_ok(A_hi, A_lo) || !planes_ok(acts_hi, acts_lo) || !planes_ok(X_hi, X_lo) || !planes_ok(R_hi, R_lo) || !bias)
+        return T2S_EINVAL;
+    if (B <= 0 || L <= 0 || C <= 0 || C % 4 || Lp != t2s_plane_rows(L, halo) || Mpad % 256 || Mpad < C || !al16(bias)) return T2S_EINVAL;
+    if ((act_bchunks != 0 && act_bchunks < cdiv(C, 32)) || (pair8 && C % 32)) return T2S_EINVAL;
+    ConvGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A_hi = (const u16*)A_hi; a.A_lo = (const u16*)A_lo;
+    a.X_hi = (const u16*)acts_hi; a.X_lo = (const u16*)acts_lo; a.xbs = act_bchunks;
+    a.bias = bias; a.O_hi = (u16*)X_hi; a.O_lo = (u16*)X_lo;
+    a.R_hi = (const u16*)R_hi; a.R_lo = (const u16*)R_lo;
+    a.xc = cdiv(C, 32); a.sc = 0; a.oc = cdiv(C, 32);
+    a.taps = 1; a.dil = 1; a.nk_x = a.xc; a.nk = a.xc;
+    a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
+    a.n_mtiles = cdiv(C, 128); a.n_ttiles = cdiv(L, 256);
+    a.C = 0; a.n_res = C;
+    a.pair8 = pair8 ? 1 : 0;
+    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_RESSKIP, (hipStream_t)stream, 128));
+    return T2S_OK;
+}
+
+int t2s_wg_skip_sum(const void* A_hi, const void* A_lo, const float* bias, const void* acts_hi, const void* acts_lo,
+                    int n_k_chunks, int act_bchunks, float* skip, int B, int C, int L, int Lp, int halo, int Mpad, void* stream) {
+    if (!planes_ok(A_hi, A_lo) || !planes_ok(acts_hi, acts_lo) || !bias || !skip || !al16(skip) || !al16(bias)) return T2S_EINVAL;
+    if (B <= 0 || L <= 0 || C <= 0 || C % 4 || n_k_chunks <= 0 || Lp != t2s_plane_rows(L, halo) || Mpad % 256 || Mpad < C) return T2S_EINVAL;
+    if (act_bchunks != 0 && act_bchunks < n_k_chunks) return T2S_EINVAL;
+    ConvGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A_hi = (const u16*)A_hi; a.A_lo = (const u16*)A_lo;
+    a.X_hi = (const u16*)acts_hi; a.X_lo = (const u16*)acts_lo; a.xbs = act_bchunks;
+    a.bias = bias; a.skip = skip;
+    a.xc = n_k_chunks; a.sc = 0; a.oc = cdiv(C, 32);
+    a.taps = 1; a.dil = 1; a.nk_x = a.xc; a.nk = a.xc;
+    a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
+    a.n_ttiles = cdiv(L, 256);
+    a.C = C; a.n_res = 0; a.skip_init = 1;
+    const int mt_rows = cdiv(C, 256) * a.n_ttiles * B < 200 ? 128 : 256;
+    a.n_mtiles = cdiv(C, mt_rows);
+    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_RESSKIP, (hipStream_t)stream, mt_rows));
+    return T2S_OK;
+}
+
 int t2s_wg_res_skip_train(const void* A_hi, const void* A_lo, const float* bias, const void* acts_hi,
                           const void* acts_lo, const void* R_hi, const void* R_lo, void* X_hi, void* X_lo, float* skip,
                           int B, int C, int n_res, int skip_init, int L, int Lp, int halo, int Mpad, void* stream) {
@@ -80,14 +159,14 @@ int t2s_wg_res_skip_train(const void* A_hi, const void* A_lo, const float* bias,
 
 int t2s_wg_bwd_gate_dgrad(const void* A_hi, const void* A_lo, const float* zero_bias, const void* DX_hi,
                           const void* DX_lo, const void* DS_hi, const void* DS_lo, const void* T_hi, const void* T_lo,
-                          const void* G_hi, const void* G_lo, void* DP_hi, void* DP_lo, int dp_bchunks, int B, int C, int L, int Lp,
-                          int halo, int Mpad, void* stream) {
+                          const void* G_hi, const void* G_lo, int tg_bchunks, void* DP_hi, void* DP_lo, int dp_bchunks, int B, int C,
+                          int L, int Lp, int halo, int Mpad, void* stream) {
     if (!planes_ok(A_hi, A_lo) || !planes_ok(DS_hi, DS_lo) || !planes_ok(T_hi, T_lo) || !planes_ok(G_hi, G_lo) ||
         !planes_ok(DP_hi, DP_lo) || !zero_bias)
         return T2S_EINVAL;
     if (DX_hi && !planes_ok(DX_hi, DX_lo)) return T2S_EINVAL;
     if (B <= 0 || L <= 0 || C <= 0 || C % 32 || Lp != t2s_plane_rows(L, halo) || Mpad % 256 || Mpad < C) return T2S_EINVAL;
-    if (dp_bchunks != 0 && dp_bchunks < 2 * (C / 32)) return T2S_EINVAL;
+    if ((dp_bchunks != 0 && dp_bchunks < 2 * (C / 32)) || (tg_bchunks != 0 && tg_bchunks < C / 32)) return T2S_EINVAL;
     ConvGemmArgs a;
     memset(&a, 0, sizeof(a));
     a.A_hi = (const u16*)A_hi; a.A_lo = (const u16*)A_lo;
@@ -100,7 +179,8 @@ int t2s_wg_bwd_gate_dgrad(const void* A_hi, const void* A_lo, const float* zero_
     }
     a.bias = zero_bias; a.O_hi = (u16*)DP_hi; a.O_lo = (u16*)DP_lo;
     a.T_hi = (u16*)T_hi; a.T_lo = (u16*)T_lo; a.G_hi = (u16*)G_hi; a.G_lo = (u16*)G_lo;
-    a.oc = dp_bchunks ? dp_bchunks : 2 * cc; a.tc = cc;      // oc = batch stride of the output planes (a slice of a wider set)
+    a.oc = dp_bchunks ? dp_bchunks : 2 * cc;                 // oc = batch stride of the output planes (a slice of a wider set)
+    a.tc = tg_bchunks ? tg_bchunks : cc;                     // the same for the saved gate output / sigmoid planes
     a.taps = 1; a.dil = 1; a.nk_x = a.xc; a.nk = a.xc + a.sc;
     a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
     a.n_ttiles = cdiv(L, 256);

@@ -143,7 +143,7 @@ struct EndFoldJob {        // one WN layer: fold_w[c][j] = sum_o W_end[j][o] * s
 };
 hipError_t t2s_launch_endfold_weights(const EndFoldJob* jobs, int n_jobs, int C, hipStream_t stream);
 hipError_t t2s_launch_end_fold_affine(const float* fold_acc, int nslots, const float* bes, int n_layers,
-                                      const float* b_end, float* z, float* log_s, int B, int n_group, int c_off,
+                                      const float* b_end, float* z, float* log_s, float* wn_out, int B, int n_group, int c_off,
                                       int n_half, int L, int reverse, hipStream_t stream);
 hipError_t t2s_launch_end_affine(const float* skip, const float* w_end, const float* b_end, float* z, float* log_s,
                                  float* wn_out, int B, int n_group, int c_off, int n_half, int C, int L, int Lp, int halo,

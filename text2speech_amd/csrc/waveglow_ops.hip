@@ -940,8 +940,8 @@ hipError_t t2s_launch_endfold_weights(const EndFoldJob* jobs, int n_jobs, int C,
 // out[j][t] = b_end[j] + sum_layers bes[layer][j] + sum_slots fold_acc[slot][b][j][t], then the affine coupling
 // (reference glow.py:175,241-246; reverse: glow.py:276-280)
 __global__ void end_fold_affine_kernel(const float* __restrict__ fold_acc, int nslots, const float* __restrict__ bes,
-                                       int n_layers, const float* __restrict__ b_end, float* z, float* log_s, int B, int G,
-                                       int c_off, int nh, int L, int reverse) {
+                                       int n_layers, const float* __restrict__ b_end, float* z, float* log_s, float* wn_out,
+                                       int B, int G, int c_off, int nh, int L, int reverse) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y, b = blockIdx.z;
     if (t >= L) return;
@@ -955,11 +955,15 @@ __global__ void end_fold_affine_kernel(const float* __restrict__ fold_acc, int n
     const float a1 = *zp;
     *zp = reverse ? (a1 - bb) / expf(ls) : expf(ls) * a1 + bb;
     if (log_s) log_s[((size_t)b * nh + i) * L + t] = ls;
+    if (wn_out) {           // training: (b ; log_s) as WN.end's output, what the coupling's backward reads
+        wn_out[((size_t)b * 2 * nh + i) * L + t] = bb;
+        wn_out[((size_t)b * 2 * nh + nh + i) * L + t] = ls;
+    }
 }
 hipError_t t2s_launch_end_fold_affine(const float* fold_acc, int nslots, const float* bes, int n_layers,
-                                      const float* b_end, float* z, float* log_s, int B, int n_group, int c_off,
+                                      const float* b_end, float* z, float* log_s, float* wn_out, int B, int n_group, int c_off,
                                       int n_half, int L, int reverse, hipStream_t stream) {
     hipLaunchKernelGGL(end_fold_affine_kernel, dim3((L + 255) / 256, n_half, B), dim3(256), 0, stream, fold_acc, nslots, bes,
-                       n_layers, b_end, z, log_s, B, n_group, c_off, n_half, L, reverse);
+                       n_layers, b_end, z, log_s, wn_out, B, n_group, c_off, n_half, L, reverse);
     return hipGetLastError();
 }

@@ -434,8 +434,8 @@ class _Engine:
         if self.use_fold and wn_out is None and skip is None:
             fl = self.packed["flows"][k]
             _lib.call("t2s_wg_end_fold_affine", _lib.ptr(w["fold_acc"]), w["fold_acc"].size(0), _lib.ptr(fl["bes"]),
-                      g["nl"], _lib.ptr(b_end), _lib.ptr(z), _lib.ptr(log_s), B, m.n_group, c_off, n_half, L,
-                      1 if reverse else 0, _lib.current_stream())
+                      g["nl"], _lib.ptr(b_end), _lib.ptr(z), _lib.ptr(log_s), _lib.ptr(w.get("wn_out")), B, m.n_group, c_off,
+                      n_half, L, 1 if reverse else 0, _lib.current_stream())
             return
         _lib.call("t2s_wg_end_affine", _lib.ptr(w["skip"] if skip is None else skip), _lib.ptr(w_end), _lib.ptr(b_end),
                   _lib.ptr(z), _lib.ptr(log_s), _lib.ptr(wn_out), B, m.n_group, c_off, n_half, g["C"], L, w["Lp"], g["halo"], 1 if reverse else 0,

@@ -46,13 +46,29 @@ def _alloc_train(eng, B, L, dev):
     st.Lp = Lp
     pl = lambda ch: (_bf(B, ch, Lp, 32, dev=dev), _bf(B, ch, Lp, 32, dev=dev))
     st.S_planes = pl(sc)
-    st.layers = []
+    # Training forward = the no-grad forward's kernels (WN.end folded into the gate GEMM's epilogue, residual-only GEMM on
+    # 128-row tiles) + what the backward needs: every layer's input x, gate output and sigmoid.  The skip sum is never formed in
+    # the forward; the backward rebuilds it once per flow from the saved gate outputs (t2s_wg_skip_sum), which is why the gate
+    # outputs of a flow's layers sit side by side in ONE plane set (layer i = chunks [xc i, xc (i + 1)) of every batch entry).
+    st.fold_train = C % 16 == 0 and eng.use_fold and not os.environ.get("T2S_TRAIN_NO_FOLD")
+    st.act_bchunks = nl * xc if st.fold_train else 0
+    st.layers, st.AF, st.GF = [], [], []
     for k in range(m.n_flows):
-        fl = []
-        for i in range(nl):
-            fl.append(dict(X=pl(xc), A=pl(xc), G=pl(xc)))       # tanh is not kept: the backward rebuilds it as A / G
-        st.layers.append(fl)
-    st.skip = [torch.zeros(B, xc, Lp, 32, dtype=torch.float32, device=dev) for _ in range(m.n_flows)]
+        if st.fold_train:
+            st.AF.append(pl(nl * xc))
+            st.GF.append(pl(nl * xc))
+            st.layers.append([dict(X=pl(xc)) for _ in range(nl)])
+        else:
+            st.layers.append([dict(X=pl(xc), A=pl(xc), G=pl(xc)) for _ in range(nl)])   # tanh is rebuilt as A / G
+    if st.fold_train:
+        st.fold_acc = torch.zeros(_lib.load().t2s_wg_gate_fold_slots(B, C, L), B, 8, L, dtype=torch.float32, device=dev)
+        st.skip = [torch.zeros(B, xc, Lp, 32, dtype=torch.float32, device=dev)] * m.n_flows      # one buffer, rebuilt per flow
+        st.Mskip = _lib.padded_rows(C)
+        st.A_skip = (_bf(nl * g["Cpad"] // 32, st.Mskip, 32, dev=dev), _bf(nl * g["Cpad"] // 32, st.Mskip, 32, dev=dev))
+        st.bias_skip = torch.zeros(st.Mskip, dtype=torch.float32, device=dev)
+        st.sw_scratch_side = torch.empty(_lib.load().t2s_small_wgrad_scratch(B, xc), dtype=torch.float32, device=dev)
+    else:
+        st.skip = [torch.zeros(B, xc, Lp, 32, dtype=torch.float32, device=dev) for _ in range(m.n_flows)]
     st.wn_out = [None] * m.n_flows
     # backward scratch
     nt = Lp // 32
@@ -118,6 +134,16 @@ def _alloc_train(eng, B, L, dev):
     return st
 
 
+def _act_ptrs(ts, k, i, which):
+    """(hi, lo) device pointers of layer i's saved gate output (which = "A") or sigmoid ("G") in flow k."""
+    if not ts.fold_train:
+        t = ts.layers[k][i][which]
+        return _ptr(t[0]), _ptr(t[1])
+    pair = ts.AF[k] if which == "A" else ts.GF[k]
+    off = 2 * i * (pair[0].size(1) // len(ts.layers[k])) * pair[0].size(2) * 32          # bytes: xc chunks x Lp rows x 32 ch
+    return _lib.c_vp(pair[0].data_ptr() + off), _lib.c_vp(pair[1].data_ptr() + off)
+
+
 def _chunk_rows(pair, n_chunks, shift=0, first=0):
     """t2s_wgrad_chunk rows of chunks [first, first + n_chunks) of a (hi, lo) plane pair [B, chunks, Lp, 32], rows shifted by
     `shift` (a dilated tap)."""
@@ -135,6 +161,7 @@ def _chunk_table(ts, rows, dev):
 
 
 def _cl_tables(ts, key, lay_sv, last, xc, sc, ks, d, dev, layer):
+    flow = key[0]
     """Operand tables of the two weight-gradient GEMMs of one WN layer (the buffers they point at are allocated once per shape,
     so the tables are built once)."""
     t = ts.cl_tables.get(key)
@@ -142,7 +169,8 @@ def _cl_tables(ts, key, lay_sv, last, xc, sc, ks, d, dev, layer):
         return t
     ones = [[ts.ones_plane.data_ptr(), ts.zero_plane.data_ptr(), 0]]
     a1 = ([] if last else _chunk_rows(ts.DX, xc)) + _chunk_rows(ts.DS, xc)            # [d_x ; d_skip]
-    b1 = _chunk_rows(lay_sv["A"], xc) + ([] if ts.bias_cols else ones)                  # [acts | 1] (or the kernel's row sums)
+    acts = _chunk_rows(ts.AF[flow], xc, first=layer * xc) if ts.fold_train else _chunk_rows(lay_sv["A"], xc)
+    b1 = acts + ([] if ts.bias_cols else ones)                                          # [acts | 1] (or the kernel's row sums)
     a2 = _chunk_rows(ts.DP, 2 * xc, first=layer * 2 * xc)                               # d_pre (tanh half, sigmoid half)
     b2 = []
     for tap in range(ks):
@@ -163,8 +191,9 @@ def forward_train(eng, mel, audio):
     L = T // G
     g = eng.geom()
     C, nl, ks = g["C"], g["nl"], g["ks"]
-    eng.pack_weights(dev, force=True)
     ts = _alloc_train(eng, B, L, dev)
+    eng.pack_weights(dev, force=True, res_pair8=ts.fold_train)
+    pair8 = 1 if (ts.fold_train and eng.packed.get("res_pair8")) else 0
     st = _lib.current_stream()
     w = dict(Lp=ts.Lp, Sh=ts.S_planes[0], Sl=ts.S_planes[1])
     eng._upsample(mel, B, L, w)
@@ -189,19 +218,35 @@ def forward_train(eng, mel, audio):
                   _ptr(lay[0]["X"][0]), _ptr(lay[0]["X"][1]), st)
         for i in range(nl):
             ly, sv = fl["layers"][i], lay[i]
-            _lib.call("t2s_wg_in_cond_gate_train", _ptr(ly["A1h"]), _ptr(ly["A1l"]), _ptr(ly["b1"]), _ptr(sv["X"][0]),
-                      _ptr(sv["X"][1]), _ptr(ts.S_planes[0]), _ptr(ts.S_planes[1]), _ptr(sv["A"][0]), _ptr(sv["A"][1]),
-                      None, None, _ptr(sv["G"][0]), _ptr(sv["G"][1]), B, C, g["n_cond"], ks, 2 ** i,
-                      L, ts.Lp, g["halo"], g["Mpad1"], st)
             last = i == nl - 1
+            a_h, a_l = _act_ptrs(ts, k, i, "A")
+            g_h, g_l = _act_ptrs(ts, k, i, "G")
+            if ts.fold_train:
+                _lib.call("t2s_wg_in_cond_gate_fold_train", _ptr(ly["A1h"]), _ptr(ly["A1l"]), _ptr(ly["b1"]), _ptr(sv["X"][0]),
+                          _ptr(sv["X"][1]), _ptr(ts.S_planes[0]), _ptr(ts.S_planes[1]), a_h, a_l, g_h, g_l, ts.act_bchunks,
+                          _ptr(ly["fold_A"]), _ptr(ts.fold_acc), 1 if i == 0 else 0, B, C, g["n_cond"], ks, 2 ** i, L, ts.Lp,
+                          g["halo"], g["Mpad1"], st)
+                if not last:        # the last layer has no residual half; its skip half lives in the fold
+                    nxt = lay[i + 1]["X"]
+                    _lib.call("t2s_wg_res_only_train", _ptr(ly["A2h"]), _ptr(ly["A2l"]), _ptr(ly["b2"]), a_h, a_l, ts.act_bchunks,
+                              _ptr(sv["X"][0]), _ptr(sv["X"][1]), _ptr(nxt[0]), _ptr(nxt[1]), B, C, L, ts.Lp, g["halo"],
+                              ly["Mpad2"], pair8, st)
+                continue
+            _lib.call("t2s_wg_in_cond_gate_train", _ptr(ly["A1h"]), _ptr(ly["A1l"]), _ptr(ly["b1"]), _ptr(sv["X"][0]),
+                      _ptr(sv["X"][1]), _ptr(ts.S_planes[0]), _ptr(ts.S_planes[1]), a_h, a_l,
+                      None, None, g_h, g_l, B, C, g["n_cond"], ks, 2 ** i,
+                      L, ts.Lp, g["halo"], g["Mpad1"], st)
             nxt = None if last else lay[i + 1]["X"]
-            _lib.call("t2s_wg_res_skip_train", _ptr(ly["A2h"]), _ptr(ly["A2l"]), _ptr(ly["b2"]), _ptr(sv["A"][0]),
-                      _ptr(sv["A"][1]), None if last else _ptr(sv["X"][0]), None if last else _ptr(sv["X"][1]),
+            _lib.call("t2s_wg_res_skip_train", _ptr(ly["A2h"]), _ptr(ly["A2l"]), _ptr(ly["b2"]), a_h, a_l,
+                      None if last else _ptr(sv["X"][0]), None if last else _ptr(sv["X"][1]),
                       None if last else _ptr(nxt[0]), None if last else _ptr(nxt[1]), _ptr(ts.skip[k]), B, C,
                       0 if last else C, 1 if i == 0 else 0, L, ts.Lp, g["halo"], ly["Mpad2"], st)
         log_s = torch.empty(B, n_half, L, dtype=torch.float32, device=dev)
         ts.wn_out[k] = torch.empty(B, 2 * n_half, L, dtype=torch.float32, device=dev)
-        eng._end(k, z, log_s, B, L, dict(Lp=ts.Lp), c_off, n_half, reverse=False, wn_out=ts.wn_out[k], skip=ts.skip[k])
+        if ts.fold_train:
+            eng._end(k, z, log_s, B, L, dict(Lp=ts.Lp, fold_acc=ts.fold_acc, wn_out=ts.wn_out[k]), c_off, n_half, reverse=False)
+        else:
+            eng._end(k, z, log_s, B, L, dict(Lp=ts.Lp), c_off, n_half, reverse=False, wn_out=ts.wn_out[k], skip=ts.skip[k])
         log_s_list.append(log_s)
     ts.z_final = z
     ts.mel = _f32c(mel)
@@ -331,8 +376,30 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         w_end = _f32c(wn.end.weight)
         dW_end = bucket.take(*wn.end.weight.shape)
         db_end = bucket.take(nj)
-        _lib.call("t2s_small_wgrad", None, None, _ptr(ts.skip[k]), _ptr(d_out), _ptr(dW_end), None, _ptr(ts.sw_scratch), B, xc, Lp, halo, L, C, nj,
-                  nj, 0, 1, st)
+        if ts.fold_train:
+            # The forward never formed the skip sum (WN.end is folded into the gate GEMM there).  WN.end's weight gradient needs
+            # it once: skip = sum_i (W_skip,i acts_i + b_skip,i) as ONE GEMM over the flow-wide gate-output planes, K = nl * C,
+            # with the skip rows of the nl res_skip weights packed one after the other along K.  On the weight-gradient stream.
+            ev_dout = torch.cuda.Event()
+            ev_dout.record(main_s)
+            side_s.wait_event(ev_dout)
+            for i in range(nl):
+                conv = wn.res_skip_layers[i]
+                v, gg = _vg(conv)
+                v32, g32, b32 = _f32c(v), (None if gg is None else _f32c(gg)), _f32c(conv.bias)
+                keep.extend([v32, g32, b32])
+                r0 = C if i < nl - 1 else 0                      # skip rows: the second half, or all rows of the last layer
+                _lib.call("t2s_pack_conv_weight", _lib.c_vp(v32.data_ptr() + 4 * r0 * C),
+                          None if g32 is None else _lib.c_vp(g32.data_ptr() + 4 * r0), 0, _lib.c_vp(b32.data_ptr() + 4 * r0), C, C, 1,
+                          0, 0, 0, ts.Mskip, i * g["Cpad"], g["Cpad"], _ptr(ts.A_skip[0]), _ptr(ts.A_skip[1]), _ptr(ts.bias_skip),
+                          1 if i else 0, st2)
+            _lib.call("t2s_wg_skip_sum", _ptr(ts.A_skip[0]), _ptr(ts.A_skip[1]), _ptr(ts.bias_skip), _ptr(ts.AF[k][0]),
+                      _ptr(ts.AF[k][1]), nl * xc, ts.act_bchunks, _ptr(ts.skip[k]), B, C, L, Lp, halo, ts.Mskip, st2)
+            _lib.call("t2s_small_wgrad", None, None, _ptr(ts.skip[k]), _ptr(d_out), _ptr(dW_end), None, _ptr(ts.sw_scratch_side), B, xc,
+                      Lp, halo, L, C, nj, nj, 0, 1, st2)
+        else:
+            _lib.call("t2s_small_wgrad", None, None, _ptr(ts.skip[k]), _ptr(d_out), _ptr(dW_end), None, _ptr(ts.sw_scratch), B, xc, Lp,
+                      halo, L, C, nj, nj, 0, 1, st)
         _lib.call("t2s_rows_sum", _ptr(d_out), B, nj, 0, nj, L, _ptr(db_end), st)
         grads[id(wn.end.weight)] = dW_end
         grads[id(wn.end.bias)] = db_end
@@ -358,10 +425,11 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             # this layer's slice of the flow-wide d_pre planes (bytes from the start of each plane)
             dp_off = 2 * i * 2 * xc * Lp * 32
             dp_h, dp_l = _lib.c_vp(ts.DP[0].data_ptr() + dp_off), _lib.c_vp(ts.DP[1].data_ptr() + dp_off)
+            a_h, a_l = _act_ptrs(ts, k, i, "A")
+            g_h, g_l = _act_ptrs(ts, k, i, "G")
             _lib.call("t2s_wg_bwd_gate_dgrad", _ptr(ts.A_rsT[0]), _ptr(ts.A_rsT[1]), _ptr(zb),
                       None if last else _ptr(ts.DX[0]), None if last else _ptr(ts.DX[1]), _ptr(ts.DS[0]), _ptr(ts.DS[1]),
-                      _ptr(sv["A"][0]), _ptr(sv["A"][1]), _ptr(sv["G"][0]), _ptr(sv["G"][1]), dp_h, dp_l, ts.dp_chunks,
-                      B, C, L, Lp, halo, ts.Mc, st)
+                      a_h, a_l, g_h, g_l, ts.act_bchunks, dp_h, dp_l, ts.dp_chunks, B, C, L, Lp, halo, ts.Mc, st)
             ev_dp = torch.cuda.Event()
             ev_dp.record(main_s)
             # 2. dW_rs = [dx ; dS] . acts^T  (+ bias column)                                                 [side]
@@ -382,7 +450,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                           _ptr(ts.TM_drs[1]), Mrs, 0 if last else C, st2)
                 ev_tdrs = torch.cuda.Event()        # DX / DS have been read: the chain may update DX in place
                 ev_tdrs.record(side_s)
-                _lib.call("t2s_plane_transpose", _ptr(sv["A"][0]), _ptr(sv["A"][1]), B, xc, xc, Lp, 0, _ptr(ts.TM_act[0]),
+                _lib.call("t2s_plane_transpose", a_h, a_l, B, ts.act_bchunks or xc, xc, Lp, 0, _ptr(ts.TM_act[0]),
                           _ptr(ts.TM_act[1]), ts.N1pad, 0, st2)
                 _lib.call("t2s_wgrad_gemm_flat", _ptr(ts.TM_drs[0]), _ptr(ts.TM_drs[1]), _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]),
                           _ptr(zb), _ptr(ts.P1), B, rows2, ts.N1, Mrs, ts.N1pad, nt, ts.k0, ts.k1, ts.ks1, st2)

@@ -41,12 +41,14 @@ def waveglow_flow_sizes(cfg):
     return out
 
 
-def waveglow_state(cfg=WAVEGLOW_DEFAULT, seed=1234, end_seed=7, end_std=0.02):
+def waveglow_state(cfg=WAVEGLOW_DEFAULT, seed=1234, end_seed=7, end_std=0.02, wn_gain=1.0):
     """Deterministic WaveGlow ``state_dict`` with weight-norm (g, v) pairs.
 
     ``WN.end`` is zero-initialised in the reference (glow.py:128-130), which
     makes every coupling an identity; it is overwritten with N(0, end_std^2)
     from its own stream so the whole WN stack is exercised.
+    ``end_std`` / ``wn_gain`` (a factor on every weight-norm gain of the in / cond / res_skip layers) make the stress weights
+    of the parity tests: 0.03 / 1.25 gives max |log_s| 3-4 instead of 1.3 (tools/numerics_study.py, profiles/r03_numerics.md).
     """
     gen = torch.Generator().manual_seed(seed)
     gen_end = torch.Generator().manual_seed(end_seed)
@@ -67,12 +69,12 @@ def waveglow_state(cfg=WAVEGLOW_DEFAULT, seed=1234, end_seed=7, end_std=0.02):
 
     for k, (n_rem, n_half) in enumerate(waveglow_flow_sizes(cfg)):
         for i in range(nl):
-            wn_pair(f"WN.{k}.in_layers.{i}", 2 * C, C, ks)
+            wn_pair(f"WN.{k}.in_layers.{i}", 2 * C, C, ks, gain=wn_gain)
         for i in range(nl):
             rs = 2 * C if i < nl - 1 else C
-            wn_pair(f"WN.{k}.res_skip_layers.{i}", rs, C, 1, gain=0.5)
+            wn_pair(f"WN.{k}.res_skip_layers.{i}", rs, C, 1, gain=0.5 * wn_gain)
         for i in range(nl):
-            wn_pair(f"WN.{k}.cond_layers.{i}", 2 * C, n_cond, 1)
+            wn_pair(f"WN.{k}.cond_layers.{i}", 2 * C, n_cond, 1, gain=wn_gain)
         wn_pair(f"WN.{k}.start", C, n_half, 1)
         sd[f"WN.{k}.end.weight"] = _randn(gen_end, 2 * n_half, C, 1, std=end_std)
         sd[f"WN.{k}.end.bias"] = _randn(gen_end, 2 * n_half, std=end_std)

@@ -79,3 +79,22 @@ for k, v in sorted(ops.items(), key=lambda kv: -kv[1])[:60]:
     print(v, k)
     tot += v
 print("aten ops listed:", tot)
+# device-side view of the same step (roctracer): every kernel / copy that is not one of the library's own, with its launching op
+try:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof2:
+        step()
+        torch.cuda.synchronize()
+    dev = {}
+    for e in prof2.events():
+        if str(e.device_type).endswith("CUDA") or str(e.device_type).endswith("PrivateUse1"):
+            nm = e.name
+            if "t2s" in nm or "_kernel" in nm and "at::" not in nm and "rocclr" not in nm:
+                continue
+            parent = e.cpu_parent.name if getattr(e, "cpu_parent", None) is not None else "?"
+            dev[(nm[:70], parent[:40])] = dev.get((nm[:70], parent[:40]), 0) + 1
+    print("device-side events that are not library kernels:")
+    for k, v in sorted(dev.items(), key=lambda kv: -kv[1])[:30]:
+        print(v, k)
+    print(prof2.key_averages().table(sort_by="self_cuda_time_total", row_limit=25, max_name_column_width=60)[:9000])
+except Exception as ex:      # noqa: BLE001
+    print("device-side profile unavailable:", ex)
