@@ -422,6 +422,8 @@ def main():
             "roofline": roof,
             "achieved_TFLOPs_whole_step": total_samples * WG_FWD_FLOP_PER_SAMPLE * (3.0 if args.mode == "train" else 1.0) / dt / 1e12,
         }
+        if args.mode == "train" and eng.grad_sync is not None:       # per-bucket all-reduce timing of the last step (rank 0's view)
+            out["collective"] = eng.grad_sync.stats()
     # ---- data-parallel WaveGlow train step (BASELINE configs[3]) next to the forward figure, every rank takes part ----
     train_block, train_key = None, None
     if args.mode == "forward" and not args.no_train:
@@ -439,6 +441,13 @@ def main():
         try:
             tstep = make_train_step()
             k_tr, w_tr = 6, 2
+            single_ms = None
+            if world > 1 and eng.grad_sync is not None:
+                # the same step WITHOUT the gradient exchange, in this process on this GPU: DP step time minus this is the
+                # communication the backward could not hide (timing only: the ranks' weights drift apart for these steps)
+                gs_keep, eng.grad_sync = eng.grad_sync, None
+                single_ms = max_over_ranks(run_steps(tstep, 3, 2, dist, True)) / 3 * 1e3
+                eng.grad_sync = gs_keep
             dtt = max_over_ranks(run_steps(tstep, k_tr, w_tr, dist, True))
             n_samp = world * args.batch * args.segment
             flop = 3.0 * args.batch * args.segment * WG_FWD_FLOP_PER_SAMPLE          # train step ~ 3 x forward
@@ -452,7 +461,17 @@ def main():
                            "dp%d: 13 flat gradient buckets all-reduced (RCCL AVG) from inside the backward" % world}
             gs = eng.grad_sync
             if gs is not None:
-                train_block["allreduce_bytes_per_step"] = gs.bytes // max(1, gs.n_buckets) * 13
+                torch.cuda.synchronize()
+                st_ = gs.stats()
+                train_block["allreduce_bytes_per_step"] = sum(b["bytes"] for b in st_["buckets"])
+                train_block["collective"] = {"backend": st_["backend"], "ranks_in_group": st_["world"],
+                                             "buckets_last_step": st_["buckets"],
+                                             "note": "per bucket: bytes, ms from 'last gradient of the bucket written' to 'all-reduce "
+                                                     "complete' (events on the communication stream), ms since the previous bucket "
+                                                     "completed; buckets ship in backward order: flows 11 .. 0, then the upsampler"}
+                if single_ms is not None:
+                    train_block["single_gpu_ms_per_step_same_process"] = single_ms
+                    train_block["exposed_comm_ms_per_step"] = dtt / k_tr * 1e3 - single_ms
         except Exception as e:      # noqa: BLE001  (the headline line must still be printed)
             train_block = {"error": "%s: %s" % (type(e).__name__, e)}
         guard.cancel()

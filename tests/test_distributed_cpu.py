@@ -72,6 +72,9 @@ def _worker(rank, world, port, out):
         assert not gs.pending
         for k, (a, b) in enumerate(views):
             assert torch.allclose(a, torch.full_like(a, k + 0.5)) and torch.allclose(b, torch.full_like(b, 5.0))
+        # the diagnostics bench.py reports for an N > 1 run (per-bucket bytes; timing needs device events, absent on the host)
+        st = gs.stats()
+        assert st["world"] == world and st["backend"] == "gloo" and [b["bytes"] for b in st["buckets"]] == [4 * (64 * (k + 1) + 8) for k in range(5)]
         out.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         out.put((rank, repr(e)))

@@ -243,6 +243,35 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
         }
     }
 
+    // GATE_BWD on 128-row tiles (K = 32 steps, a 43 us loop): its epilogue reads the layer's saved gate output and sigmoid - 4 planes,
+    // 66 MB per launch - and writes 66 MB of d_pre: half of the kernel's time was that read-then-write burst after the loop.  As
+    // for RESSKIP above, the reads are requested HERE and ride out their latency under the K loop (128 VGPRs; -DT2S_NO_PREG: off).
+#ifdef T2S_NO_PREG
+    constexpr bool PREG = false;
+#else
+    constexpr bool PREG = EPI == EPI_GATE_BWD && MT == 128;
+#endif
+    u16x4 pg_th[PREG ? MW : 1][PREG ? NWT : 1], pg_tl[PREG ? MW : 1][PREG ? NWT : 1];
+    u16x4 pg_gh[PREG ? MW : 1][PREG ? NWT : 1], pg_gl[PREG ? MW : 1][PREG ? NWT : 1];
+    if constexpr (PREG) {
+        const int tcol_p = lane & 15, rq_p = (lane >> 4) * 4;
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+            const int ch = mt * MT + wr * (MT / 2) + m * 16 + rq_p;
+            const int chc = ch < a.C ? ch : 0;                        // rows past C read a valid row; the result is never stored
+            const size_t tgb = (((size_t)b * a.tc + (chc >> 5)) * a.Lp + a.halo) * 32 + (chc & 31);
+#pragma unroll
+            for (int n = 0; n < NWT; ++n) {
+                const int t = t0 + wc * (NWT * 16) + n * 16 + tcol_p;
+                const size_t o = tgb + (size_t)(t < a.L ? t : 0) * 32;
+                pg_th[m][n] = *(const u16x4*)(a.T_hi + o);
+                pg_tl[m][n] = *(const u16x4*)(a.T_lo + o);
+                pg_gh[m][n] = *(const u16x4*)(a.G_hi + o);
+                pg_gl[m][n] = *(const u16x4*)(a.G_lo + o);
+            }
+        }
+    }
+
   if constexpr (EF) {
     const int nk = nk_split;
     const char *nbh = nullptr, *nbl = nullptr;
@@ -678,10 +707,15 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
             for (int n = 0; n < NWT; ++n) {
                 const int t = t0 + wc * (NWT * 16) + n * 16 + tcol;
                 if (t >= a.L) continue;
-                const u16x4 th = *(const u16x4*)(a.T_hi + tgb + (size_t)t * 32);
-                const u16x4 tl = *(const u16x4*)(a.T_lo + tgb + (size_t)t * 32);
-                const u16x4 gh = *(const u16x4*)(a.G_hi + tgb + (size_t)t * 32);
-                const u16x4 gl = *(const u16x4*)(a.G_lo + tgb + (size_t)t * 32);
+                u16x4 th, tl, gh, gl;
+                if constexpr (PREG) {
+                    th = pg_th[m][n]; tl = pg_tl[m][n]; gh = pg_gh[m][n]; gl = pg_gl[m][n];
+                } else {
+                    th = *(const u16x4*)(a.T_hi + tgb + (size_t)t * 32);
+                    tl = *(const u16x4*)(a.T_lo + tgb + (size_t)t * 32);
+                    gh = *(const u16x4*)(a.G_hi + tgb + (size_t)t * 32);
+                    gl = *(const u16x4*)(a.G_lo + tgb + (size_t)t * 32);
+                }
                 u16x4 h1, l1, h2, l2;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {

@@ -94,7 +94,12 @@ __device__ unsigned long long t2s_pp_stamps[1024 * 8];
 // ph_FT batch entries x ph_FT mel frames of ONE phase phi = t mod ph_P of the hop (plane rows t = ph_P * f + phi, 2 KB apart);
 // the conditioning operand is the mel-window planes S[b][sc][ph_Fp][32] (row = frame) against the phase's composed weights
 // A2[phi][sc][Mpad][32].  Everything else - tile, schedule, epilogue arithmetic - is the kernel above.
-template <int ABL, bool PH>
+// EPI: EPI_GATE (the WaveGlow gate, above), or - round 3, for the training backward - EPI_RESSKIP in its accumulate form
+// (every row a residual row: O (+)= acc, t2s_conv_accumulate: the data gradient of in_layers / cond_layers) and EPI_GATE_BWD
+// (t2s_wg_bwd_gate_dgrad).  Those GEMMs have M = C = 512, two 256-row tiles: alone they fill half the chip, but the backward
+// runs them next to the weight-gradient stream, and what counts there is the time a CU spends per unit of work - 2.1 us per
+// 256 x 256 x 32 step on this schedule against 2 x 1.33 us on the lockstep 128-row tiles.
+template <int ABL, bool PH, int EPI = EPI_GATE>
 __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -420,6 +425,7 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
         }
         cok[n] = cb[n] < a.B && ct[n] < a.L;
     }
+  if constexpr (EPI == EPI_GATE) {
     // Everything the epilogue reads from memory is requested here in one batch (the fragment registers are free now): the 16
     // bias vectors, the folded-WN.end weights and - for layers after the first - the running fold sums this wave adds to.  One
     // memory round trip instead of a dependent one in front of each (pair, half) block and a read-modify-write at the very end.
@@ -543,6 +549,111 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
             }
         }
     }
+  } else if constexpr (EPI == EPI_RESSKIP) {
+    // O (+)= acc (+ bias): rows = output channels in identity order, a lane holds channels prow .. prow+3 of one time step.
+    // The old values of two m-tiles (8 pieces of 8 bytes per plane) are requested together before any of them is consumed.
+#pragma unroll
+    for (int m0 = 0; m0 < 8; m0 += 2) {
+        u16x4 oh[2][4], ol[2][4];
+        f32x4 bv[2];
+        size_t ob[2];
+        bool rok[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int m = m0 + mi;
+            const int prow = mt * 256 + (m >> 2) * 128 + wr * 64 + (m & 3) * 16 + rq;
+            rok[mi] = prow < a.n_res;
+            const int ch = rok[mi] ? prow : 0;
+            bv[mi] = *(const f32x4*)(a.bias + ch);
+            ob[mi] = ((size_t)(ch >> 5) * a.Lp + a.halo) * 32 + (ch & 31);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                oh[mi][n] = (u16x4){0, 0, 0, 0};
+                ol[mi][n] = (u16x4){0, 0, 0, 0};
+                if (rok[mi] && cok[n] && !a.res_init) {
+                    const size_t o = ob[mi] + ((size_t)cb[n] * a.oc * a.Lp + (size_t)ct[n]) * 32;
+                    oh[mi][n] = *(const u16x4*)((a.R_hi ? a.R_hi : a.O_hi) + o);
+                    ol[mi][n] = *(const u16x4*)((a.R_lo ? a.R_lo : a.O_lo) + o);
+                }
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            if (!rok[mi]) continue;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (!cok[n]) continue;
+                u16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    u16 h, l;
+                    split_bf16(join_bf16(oh[mi][n][e], ol[mi][n][e]) + (acc[m0 + mi][n][e] + bv[mi][e]), h, l);
+                    hi[e] = h;
+                    lo[e] = l;
+                }
+                const size_t o = ob[mi] + ((size_t)cb[n] * a.oc * a.Lp + (size_t)ct[n]) * 32;
+                pp_store8(a.O_hi + o, hi);
+                pp_store8(a.O_lo + o, lo);
+            }
+        }
+    }
+  } else {
+    // EPI_GATE_BWD (csrc/conv_gemm.hip has the derivation): acc = d_acts[c][t]; with the saved a = tanh * sigmoid and g = sigmoid,
+    // t = a / g:  d_pre[c] = d_acts g (1 - t^2),  d_pre[C + c] = d_acts a (1 - g).  T_hi / T_lo hold a, G_hi / G_lo hold g (tc =
+    // their batch stride in chunks), O planes take 2C channels (oc = their batch stride).
+#pragma unroll
+    for (int m0 = 0; m0 < 8; m0 += 2) {
+        u16x4 th[2][4], tl[2][4], gh[2][4], gl[2][4];
+        bool rok[2];
+        int chs[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int m = m0 + mi;
+            const int ch = mt * 256 + (m >> 2) * 128 + wr * 64 + (m & 3) * 16 + rq;
+            rok[mi] = ch < a.C;
+            chs[mi] = rok[mi] ? ch : 0;
+            const size_t tgb = ((size_t)(chs[mi] >> 5) * a.Lp + a.halo) * 32 + (chs[mi] & 31);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const size_t o = tgb + ((size_t)(cok[n] ? cb[n] : 0) * a.tc * a.Lp + (size_t)(cok[n] ? ct[n] : 0)) * 32;
+                th[mi][n] = *(const u16x4*)(a.T_hi + o);
+                tl[mi][n] = *(const u16x4*)(a.T_lo + o);
+                gh[mi][n] = *(const u16x4*)(a.G_hi + o);
+                gl[mi][n] = *(const u16x4*)(a.G_lo + o);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            if (!rok[mi]) continue;
+            const int ch = chs[mi], ch2 = ch + a.C;
+            const size_t o1b = ((size_t)(ch >> 5) * a.Lp + a.halo) * 32 + (ch & 31);
+            const size_t o2b = ((size_t)(ch2 >> 5) * a.Lp + a.halo) * 32 + (ch2 & 31);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (!cok[n]) continue;
+                u16x4 h1, l1, h2, l2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float av = join_bf16(th[mi][n][e], tl[mi][n][e]), gv = join_bf16(gh[mi][n][e], gl[mi][n][e]);
+                    const float tv = gv != 0.0f ? av / gv : 0.0f;
+                    const float da = acc[m0 + mi][n][e];
+                    u16 h, l;
+                    split_bf16(da * gv * (1.0f - tv * tv), h, l);
+                    h1[e] = h;
+                    l1[e] = l;
+                    split_bf16(da * av * (1.0f - gv), h, l);
+                    h2[e] = h;
+                    l2[e] = l;
+                }
+                const size_t bo = ((size_t)cb[n] * a.oc * a.Lp + (size_t)ct[n]) * 32;
+                pp_store8(a.O_hi + o1b + bo, h1);
+                pp_store8(a.O_lo + o1b + bo, l1);
+                pp_store8(a.O_hi + o2b + bo, h2);
+                pp_store8(a.O_lo + o2b + bo, l2);
+            }
+        }
+    }
+  }
 #ifdef T2S_GEMM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -550,15 +661,27 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
     PP_RSTAMP(5)
 }
 
-template <int ABL, bool PH = false>
+template <int ABL, bool PH = false, int EPI = EPI_GATE>
 static hipError_t launch_pp(const ConvGemmArgs& a, hipStream_t stream) {
     const int nwg = PH ? a.n_mtiles * a.ph_P * a.ph_nft * ((a.B + a.ph_bper - 1) / a.ph_bper) : a.n_mtiles * a.n_ttiles * a.B;
     constexpr int lds = 2 * PP_BUF;
     static std::atomic<unsigned long long> attr_mask{0};
-    const hipError_t e = t2s_raise_lds_limit((const void*)gate_gemm_pp_kernel<ABL, PH>, lds, attr_mask);
+    const hipError_t e = t2s_raise_lds_limit((const void*)gate_gemm_pp_kernel<ABL, PH, EPI>, lds, attr_mask);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((gate_gemm_pp_kernel<ABL, PH>), dim3(nwg), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL((gate_gemm_pp_kernel<ABL, PH, EPI>), dim3(nwg), dim3(512), lds, stream, a);
     return hipGetLastError();
+}
+
+// the accumulate / gate-backward GEMMs of the training backward on the ping-pong schedule (256-row tiles); the caller has checked
+// t2s_pp_shape_ok(a)
+hipError_t t2s_launch_bwd_gemm_pp(const ConvGemmArgs& a, int epi, hipStream_t stream) {
+    if (epi == EPI_RESSKIP) return launch_pp<0, false, EPI_RESSKIP>(a, stream);
+    if (epi == EPI_GATE_BWD) return launch_pp<0, false, EPI_GATE_BWD>(a, stream);
+    return hipErrorInvalidValue;
+}
+bool t2s_pp_shape_ok(const ConvGemmArgs& a) {
+    return a.ksplit <= 1 && a.k0 == 0 && a.kflat == 0 && a.nk == a.nk_x + a.sc && a.nk_x == a.taps * a.xc && a.a_bstride == 0 &&
+           (a.taps >> 1) * a.dil <= a.halo && a.ph_P == 0 && a.nk >= 2;
 }
 
 #ifdef T2S_GEMM_STAMPS

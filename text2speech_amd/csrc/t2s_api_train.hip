@@ -7,6 +7,7 @@
 #include <string.h>
 
 extern "C" int t2s_internal_fail_hip(int e);
+
 #define T2S_CHECK_HIP(expr)                                          \
     do {                                                             \
         hipError_t _e = (expr);                                      \
@@ -15,6 +16,16 @@ extern "C" int t2s_internal_fail_hip(int e);
 
 static inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+#include <stdlib.h>
+// The accumulate / gate-backward GEMMs of the training backward: 256-row tiles on the ping-pong schedule (csrc/gate_gemm_pp.hip)
+// once they give at least ~100 workgroups - M = 512 at 8 x 16000 is 128, half the chip, and the rest is taken by the
+// weight-gradient stream that runs beside them - else the lockstep kernels on 128-row tiles (twice the workgroups).
+// T2S_BWD_PP256=0 restores the round-2 choice for A/B runs.
+static bool bwd_pp256(const ConvGemmArgs& a, int rows) {
+    static const int on = getenv("T2S_BWD_PP256") ? atoi(getenv("T2S_BWD_PP256")) : 1;
+    return on && t2s_pp_shape_ok(a) && (long)cdiv(rows, 256) * a.n_ttiles * a.B >= 100;
+}
+
 static int planes_ok(const void* a, const void* b) { return a && b && al16(a) && al16(b); }
 
 // rows [row0, row0+1) scale kernel lives in waveglow_ops.hip's weightnorm_small (scale-only form below)
@@ -185,6 +196,11 @@ int t2s_wg_bwd_gate_dgrad(const void* A_hi, const void* A_lo, const float* zero_
     a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
     a.n_ttiles = cdiv(L, 256);
     a.C = C;
+    if (bwd_pp256(a, C)) {
+        a.n_mtiles = cdiv(C, 256);
+        T2S_CHECK_HIP(t2s_launch_bwd_gemm_pp(a, EPI_GATE_BWD, (hipStream_t)stream));
+        return T2S_OK;
+    }
     // 128-row tiles when 256-row tiles would leave half the CUs without a workgroup (C = 512: 2 x 64 tiles)
     const int mt_rows = cdiv(C, 256) * a.n_ttiles * B < 200 ? 128 : 256;
     a.n_mtiles = cdiv(C, mt_rows);
@@ -209,6 +225,11 @@ int t2s_conv_accumulate(const void* A_hi, const void* A_lo, const float* zero_bi
     a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
     a.n_ttiles = cdiv(L, 256);
     a.C = 0; a.n_res = Cout; a.res_init = init;      // every row takes the residual branch
+    if (bwd_pp256(a, Cout)) {
+        a.n_mtiles = cdiv(Cout, 256);
+        T2S_CHECK_HIP(t2s_launch_bwd_gemm_pp(a, EPI_RESSKIP, (hipStream_t)stream));
+        return T2S_OK;
+    }
     // 128-row tiles when 256-row tiles would leave most CUs without a workgroup
     const int mt_rows = (cdiv(Cout, 256) * a.n_ttiles * B <= 128 || Cout % 256 == 0) && cdiv(Cout, 256) * a.n_ttiles * B < 200 ? 128 : 256;
     a.n_mtiles = cdiv(Cout, mt_rows);

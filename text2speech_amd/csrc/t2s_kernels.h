@@ -66,6 +66,9 @@ struct ConvGemmArgs {
 hipError_t t2s_launch_conv_gemm(const ConvGemmArgs& a, int epi, hipStream_t stream, int mt_rows = 256);
 // EPI_GATE, 256 x 256 tile, plain K order (nk = taps * xc + sc): the ping-pong schedule of csrc/gate_gemm_pp.hip
 hipError_t t2s_launch_gate_gemm_pp(const ConvGemmArgs& a, hipStream_t stream);
+// EPI_RESSKIP (accumulate form: n_res = every row, C = 0) / EPI_GATE_BWD on the same schedule; a.n_mtiles counts 256-row tiles
+hipError_t t2s_launch_bwd_gemm_pp(const ConvGemmArgs& a, int epi, hipStream_t stream);
+bool t2s_pp_shape_ok(const ConvGemmArgs& a);
 
 // csrc/wgrad_cl.hip: weight-gradient GEMM straight from channel-last planes (transposed LDS reads)
 struct WgradChunk {            // one 32-channel chunk of an operand; mirrors t2s_wgrad_chunk in include/t2s_hip.h

@@ -42,29 +42,87 @@ def _avg_op():
 
 
 class GradSync:
-    """Bucketed, overlapped gradient averaging used from inside the hand-written backward."""
+    """Bucketed, overlapped gradient averaging used from inside the hand-written backward.
 
-    def __init__(self, group=None):
+    Each bucket is shipped from a dedicated communication stream: that stream waits for the event that marks the bucket
+    complete (recorded by the caller on whichever stream wrote the last gradient), hands the flat buffer to the collective and
+    records an event behind it, so the compute streams are never blocked by a collective until ``finish()``, and every bucket has
+    a (ready, done) event pair of its own - the per-bucket timing an 8-GPU run needs to be diagnosable:
+    ``stats()`` returns, per bucket of the last step, bytes, ready -> complete ms and the gap to the previous completion.
+    """
+
+    def __init__(self, group=None, timing=True):
         self.group = group
         self.world = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
         self.pending = []
         self.n_buckets = 0
         self.bytes = 0
+        self.timing = timing
+        self.comm_stream = None
+        self._last = []            # (bytes, ev_ready, ev_done) of the step that finished last
 
-    def reduce_async(self, flat):
-        """Start averaging one flat gradient bucket; returns immediately."""
+    def reduce_async(self, flat, ready_events=()):
+        """Start averaging one flat gradient bucket; returns immediately.  ``ready_events``: events recorded by the caller, one
+        per stream that wrote gradients into the bucket, each after its last write (default: now, on the current stream)."""
         op = _avg_op()
-        h = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
-        self.pending.append((h, flat, op))
+        cuda = flat.is_cuda
+        if cuda and self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(device=flat.device)
+        ev_ready = ev_done = None
+        if cuda:
+            if not ready_events:
+                e = torch.cuda.Event()
+                e.record()
+                ready_events = (e,)
+            for e in ready_events:
+                self.comm_stream.wait_event(e)
+            with torch.cuda.stream(self.comm_stream):
+                ev_ready = torch.cuda.Event(enable_timing=self.timing)      # fires when the last of the bucket's writers is done
+                ev_ready.record()
+                h = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
+                h.wait()                                    # stream-level for RCCL: the comm stream now trails the collective
+                if op == dist.ReduceOp.SUM:
+                    flat.mul_(1.0 / self.world)
+                ev_done = torch.cuda.Event(enable_timing=self.timing)
+                ev_done.record()
+            flat.record_stream(self.comm_stream)
+        else:
+            h = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
+        self.pending.append((h, flat, op, ev_ready, ev_done))
         self.n_buckets += 1
         self.bytes += flat.numel() * flat.element_size()
 
     def finish(self):
-        for h, flat, op in self.pending:
-            h.wait()
-            if op == dist.ReduceOp.SUM:
-                flat.mul_(1.0 / self.world)
+        """Every shipped bucket has been averaged before the caller's stream goes on (and before ``optimizer.step()``)."""
+        last = []
+        for h, flat, op, ev_ready, ev_done in self.pending:
+            if ev_done is not None:
+                torch.cuda.current_stream(flat.device).wait_event(ev_done)
+            else:
+                h.wait()
+                if op == dist.ReduceOp.SUM:
+                    flat.mul_(1.0 / self.world)
+            last.append((flat.numel() * flat.element_size(), ev_ready, ev_done))
+        self._last = last
         self.pending = []
+
+    def stats(self):
+        """Per-bucket figures of the last finished step (call after a device synchronize): bytes, ms from 'bucket ready' to
+        'all-reduce complete', ms between consecutive completions (back-to-back buckets: bytes / that = the achieved bus rate)."""
+        out, prev_done = [], None
+        for nbytes, ev_ready, ev_done in self._last:
+            row = {"bytes": nbytes}
+            if ev_ready is not None and ev_done is not None and self.timing:
+                try:
+                    row["ready_to_complete_ms"] = ev_ready.elapsed_time(ev_done)
+                    if prev_done is not None:
+                        row["since_previous_complete_ms"] = prev_done.elapsed_time(ev_done)
+                except RuntimeError:            # an event that was never recorded / not yet complete
+                    pass
+            prev_done = ev_done
+            out.append(row)
+        return {"world": self.world, "backend": self.backend, "buckets": out}
 
 
 def _broadcast_flat(tensors, src=0, bucket_elems=32 * 1024 * 1024):

@@ -73,12 +73,15 @@ def _alloc_train(eng, B, L, dev):
     # backward scratch
     nt = Lp // 32
     st.nt = nt
-    st.DX, st.DS = pl(xc), pl(xc)
+    # DS (d_skip of a flow) and the flow-wide d_pre planes exist twice: flow k works in parity k & 1, so the data-gradient chain
+    # of the next flow never waits for the weight-gradient stream to finish reading this flow's (it may lag by one flow)
+    st.DX = pl(xc)
+    st.DS2 = [pl(xc), pl(xc)]
     # d_pre of ALL layers of a flow side by side (layer i = chunks [2 xc i, 2 xc (i + 1)) of every batch entry; 0.6 GB at
     # 8 x 16000): the conditioning gradient d_spect += sum_i W_cond,i^T d_pre_i is then ONE GEMM per flow with K = n_layers * 2C
     # instead of one 192-workgroup GEMM and one read-modify-write of d_spect per layer, and a layer's d_pre stays valid until the
     # flow ends (the weight-gradient stream may lag behind the data-gradient chain)
-    st.DP = pl(nl * 2 * xc)
+    st.DP2 = [pl(nl * 2 * xc), pl(nl * 2 * xc)]
     st.dp_chunks = nl * 2 * xc
     st.DSp = pl(sc)
     st.N2 = 3 * C + g["n_cond"] + 1
@@ -168,10 +171,11 @@ def _cl_tables(ts, key, lay_sv, last, xc, sc, ks, d, dev, layer):
     if t is not None:
         return t
     ones = [[ts.ones_plane.data_ptr(), ts.zero_plane.data_ptr(), 0]]
-    a1 = ([] if last else _chunk_rows(ts.DX, xc)) + _chunk_rows(ts.DS, xc)            # [d_x ; d_skip]
+    DS, DP = ts.DS2[flow & 1], ts.DP2[flow & 1]
+    a1 = ([] if last else _chunk_rows(ts.DX, xc)) + _chunk_rows(DS, xc)               # [d_x ; d_skip]
     acts = _chunk_rows(ts.AF[flow], xc, first=layer * xc) if ts.fold_train else _chunk_rows(lay_sv["A"], xc)
     b1 = acts + ([] if ts.bias_cols else ones)                                          # [acts | 1] (or the kernel's row sums)
-    a2 = _chunk_rows(ts.DP, 2 * xc, first=layer * 2 * xc)                               # d_pre (tanh half, sigmoid half)
+    a2 = _chunk_rows(DP, 2 * xc, first=layer * 2 * xc)                                  # d_pre (tanh half, sigmoid half)
     b2 = []
     for tap in range(ks):
         b2 += _chunk_rows(lay_sv["X"], xc, (tap - ks // 2) * d)                         # x shifted by the dilated tap
@@ -300,6 +304,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         _lib.call("t2s_tm_ones_row", _ptr(ts.TM_x[0]), _ptr(ts.TM_x[1]), B, Lp, halo, L, ts.N2pad, ts.N2 - 1, st2)
         _lib.call("t2s_tm_ones_row", _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]), B, Lp, halo, L, ts.N1pad, C, st2)
     dsp_init = 1
+    side_done = {}                          # flow -> event: the weight-gradient stream has finished that flow
     per_layer_cond = bool(os.environ.get("T2S_WCOND_PER_LAYER"))
     keep = []
 
@@ -324,9 +329,10 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             self.off += -(-n // 4) * 4
             return v
 
-        def ship(self):
+        def ship(self, events=()):
+            """events: what must have completed before the bucket is whole (one per stream that wrote gradients into it)."""
             if sync is not None:
-                sync.reduce_async(self.flat[:self.off])
+                sync.reduce_async(self.flat[:self.off], ready_events=events)
 
     bucket = None
 
@@ -361,6 +367,9 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         lay = ts.layers[k]
         nj = 2 * n_half
         bucket = _Bucket(list(wn.parameters()) + list(m.convinv[k].parameters()))
+        DS, DP = ts.DS2[k & 1], ts.DP2[k & 1]
+        if side_done.get(k + 2) is not None:
+            main_s.wait_event(side_done[k + 2])     # the weight-gradient stream has finished with this parity's DS / d_pre planes
         # ---- affine coupling backward, un-apply (a1 restored in zw) ----
         d_out = new(B, nj, L)
         gls, gls_scalar = g_log_s[k], 0
@@ -406,8 +415,8 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         w_endT = new(C, nj)
         _lib.call("t2s_transpose", _ptr(w_end), _ptr(w_endT), nj, C, st)
         keep.extend([w_end, w_endT])
-        _lib.call("t2s_wg_start", _ptr(d_out), _ptr(w_endT), _ptr(zb), B, nj, 0, nj, C, L, Lp, halo, _ptr(ts.DS[0]),
-                  _ptr(ts.DS[1]), st)
+        _lib.call("t2s_wg_start", _ptr(d_out), _ptr(w_endT), _ptr(zb), B, nj, 0, nj, C, L, Lp, halo, _ptr(DS[0]),
+                  _ptr(DS[1]), st)
         # d_skip rows of every layer's d_rs are the same: transpose once per flow
         for i in reversed(range(nl)):
             last = i == nl - 1
@@ -424,11 +433,11 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             ev_in.record(main_s)
             # this layer's slice of the flow-wide d_pre planes (bytes from the start of each plane)
             dp_off = 2 * i * 2 * xc * Lp * 32
-            dp_h, dp_l = _lib.c_vp(ts.DP[0].data_ptr() + dp_off), _lib.c_vp(ts.DP[1].data_ptr() + dp_off)
+            dp_h, dp_l = _lib.c_vp(DP[0].data_ptr() + dp_off), _lib.c_vp(DP[1].data_ptr() + dp_off)
             a_h, a_l = _act_ptrs(ts, k, i, "A")
             g_h, g_l = _act_ptrs(ts, k, i, "G")
             _lib.call("t2s_wg_bwd_gate_dgrad", _ptr(ts.A_rsT[0]), _ptr(ts.A_rsT[1]), _ptr(zb),
-                      None if last else _ptr(ts.DX[0]), None if last else _ptr(ts.DX[1]), _ptr(ts.DS[0]), _ptr(ts.DS[1]),
+                      None if last else _ptr(ts.DX[0]), None if last else _ptr(ts.DX[1]), _ptr(DS[0]), _ptr(DS[1]),
                       a_h, a_l, g_h, g_l, ts.act_bchunks, dp_h, dp_l, ts.dp_chunks, B, C, L, Lp, halo, ts.Mc, st)
             ev_dp = torch.cuda.Event()
             ev_dp.record(main_s)
@@ -446,7 +455,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                 if not last:
                     _lib.call("t2s_plane_transpose", _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, xc, xc, Lp, 0, _ptr(ts.TM_drs[0]),
                               _ptr(ts.TM_drs[1]), Mrs, 0, st2)
-                _lib.call("t2s_plane_transpose", _ptr(ts.DS[0]), _ptr(ts.DS[1]), B, xc, xc, Lp, 0, _ptr(ts.TM_drs[0]),
+                _lib.call("t2s_plane_transpose", _ptr(DS[0]), _ptr(DS[1]), B, xc, xc, Lp, 0, _ptr(ts.TM_drs[0]),
                           _ptr(ts.TM_drs[1]), Mrs, 0 if last else C, st2)
                 ev_tdrs = torch.cuda.Event()        # DX / DS have been read: the chain may update DX in place
                 ev_tdrs.record(side_s)
@@ -475,7 +484,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             v_in, s_in = scale_of(conv_in, pk["s_in"])
             _lib.call("t2s_pack_transposed", _ptr(v_in), _ptr(s_in), 2 * C, C, ks, 1, 2 * C, ts.Mc, 0, _ptr(ts.A_inT[0]),
                       _ptr(ts.A_inT[1]), st)
-            main_s.wait_event(ev_tdrs)
+            main_s.wait_event(ev_tdrs)      # (events of one stream complete in order: this covers every earlier read of DX too)
             _lib.call("t2s_conv_accumulate", _ptr(ts.A_inT[0]), _ptr(ts.A_inT[1]), _ptr(zb), dp_h, dp_l, ts.dp_chunks,
                       _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, 2 * C, C, ks, d, 1 if last else 0, L, Lp, halo, ts.Mc, st)
             # W_cond,i^T goes into K-chunks [2 xc i, 2 xc (i + 1)) of the flow's conditioning-gradient GEMM
@@ -490,7 +499,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                 dsp_init = 0
         # d_spect (+)= [W_cond,0^T | ... | W_cond,nl-1^T] [d_pre_0 ; ... ; d_pre_nl-1]: one GEMM per flow, K = nl * 2C       [main]
         if not per_layer_cond:
-            _lib.call("t2s_conv_accumulate", _ptr(ts.A_cT[0]), _ptr(ts.A_cT[1]), _ptr(zb), _ptr(ts.DP[0]), _ptr(ts.DP[1]), 0,
+            _lib.call("t2s_conv_accumulate", _ptr(ts.A_cT[0]), _ptr(ts.A_cT[1]), _ptr(zb), _ptr(DP[0]), _ptr(DP[1]), 0,
                       _ptr(ts.DSp[0]), _ptr(ts.DSp[1]), B, nl * 2 * C, n_cond, 1, 1, dsp_init, L, Lp, halo, ts.Ms, st)
             dsp_init = 0
         # ---- WN.start ----
@@ -516,8 +525,14 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         _lib.call("t2s_wg_convinv", _ptr(dz), _ptr(WT), B, G, c_off, n_rem, L, st)            # dz <- W^T dz
         grads[id(m.convinv[k].conv.weight)] = dW
         keep.extend([Wk, Winv, WT, d_out])
-        main_s.wait_stream(side_s)          # this flow's weight gradients (side stream) are in the bucket
-        bucket.ship()
+        # this flow's gradients are complete once both streams get here; the bucket ships from the communication stream behind
+        # these two events, and the data-gradient chain goes straight on to the next flow (no join of the two streams)
+        ev_side = torch.cuda.Event()
+        ev_side.record(side_s)
+        side_done[k] = ev_side
+        ev_main = torch.cuda.Event()
+        ev_main.record(main_s)
+        bucket.ship((ev_main, ev_side))
     # ---- upsampler ----
     up = m.upsample
     bucket = _Bucket(up.parameters())
@@ -527,7 +542,10 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
               up.kernel_size[0], up.stride[0], G, L, Lp, halo, _ptr(dW_up), _ptr(db_up), st)
     grads[id(up.weight)] = dW_up
     grads[id(up.bias)] = db_up
-    bucket.ship()
+    ev_main = torch.cuda.Event()
+    ev_main.record(main_s)
+    bucket.ship((ev_main,))
+    main_s.wait_stream(side_s)              # every gradient has been written before autograd hands them on
     if sync is not None:
         sync.finish()
     ts.keep_bwd = keep
