@@ -183,16 +183,20 @@ def tacotron_forward(sd, hp, text, text_lengths, mels, output_lengths, masks, tr
     return mel_out, mel_post, gate_out, aligns
 
 
-def tacotron_inference(sd, hp, text, n_steps, prenet_masks, gate_threshold=None):
+def tacotron_inference(sd, hp, text, n_steps, prenet_masks, gate_threshold=None, training=False, masks=None):
     """Tacotron.inference (reference tacotron.py:51-65,431-466) for a fixed number of steps
-    (or until sigmoid(gate) > gate_threshold).  prenet_masks: [n_steps, B, 2, prenet_dim]."""
-    memory = encoder(sd, hp, text, None, False, None)
+    (or until sigmoid(gate) > gate_threshold).  prenet_masks: [n_steps, B, 2, prenet_dim].  training: the modules are in
+    .train() mode as the reference would have them if inference() were called on a training model - batch-statistics BatchNorm
+    and dropout in encoder / postnet (masks['enc'], masks['post']), dropout on both LSTM outputs (masks['att'], masks['dec']:
+    [n_steps, B, H])."""
+    memory = encoder(sd, hp, text, None, training, masks)
     B = text.size(0)
     st = DecoderState(sd, hp, memory, None)
     x = torch.zeros(B, hp["n_mel_channels"], dtype=memory.dtype)
     mel_out, gate_out, aligns = [], [], []
     for t in range(n_steps):
-        m, g, w = decode_step(sd, hp, st, prenet(sd, x, prenet_masks[t]))
+        m, g, w = decode_step(sd, hp, st, prenet(sd, x, prenet_masks[t]), masks["att"][t] if training else None,
+                              masks["dec"][t] if training else None)
         mel_out.append(m)
         gate_out.append(g)
         aligns.append(w)
@@ -202,7 +206,7 @@ def tacotron_inference(sd, hp, text, n_steps, prenet_masks, gate_threshold=None)
     mel_out = torch.stack(mel_out, 2)
     gate_out = torch.stack(gate_out, 1)                       # [B, T, 1] (reference returns [1, T, 1])
     aligns = torch.stack(aligns, 1)
-    mel_post = mel_out + postnet(sd, hp, mel_out)
+    mel_post = mel_out + postnet(sd, hp, mel_out, training, masks)
     return mel_out, mel_post, gate_out, aligns
 
 

@@ -227,6 +227,25 @@ def test_forward_training_mode_vs_golden(golden_dir):
         out2 = m((text.to(DEV), in_len.to(DEV), mel_t.to(DEV), int(in_len.max()), torch.zeros(B, device=DEV),
                   out_len.to(DEV)))
     assert bool(torch.isfinite(out2[1]).all())
-    # inference is an eval-mode path (reference inference.py:61)
-    with pytest.raises(NotImplementedError):
-        m.inference((torch.arange(8) + 2)[None].to(DEV), None)
+    # inference() on a model in .train() mode runs, as the reference's does (tacotron.py:51-65 has no mode check): batch statistics
+    # in every BatchNorm, live dropout in encoder / LSTM outputs / postnet.  Against the oracle with the same injected draws.
+    from oracle import tacotron_oracle as O
+    gen = torch.Generator().manual_seed(4)
+    n, Bi, Ti = 24, 3, 20
+    ids = torch.randint(2, 80, (Bi, Ti), generator=gen)
+    bern = lambda p, *s_: (torch.rand(*s_, generator=gen) < p).to(torch.uint8)
+    tm = {"enc": [bern(0.5, Bi, 512, Ti) for _ in range(3)], "att": bern(0.9, n, Bi, 1024), "dec": bern(0.9, n, Bi, 1024),
+          "post": [bern(0.5, Bi, 512, n) for _ in range(4)] + [bern(0.5, Bi, 80, n)]}
+    pm = bern(0.5, n, Bi, 2, 256)
+    m.decoder.gate_threshold, m.decoder.max_decoder_steps = 2.0, n
+    try:
+        got = m.inference(ids.to(DEV), None, prenet_masks=pm, train_masks=tm)
+    finally:
+        m.decoder.gate_threshold, m.decoder.max_decoder_steps = HP["gate_threshold"], HP["max_decoder_steps"]
+    masks = {"enc": [t.float() for t in tm["enc"]], "att": tm["att"].float(), "dec": tm["dec"].float(),
+             "post": [t.float() for t in tm["post"]]}
+    with torch.no_grad():
+        want = O.tacotron_inference(synth.tacotron_state(), HP, ids, n, pm.float(), training=True, masks=masks)
+    for name, a, b in zip(("mel", "mel_post", "gate", "align"), got, want):
+        assert tuple(a.shape) == tuple(b.shape), name
+        assert _rel(a, b) < 1e-3, (name, _rel(a, b))

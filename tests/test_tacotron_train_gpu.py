@@ -368,6 +368,47 @@ def test_benchmarked_shape_b32_t800_vs_reference_golden(golden_dir):
           % (float(loss), float(g["loss"]), worst_sq[0][0], worst_sq[0][1], worst[0][0], worst[0][1]))
 
 
+def test_pooled_buffers_carry_nothing_between_steps():
+    """The large save / scratch buffers of the training step come from a per-shape pool and are NOT cleared between steps
+    (tacotron.pool_take): whatever a step leaves in them must not reach the next one.  Two batches of ONE shape but different
+    ragged lengths (the second one's valid regions are shorter, so stale data of the first would sit right behind them), same
+    model object: the second step's outputs and gradients must be bit-identical to the same step on a fresh model."""
+    from text2speech_amd.tacotron import Tacotron, Tacotron2Loss
+    _lib.load()
+    B, T_in, T_out = 12, 40, 36
+    gen = torch.Generator().manual_seed(9)
+    batches = [_ragged(B, T_in, T_out, gen, din=lambda i: 0, dout=lambda i: 0),
+               _ragged(B, T_in, T_out, gen, din=lambda i: 2 * i, dout=lambda i: 2 * i if i else 0)]
+    masks = [_seeded_masks(B, T_in, T_out, gen) for _ in batches]
+    crit = Tacotron2Loss()
+
+    def step(m, k):
+        text, in_len, mel_t, gate_t, out_len = batches[k]
+        tm, pm, _ = masks[k]
+        m.load_state_dict(synth.tacotron_state(), strict=True)          # BatchNorm running statistics back to the start
+        m.zero_grad(set_to_none=True)
+        out = m((text.to(DEV), in_len.to(DEV), mel_t.to(DEV), int(in_len.max()), torch.zeros(B, device=DEV), out_len.to(DEV)),
+                prenet_masks=pm, train_masks=tm)
+        crit(out, (mel_t.to(DEV), gate_t.to(DEV))).backward()
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in out], {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    def fresh():
+        m = Tacotron(HP, 80, num_speakers=2)
+        m.load_state_dict(synth.tacotron_state(), strict=True)
+        return m.to(DEV).train()
+
+    m = fresh()
+    step(m, 0)                       # full-length batch first: fills every pooled buffer up to the shape's extent
+    out_b, grads_b = step(m, 1)      # shorter valid regions on the same buffers
+    out_f, grads_f = step(fresh(), 1)
+    for a, b in zip(out_b, out_f):
+        assert torch.equal(a, b)
+    assert sorted(grads_b) == sorted(grads_f)
+    for n in grads_f:
+        assert torch.equal(grads_b[n], grads_f[n]), n
+
+
 def test_dropout_masks_fresh_per_call_and_reproducible():
     """Every training forward / inference draws NEW dropout masks (reference: F.dropout on the global RNG,
     modules.py:21, tacotron.py:193,368,383) and torch.manual_seed reproduces them."""

@@ -10,6 +10,7 @@ Memory model (sized for 288 GB HBM3E): every WN layer's input, gate output and s
 resident as split-bf16 planes (~105 MB per layer, 10.1 GB per step at 8 x 16000; tanh is rebuilt as gate output / sigmoid) instead of being
 recomputed.
 """
+import ctypes
 import os
 
 import torch
@@ -123,9 +124,14 @@ def _alloc_train(eng, B, L, dev):
     st.P1 = torch.empty(st.ks1, 2 * C, st.ld1, dtype=torch.float32, device=dev)
     st.Mc = _lib.padded_rows(C)
     st.Ms = _lib.padded_rows(g["n_cond"])
-    st.A_rsT = (_bf(2 * C // 32, st.Mc, 32, dev=dev), _bf(2 * C // 32, st.Mc, 32, dev=dev))
-    st.A_inT = (_bf(g["ks"] * 2 * C // 32, st.Mc, 32, dev=dev), _bf(g["ks"] * 2 * C // 32, st.Mc, 32, dev=dev))
-    st.A_cT = (_bf(nl * 2 * C // 32, st.Ms, 32, dev=dev), _bf(nl * 2 * C // 32, st.Ms, 32, dev=dev))      # K = (layer, channel)
+    # Transposed weight operands of the backward's data-gradient GEMMs, one set per (flow, layer) (0.8 GB at config.json
+    # defaults): they depend on the weights only, so the forward produces them on its pack stream, under its own GEMMs, and the
+    # backward's dependent chain has three small launches per layer less.
+    pair = lambda kch, M: (_bf(kch, M, 32, dev=dev), _bf(kch, M, 32, dev=dev))
+    st.A_rsT = [[pair(2 * C // 32, st.Mc) for _ in range(nl)] for _ in range(m.n_flows)]
+    st.A_inT = [[pair(g["ks"] * 2 * C // 32, st.Mc) for _ in range(nl)] for _ in range(m.n_flows)]
+    st.A_cT = [pair(nl * 2 * C // 32, st.Ms) for _ in range(m.n_flows)]                                      # K = (layer, channel)
+    st.Winv = [torch.empty(eng._flow_geom(k)[1], eng._flow_geom(k)[1], dtype=torch.float32, device=dev) for k in range(m.n_flows)]
     st.zero_bias = torch.zeros(max(st.M2pad, st.Ms, 1024), dtype=torch.float32, device=dev)
     st.sw_scratch = torch.empty(_lib.load().t2s_small_wgrad_scratch(B, xc), dtype=torch.float32, device=dev)
     # channel-last weight-gradient GEMM (t2s_wgrad_cl): constant chunks and the per-layer operand tables (built on first use)
@@ -196,7 +202,30 @@ def forward_train(eng, mel, audio):
     g = eng.geom()
     C, nl, ks = g["C"], g["nl"], g["ks"]
     ts = _alloc_train(eng, B, L, dev)
-    eng.pack_weights(dev, force=True, res_pair8=ts.fold_train)
+    # The per-step weight work (weight-norm + pack of every convolution, the folded WN.end matrices, the 12 log-determinants and
+    # inverses of the 1x1 convolutions, the transposed operands of the backward) depends on the weights only: it runs on the
+    # engine's pack stream, flow by flow, and the main stream waits for flow k's event only - as in the no-grad forward.
+    main = torch.cuda.current_stream(dev)
+    pack_s = eng.pack_stream if getattr(eng, "pack_stream", None) is not None else torch.cuda.Stream(device=dev)
+    eng.pack_stream = pack_s
+    if os.environ.get("T2S_NO_SIDE_STREAM") or os.environ.get("T2S_PACK_OVERLAP") == "0":
+        pack_s = main
+    pack_events = []
+    log_det = torch.empty(m.n_flows, dtype=torch.float32, device=dev)
+    Ws = [_f32c(m.convinv[k].conv.weight) for k in range(m.n_flows)]
+    pack_s.wait_stream(main)
+    with torch.cuda.stream(pack_s):
+        eng.pack_weights(dev, force=True, flow_events=pack_events, res_pair8=ts.fold_train)
+        stp = _lib.current_stream()
+        if m.n_flows <= 16:         # B*L*logdet(W_k) and W_k^-1 of every flow in one launch (the table travels as a kernel argument)
+            jobs = torch.tensor([[Ws[k].data_ptr(), log_det.data_ptr() + 4 * k, ts.Winv[k].data_ptr(), eng._flow_geom(k)[1]]
+                                 for k in range(m.n_flows)], dtype=torch.int64)
+            _lib.call("t2s_small_logdet_inv_batch_host", ctypes.c_void_p(jobs.data_ptr()), m.n_flows, float(B * L), stp)
+            ts.keep_jobs = jobs
+        else:
+            for k in range(m.n_flows):
+                _lib.call("t2s_small_logdet_inv", _ptr(Ws[k]), eng._flow_geom(k)[1], float(B * L),
+                          _lib.c_vp(log_det.data_ptr() + 4 * k), _ptr(ts.Winv[k]), stp)
     pair8 = 1 if (ts.fold_train and eng.packed.get("res_pair8")) else 0
     st = _lib.current_stream()
     w = dict(Lp=ts.Lp, Sh=ts.S_planes[0], Sl=ts.S_planes[1])
@@ -205,14 +234,12 @@ def forward_train(eng, mel, audio):
     z = torch.empty(B, G, L, dtype=torch.float32, device=dev)
     _lib.call("t2s_wg_audio_squeeze", _ptr(audio32), _ptr(z), B, T, G, L, 0, st)
     log_s_list = []
-    log_det = torch.empty(m.n_flows, dtype=torch.float32, device=dev)
-    keep = [audio32]
+    keep = [audio32] + Ws
     for k in range(m.n_flows):
         c_off, n_rem, n_half = eng._flow_geom(k)
         fl = eng.packed["flows"][k]
-        Wk = _f32c(m.convinv[k].conv.weight)
-        keep.append(Wk)
-        _lib.call("t2s_small_logdet_inv", _ptr(Wk), n_rem, float(B * L), _lib.c_vp(log_det.data_ptr() + 4 * k), None, st)
+        Wk = Ws[k]
+        main.wait_event(pack_events[k])
         _lib.call("t2s_wg_convinv", _ptr(z), _ptr(Wk), B, G, c_off, n_rem, L, st)
         wn = m.WN[k]
         b_start = _f32c(wn.start.bias)
@@ -245,6 +272,24 @@ def forward_train(eng, mel, audio):
                       None if last else _ptr(sv["X"][0]), None if last else _ptr(sv["X"][1]),
                       None if last else _ptr(nxt[0]), None if last else _ptr(nxt[1]), _ptr(ts.skip[k]), B, C,
                       0 if last else C, 1 if i == 0 else 0, L, ts.Lp, g["halo"], ly["Mpad2"], st)
+        # the backward's transposed operands of this flow (weights only; per-row scales from this flow's pack): pack stream
+        with torch.cuda.stream(pack_s):
+            stp = _lib.current_stream()
+            wn_k = m.WN[k]
+            for i in range(nl):
+                last_i = i == nl - 1
+                rows2 = C if last_i else 2 * C
+                pk = fl["layers"][i]
+                v_rs = _f32c(_vg(wn_k.res_skip_layers[i])[0])
+                v_in = _f32c(_vg(wn_k.in_layers[i])[0])
+                v_c = _f32c(_vg(wn_k.cond_layers[i])[0])
+                keep.extend([v_rs, v_in, v_c])
+                _lib.call("t2s_pack_transposed", _ptr(v_rs), _ptr(pk["s_rs"]), rows2, C, 1, 0, rows2, ts.Mc, 0,
+                          _ptr(ts.A_rsT[k][i][0]), _ptr(ts.A_rsT[k][i][1]), stp)
+                _lib.call("t2s_pack_transposed", _ptr(v_in), _ptr(pk["s_in"]), 2 * C, C, ks, 1, 2 * C, ts.Mc, 0,
+                          _ptr(ts.A_inT[k][i][0]), _ptr(ts.A_inT[k][i][1]), stp)
+                _lib.call("t2s_pack_transposed", _ptr(v_c), _ptr(pk["s_cond"]), 2 * C, g["n_cond"], 1, 0, 2 * C, ts.Ms, i * 2 * C,
+                          _ptr(ts.A_cT[k][0]), _ptr(ts.A_cT[k][1]), stp)
         log_s = torch.empty(B, n_half, L, dtype=torch.float32, device=dev)
         ts.wn_out[k] = torch.empty(B, 2 * n_half, L, dtype=torch.float32, device=dev)
         if ts.fold_train:
@@ -252,6 +297,7 @@ def forward_train(eng, mel, audio):
         else:
             eng._end(k, z, log_s, B, L, dict(Lp=ts.Lp), c_off, n_half, reverse=False, wn_out=ts.wn_out[k], skip=ts.skip[k])
         log_s_list.append(log_s)
+    main.wait_stream(pack_s)            # log-determinants, inverses, transposed operands: all in before the outputs are used
     ts.z_final = z
     ts.mel = _f32c(mel)
     ts.B, ts.L = B, L
@@ -425,10 +471,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             Mrs = _lib.padded_rows(rows2)
             conv_rs, conv_in, conv_c = wn.res_skip_layers[i], wn.in_layers[i], wn.cond_layers[i]
             # 1. d_pre = gate'(T,G) * (W_rs^T [dx ; dS])                                                     [main]
-            pk = fl["layers"][i]
-            v_rs, s_rs = scale_of(conv_rs, pk["s_rs"])
-            _lib.call("t2s_pack_transposed", _ptr(v_rs), _ptr(s_rs), rows2, C, 1, 0, rows2, ts.Mc, 0, _ptr(ts.A_rsT[0]),
-                      _ptr(ts.A_rsT[1]), st)
+            A_rsT, A_inT, A_cT = ts.A_rsT[k][i], ts.A_inT[k][i], ts.A_cT[k]
             ev_in = torch.cuda.Event()          # DX / DS of this layer are final (last written on the main stream)
             ev_in.record(main_s)
             # this layer's slice of the flow-wide d_pre planes (bytes from the start of each plane)
@@ -436,7 +479,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             dp_h, dp_l = _lib.c_vp(DP[0].data_ptr() + dp_off), _lib.c_vp(DP[1].data_ptr() + dp_off)
             a_h, a_l = _act_ptrs(ts, k, i, "A")
             g_h, g_l = _act_ptrs(ts, k, i, "G")
-            _lib.call("t2s_wg_bwd_gate_dgrad", _ptr(ts.A_rsT[0]), _ptr(ts.A_rsT[1]), _ptr(zb),
+            _lib.call("t2s_wg_bwd_gate_dgrad", _ptr(A_rsT[0]), _ptr(A_rsT[1]), _ptr(zb),
                       None if last else _ptr(ts.DX[0]), None if last else _ptr(ts.DX[1]), _ptr(DS[0]), _ptr(DS[1]),
                       a_h, a_l, g_h, g_l, ts.act_bchunks, dp_h, dp_l, ts.dp_chunks, B, C, L, Lp, halo, ts.Mc, st)
             ev_dp = torch.cuda.Event()
@@ -481,25 +524,19 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             wn_grads(conv_in, ts.P2, ts.ks2, 2 * C, ts.ld2, 0, C, ts.N2 - 1, 2 * C, C, ks, stream=st2)
             wn_grads(conv_c, ts.P2, ts.ks2, 2 * C, ts.ld2, ks * C, 0, ts.N2 - 1, 2 * C, n_cond, 1, stream=st2)
             # 4. dx (+)= W_in^T (*) d_pre ;  d_spect += W_cond^T d_pre                                       [main]
-            v_in, s_in = scale_of(conv_in, pk["s_in"])
-            _lib.call("t2s_pack_transposed", _ptr(v_in), _ptr(s_in), 2 * C, C, ks, 1, 2 * C, ts.Mc, 0, _ptr(ts.A_inT[0]),
-                      _ptr(ts.A_inT[1]), st)
             main_s.wait_event(ev_tdrs)      # (events of one stream complete in order: this covers every earlier read of DX too)
-            _lib.call("t2s_conv_accumulate", _ptr(ts.A_inT[0]), _ptr(ts.A_inT[1]), _ptr(zb), dp_h, dp_l, ts.dp_chunks,
+            _lib.call("t2s_conv_accumulate", _ptr(A_inT[0]), _ptr(A_inT[1]), _ptr(zb), dp_h, dp_l, ts.dp_chunks,
                       _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, 2 * C, C, ks, d, 1 if last else 0, L, Lp, halo, ts.Mc, st)
-            # W_cond,i^T goes into K-chunks [2 xc i, 2 xc (i + 1)) of the flow's conditioning-gradient GEMM
-            v_c, s_c = scale_of(conv_c, pk["s_cond"])
-            _lib.call("t2s_pack_transposed", _ptr(v_c), _ptr(s_c), 2 * C, n_cond, 1, 0, 2 * C, ts.Ms, i * 2 * C, _ptr(ts.A_cT[0]),
-                      _ptr(ts.A_cT[1]), st)
+            # (W_cond,i^T sits in K-chunks [2 xc i, 2 xc (i + 1)) of the flow's conditioning-gradient operand A_cT)
             if per_layer_cond:          # A/B switch (T2S_WCOND_PER_LAYER=1): the round-2 form, one accumulate per layer
                 a_off = 2 * i * 2 * xc * ts.Ms * 32
-                _lib.call("t2s_conv_accumulate", _lib.c_vp(ts.A_cT[0].data_ptr() + a_off), _lib.c_vp(ts.A_cT[1].data_ptr() + a_off),
+                _lib.call("t2s_conv_accumulate", _lib.c_vp(A_cT[0].data_ptr() + a_off), _lib.c_vp(A_cT[1].data_ptr() + a_off),
                           _ptr(zb), dp_h, dp_l, ts.dp_chunks, _ptr(ts.DSp[0]), _ptr(ts.DSp[1]), B, 2 * C, n_cond, 1, 1, dsp_init,
                           L, Lp, halo, ts.Ms, st)
                 dsp_init = 0
         # d_spect (+)= [W_cond,0^T | ... | W_cond,nl-1^T] [d_pre_0 ; ... ; d_pre_nl-1]: one GEMM per flow, K = nl * 2C       [main]
         if not per_layer_cond:
-            _lib.call("t2s_conv_accumulate", _ptr(ts.A_cT[0]), _ptr(ts.A_cT[1]), _ptr(zb), _ptr(DP[0]), _ptr(DP[1]), 0,
+            _lib.call("t2s_conv_accumulate", _ptr(ts.A_cT[k][0]), _ptr(ts.A_cT[k][1]), _ptr(zb), _ptr(DP[0]), _ptr(DP[1]), 0,
                       _ptr(ts.DSp[0]), _ptr(ts.DSp[1]), B, nl * 2 * C, n_cond, 1, 1, dsp_init, L, Lp, halo, ts.Ms, st)
             dsp_init = 0
         # ---- WN.start ----
@@ -514,9 +551,8 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                   L, Lp, halo, st)
         # ---- invertible 1x1 conv ----
         Wk = _f32c(m.convinv[k].conv.weight)
-        Winv = new(n_rem, n_rem)
+        Winv = ts.Winv[k]                   # from the forward's batched launch
         WT = new(n_rem, n_rem)
-        _lib.call("t2s_small_logdet_inv", _ptr(Wk), n_rem, 1.0, None, _ptr(Winv), st)
         _lib.call("t2s_transpose", _ptr(Wk), _ptr(WT), n_rem, n_rem, st)
         _lib.call("t2s_wg_convinv", _ptr(zw), _ptr(Winv), B, G, c_off, n_rem, L, st)          # zw <- flow input
         dW = bucket.take(*m.convinv[k].conv.weight.shape)

@@ -18,7 +18,7 @@ import ctypes
 import torch
 
 from .. import _lib
-from .tacotron import _f32
+from .tacotron import _f32, pool_take
 
 vp, i32, f32c, lng = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long
 
@@ -73,16 +73,35 @@ class _Bwd:
         self.st = _lib.current_stream()
         self.grads = {}
         self.keep = []
-        self.zero_bias = torch.zeros(8192, dtype=torch.float32, device=self.dev)
+        if eng.pool is None:
+            eng.pool = {}
+        self.leases = []            # buffers of this backward pass, back in the engine's pool when it is released
+        self.zero_bias = pool_take(eng.pool, self.leases, "zero_bias", (8192,), torch.float32, self.dev, zero_once=True)
+        self._seq = 0
 
-    def new(self, *shape):
+    def new(self, *shape, tag=None):
+        """f32 scratch every element of which its producer writes.  tag: take it from the engine's pool (large buffers)."""
+        if tag is not None:
+            return pool_take(self.eng.pool, self.leases, tag, shape, torch.float32, self.dev)
         return torch.empty(*shape, dtype=torch.float32, device=self.dev)
 
     def zeros(self, *shape):
+        """f32 scratch that must START at zero (accumulators, carries): cleared every step."""
         return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
 
-    def bf(self, *shape):
+    def bf(self, *shape, tag=None):
+        """bf16 operand planes.  Their producers write the valid region and leave padding (halo rows, rows / columns / K-blocks
+        past the operand's extent) untouched, and that padding must read as zero.  Which elements are padding depends on the
+        shape and the call site only - never on the data or on sequence lengths (ragged entries are zeroed BY VALUE inside the
+        valid region) - so a pooled buffer zeroed once at creation stays correct: tag = the call site (+ loop index where several
+        are alive at once).  No tag: a fresh zero-filled tensor."""
+        if tag is not None:
+            return pool_take(self.eng.pool, self.leases, tag, shape, torch.bfloat16, self.dev, zero_once=True)
         return torch.zeros(*shape, dtype=torch.bfloat16, device=self.dev)
+
+    def seq(self):
+        self._seq += 1
+        return self._seq
 
     # ------------------------------------------------------------------ generic pieces
     def gemv(self, W, ld, K, x_ptr, sx, y_ptr, sy_item, rows, items):
@@ -105,8 +124,9 @@ class _Bwd:
         Mpad = _lib.padded_rows(M4)
         N = N_cols + 1
         Npad = _ru(N, 256)
-        A = (self.bf(nch, Mpad, 32), self.bf(nch, Mpad, 32))
-        X = (self.bf(nch, Npad, 32), self.bf(nch, Npad, 32))
+        n_ = self.seq()             # the n-th call of a backward pass is the same call site in every step
+        A = (self.bf(nch, Mpad, 32, tag=("iw_Ah", n_)), self.bf(nch, Mpad, 32, tag=("iw_Al", n_)))
+        X = (self.bf(nch, Npad, 32, tag=("iw_Xh", n_)), self.bf(nch, Npad, 32, tag=("iw_Xl", n_)))
         for (ptr, ld, C, off, shift) in a_srcs:
             _lib.call("t2s_rows_to_tm", ptr, ld, items, items_pad, shift, C, _p(A[0]), _p(A[1]), Mpad, off, self.st)
         for (ptr, ld, C, off, shift) in x_srcs:
@@ -141,7 +161,8 @@ class _Bwd:
             B, T, Lp, halo = s["B"], s["T"], s["Lp"], s["halo"]
             Cout, Cin, Kt = layer["Cout"], layer["Cin"], layer["taps"]
             occ = -(-Cout // 32)
-            dconv = (self.bf(B, occ, Lp, 32), self.bf(B, occ, Lp, 32))
+            cs_ = self.seq()
+            dconv = (self.bf(B, occ, Lp, 32, tag=("cs_dch", cs_)), self.bf(B, occ, Lp, 32, tag=("cs_dcl", cs_)))
             dgamma, dbeta = self.new(Cout), self.new(Cout)
             g32, b32 = _f32(bn.weight), _f32(bn.bias)
             a = _BnBwd(x=s["y"].data_ptr(), mean=s["mean"].data_ptr(), var=s["var"].data_ptr(), gamma=g32.data_ptr(),
@@ -162,8 +183,8 @@ class _Bwd:
             Ncols = Kt * Cin_pad
             N = Ncols + 1
             Npad = _ru(N, 256)
-            A = (self.bf(B, nt, Mpad, 32), self.bf(B, nt, Mpad, 32))
-            X = (self.bf(B, nt, Npad, 32), self.bf(B, nt, Npad, 32))
+            A = (self.bf(B, nt, Mpad, 32, tag=("cs_Ah", cs_)), self.bf(B, nt, Mpad, 32, tag=("cs_Al", cs_)))
+            X = (self.bf(B, nt, Npad, 32, tag=("cs_Xh", cs_)), self.bf(B, nt, Npad, 32, tag=("cs_Xl", cs_)))
             _lib.call("t2s_plane_transpose", _p(dconv[0]), _p(dconv[1]), B, occ, occ, Lp, 0, _p(A[0]), _p(A[1]), Mpad, 0, self.st)
             icc = Cin_pad // 32
             for tap in range(Kt):
@@ -180,9 +201,9 @@ class _Bwd:
             w32 = _f32(conv.weight)
             Opad = _ru(Cout, 32)
             Mi = _lib.padded_rows(Cin)
-            At = (self.bf(Kt * Opad // 32, Mi, 32), self.bf(Kt * Opad // 32, Mi, 32))
+            At = (self.bf(Kt * Opad // 32, Mi, 32, tag=("cs_Ath", cs_)), self.bf(Kt * Opad // 32, Mi, 32, tag=("cs_Atl", cs_)))
             _lib.call("t2s_pack_transposed", _p(w32), None, Cout, Cin, Kt, 1, Opad, Mi, 0, _p(At[0]), _p(At[1]), self.st)
-            d_in = (self.bf(B, icc, Lp, 32), self.bf(B, icc, Lp, 32))
+            d_in = (self.bf(B, icc, Lp, 32, tag=("cs_dih", cs_)), self.bf(B, icc, Lp, 32, tag=("cs_dil", cs_)))
             _lib.call("t2s_conv_accumulate", _p(At[0]), _p(At[1]), _p(self.zero_bias), _p(dconv[0]), _p(dconv[1]), 0, _p(d_in[0]),
                       _p(d_in[1]), B, Cout, _ru(Cin, 4), Kt, 1, 1, T, Lp, halo, Mi, self.st)
             self.keep += [w32, At, d_in]
@@ -250,10 +271,11 @@ class _Bwd:
         W_dT = self.transpose(torch.cat([P["dec_w_ih"], P["dec_w_hh"]], 1).contiguous())      # [A+E+D][4D]
         W_aT = self.transpose(torch.cat([P["att_w_ih"], P["att_w_hh"]], 1).contiguous())      # [Pd+E+A][4A]
         KD, KA = A + E + D, Pd + E + A
-        out_d = self.zeros(T, B, KD)
-        out_a = self.zeros(T, B, KA)
-        dg_d, dg_a = self.zeros(T, B, 4 * D), self.zeros(T, B, 4 * A)
-        dq_all = self.zeros(T, B, ad)
+        # written whole, step by step, by the BPTT kernels (every batch entry, every column): pooled, never cleared
+        out_d = self.new(T, B, KD, tag="bptt_out_d")
+        out_a = self.new(T, B, KA, tag="bptt_out_a")
+        dg_d, dg_a = self.new(T, B, 4 * D, tag="bptt_dg_d"), self.new(T, B, 4 * A, tag="bptt_dg_a")
+        dq_all = self.new(T, B, ad, tag="bptt_dq_all")
         dc_d, dc_a = self.zeros(B, D), self.zeros(B, A)
         dw_c, dwc_c = self.zeros(B, T_in), self.zeros(B, T_in)
         d_pmem, d_memory = self.zeros(B, T_in, ad), self.zeros(B, T_in, E)

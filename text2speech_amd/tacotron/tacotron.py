@@ -106,7 +106,35 @@ def _f32(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+class _Lease:
+    """A buffer taken from the engine's per-shape pool; goes back when its holder (the autograd context of one step, or that
+    step's backward scratch) is released.  While leased it is in no free list, so two live steps never share a buffer; reuse is
+    stream-ordered like the caching allocator's."""
+
+    def __init__(self, free, tensor):
+        self.free, self.tensor = free, tensor
+
+    def __del__(self):
+        try:
+            self.free.append(self.tensor)
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def pool_take(pool, holder, tag, shape, dtype, device, zero_once=False):
+    """Buffer of `shape` for call site `tag`: reused from the pool when one is free (NOT cleared - either every element is
+    rewritten by the kernels that own it, or, with zero_once, the elements they never write were zeroed when the buffer was
+    created and depend on the shape only), else allocated.  `holder` (a list) keeps the lease."""
+    key = (tag, tuple(int(x) for x in shape), dtype, str(device))
+    free = pool.setdefault(key, [])
+    t = free.pop() if free else (torch.zeros if zero_once else torch.empty)(*shape, dtype=dtype, device=device)
+    holder.append(_Lease(free, t))
+    return t
+
+
 class _TacoEngine:
+    pool = None     # per-engine buffer pool (created on first use): {(tag, shape, dtype, device): [free tensors]}
+
     def __init__(self, model):
         self.m = model
         self.prep = None
@@ -408,20 +436,32 @@ class _TacoEngine:
         ``torch.manual_seed`` reproduces them.  Host-side draw: no device synchronisation."""
         return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
-    def inference(self, ids, prenet_masks=None, seed=None, chunk=64):
+    def inference(self, ids, prenet_masks=None, seed=None, chunk=64, train_masks=None):
+        """Tacotron.inference (reference tacotron.py:51-65).  In ``.train()`` mode the reference simply runs with its modules in
+        training mode: the encoder / postnet convolutions use batch statistics and dropout(0.5) (tacotron.py:193, modules.py:131-137)
+        and both LSTM outputs get dropout (tacotron.py:368,383); the same here (``train_masks`` as in ``forward``, 'att' / 'dec' of
+        shape [max_decoder_steps, B, H])."""
         if seed is None:
             seed = self.fresh_seed()
         m = self.m
         dec = m.decoder
         dev = ids.device
         self.prepare(dev)
-        memory, _ = self.encode(ids, None)
+        memory, _ = self.encode(ids, None, train_masks, seed)
         B = ids.size(0)
         T_cap = int(dec.max_decoder_steps)
         n_mel = dec.n_mel_channels * dec.n_frames_per_step
         mk = self._masks(prenet_masks, T_cap, B, dec.prenet_dim, dev, seed)
         mel_gate = torch.zeros(B, n_mel + 1, T_cap, dtype=torch.float32, device=dev)
-        d, S = self._decoder_struct(memory, None, T_cap, False, dict(prenet_masks=mk, mel_gate_out=mel_gate))
+        extra = dict(prenet_masks=mk, mel_gate_out=mel_gate)
+        if m.training:
+            tm = train_masks or {}
+            extra["att_drop"] = self._drop(tm.get("att"), (T_cap, B, dec.attention_rnn_dim), 1 - dec.p_attention_dropout, dev, seed + 301)
+            extra["dec_drop"] = self._drop(tm.get("dec"), (T_cap, B, dec.decoder_rnn_dim), 1 - dec.p_decoder_dropout, dev, seed + 302)
+        d, S = self._decoder_struct(memory, None, T_cap, False, extra)
+        if m.training:
+            d.att_drop_scale = 1.0 / (1.0 - dec.p_attention_dropout)
+            d.dec_drop_scale = 1.0 / (1.0 - dec.p_decoder_dropout)
         d.mask_steps = mk.numel() // (B * 2 * dec.prenet_dim)
         stop = torch.full((B,), -1, dtype=torch.int32, device=dev)
         st = _lib.current_stream()
@@ -442,7 +482,7 @@ class _TacoEngine:
         mel = mel_gate[:, :n_mel, :n_done].contiguous()
         gate = mel_gate[:, n_mel, :n_done].unsqueeze(-1).contiguous()          # [B, T, 1] as the reference returns
         align = S["align_out"][:, :n_done].contiguous()
-        mel_post = mel + self.postnet(mel)
+        mel_post = mel + self.postnet(mel, train_masks, seed)
         return [mel, mel_post, gate, align]
 
     def forward(self, text, text_lengths, mels, output_lengths, prenet_masks=None, seed=None, train_masks=None, save=None):
@@ -476,10 +516,17 @@ class _TacoEngine:
         if save is not None:        # per-step state the decoder backward needs (teacher-forced, training)
             A_, T_in_ = dec.attention_rnn_dim, memory.size(1)
             ad_ = dec.attention_layer.query_layer.linear_layer.out_features
-            zf = lambda *sh: torch.zeros(*sh, dtype=torch.float32, device=dev)
-            extra.update(att_gates_all=zf(T_out, B, 4 * A_), att_c_all=zf(T_out, B, A_), dec_gates_all=zf(T_out, B, 4 * D),
-                         dec_c_all=zf(T_out, B, D), att_h_all=zf(T_out, B, A_), q_all=zf(T_out, B, ad_),
-                         wcum_all=zf(T_out, B, T_in_))
+            # 1.2 GB at B=32, T_out=800.  Every element is written by the decode steps (each step stores the gates / cell state /
+            # query / cumulative weights of ALL batch entries and ALL encoder positions), so nothing is cleared: the buffers
+            # come from the engine's pool and go back when this step's autograd context is released.
+            if self.pool is None:
+                self.pool = {}
+            leases = save.setdefault("_leases", [])
+            zf = lambda name, *sh: pool_take(self.pool, leases, name, sh, torch.float32, dev)
+            extra.update(att_gates_all=zf("att_gates_all", T_out, B, 4 * A_), att_c_all=zf("att_c_all", T_out, B, A_),
+                         dec_gates_all=zf("dec_gates_all", T_out, B, 4 * D), dec_c_all=zf("dec_c_all", T_out, B, D),
+                         att_h_all=zf("att_h_all", T_out, B, A_), q_all=zf("q_all", T_out, B, ad_),
+                         wcum_all=zf("wcum_all", T_out, B, T_in_))
         d, S = self._decoder_struct(memory, len32, T_out, True, extra)
         if m.training:
             d.att_drop_scale = 1.0 / (1.0 - dec.p_attention_dropout)
@@ -561,13 +608,12 @@ class Tacotron(nn.Module):
                                       train_masks=train_masks)
         return self._as_module_dtype(out)
 
-    def inference(self, inputs, speaker_id=None, prenet_masks=None):
-        """Autoregressive decode (reference tacotron.py:51-65)."""
+    def inference(self, inputs, speaker_id=None, prenet_masks=None, train_masks=None):
+        """Autoregressive decode (reference tacotron.py:51-65).  Works in ``.train()`` mode as the reference's does (batch-statistics
+        BatchNorm and live dropout everywhere; ``train_masks`` injects the draws), although inference.py:61 calls it in eval mode."""
         self._check(inputs)
-        if self.training:
-            raise NotImplementedError("Tacotron.inference is an eval-mode path (reference inference.py:61); call .eval()")
         with torch.no_grad():
-            out = self._eng().inference(inputs, prenet_masks)
+            out = self._eng().inference(inputs, prenet_masks, train_masks=train_masks)
         return self._as_module_dtype(self.parse_output(out))
 
     def _as_module_dtype(self, outputs):
