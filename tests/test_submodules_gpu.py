@@ -1,0 +1,122 @@
+"""The reference's sub-module call surface: Encoder.forward / .inference, Prenet.forward, Postnet.forward,
+Decoder.forward / .inference (reference tacotron.py:192-220,395-466, modules.py:19-22,131-137), WN.forward and
+Invertible1x1Conv.forward (waveglow/glow.py:82-102,154-175) - each against the oracle's function of the same name."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from text2speech_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HP = synth.TACOTRON_HPARAMS
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def taco():
+    _lib.load()
+    from text2speech_amd.tacotron import Tacotron
+    m = Tacotron(HP, 80, num_speakers=2)
+    m.load_state_dict(synth.tacotron_state(), strict=True)
+    return m.to(DEV).eval()
+
+
+def test_tacotron_submodules_vs_oracle(taco):
+    from oracle import tacotron_oracle as O
+    sd = synth.tacotron_state()
+    gen = torch.Generator().manual_seed(12)
+    B, T_in, T_out = 3, 24, 18
+    ids = torch.randint(2, 80, (B, T_in), generator=gen)
+    lengths = torch.tensor([24, 20, 13])
+    for b in range(B):
+        ids[b, lengths[b]:] = 0
+    emb = sd["embedding.weight"][ids].transpose(1, 2).contiguous()              # [B, 512, T]: what Tacotron.forward hands the encoder
+    # Encoder.forward (lengths) / .inference (none)
+    mem = taco.encoder(emb.to(DEV), lengths.to(DEV))
+    with torch.no_grad():
+        want = O.encoder(sd, HP, ids, lengths)
+        want_inf = O.encoder(sd, HP, ids[:1], None)
+    assert tuple(mem.shape) == tuple(want.shape) and _rel(mem, want) < 1e-3
+    assert _rel(taco.encoder.inference(emb[:1].to(DEV)), want_inf) < 1e-3
+    # Prenet.forward: the dropout is always on; the draws injected
+    x = torch.randn(7, B, 80, generator=gen)
+    pm = (torch.rand(7 * B, 1, 2, 256, generator=gen) < 0.5).to(torch.uint8)
+    got = taco.decoder.prenet(x.to(DEV), masks=pm)
+    with torch.no_grad():
+        want = O.prenet(sd, x.reshape(-1, 80), pm.float().reshape(-1, 2, 256)).view(7, B, 256)
+    assert tuple(got.shape) == (7, B, 256) and _rel(got, want) < 1e-5
+    assert bool(torch.isfinite(taco.decoder.prenet(x.to(DEV))).all())           # device-drawn masks
+    # Postnet.forward (eval): the residual, which the caller adds
+    mel = torch.randn(B, 80, T_out, generator=gen)
+    with torch.no_grad():
+        want = O.postnet(sd, HP, mel)
+    assert _rel(taco.postnet(mel.to(DEV)), want) < 1e-3
+    # Decoder.forward: teacher-forced, memory from the encoder above
+    pm2 = (torch.rand(T_out + 1, B, 2, 256, generator=gen) < 0.5).to(torch.uint8)
+    mel_o, gate_o, align_o = taco.decoder(mem, mel.to(DEV), lengths.to(DEV), prenet_masks=pm2)
+    with torch.no_grad():
+        w = O.tacotron_forward(sd, HP, ids, lengths, mel, None, {"prenet": pm2.float()})
+    assert _rel(mel_o, w[0]) < 1e-3 and _rel(gate_o, w[2]) < 1e-3 and _rel(align_o, w[3]) < 1e-3
+    # Decoder.inference: forced length
+    n = 16
+    pm3 = (torch.rand(n, 1, 2, 256, generator=gen) < 0.5).to(torch.uint8)
+    taco.decoder.gate_threshold, taco.decoder.max_decoder_steps = 2.0, n
+    try:
+        mel_i, gate_i, align_i = taco.decoder.inference(taco.encoder.inference(emb[:1].to(DEV)), prenet_masks=pm3)
+    finally:
+        taco.decoder.gate_threshold, taco.decoder.max_decoder_steps = HP["gate_threshold"], HP["max_decoder_steps"]
+    with torch.no_grad():
+        w = O.tacotron_inference(sd, HP, ids[:1], n, pm3.float())
+    assert _rel(mel_i, w[0]) < 1e-3 and _rel(align_i, w[3]) < 1e-3 and tuple(gate_i.shape) == (1, n, 1)
+
+
+def test_submodules_survive_copy_and_pickle(taco):
+    import copy
+    import pickle
+    m2 = pickle.loads(pickle.dumps(taco.cpu()))
+    taco.to(DEV)
+    m2 = m2.to(DEV).eval()
+    mel = torch.randn(1, 80, 8).to(DEV)
+    assert torch.equal(m2.postnet(mel), taco.postnet(mel))
+    m3 = copy.deepcopy(taco)
+    assert m3.decoder.prenet.__dict__["_owner"]() is m3 and torch.equal(m3.postnet(mel), taco.postnet(mel))
+    from text2speech_amd.tacotron.modules import Postnet
+    with pytest.raises(RuntimeError):
+        Postnet(HP)(mel)                                   # a stand-alone container has no engine
+
+
+def test_waveglow_submodules_vs_oracle():
+    from oracle import waveglow_oracle as O
+    from text2speech_amd.glow import WaveGlow
+    _lib.load()
+    cfg = synth.WAVEGLOW_SMALL
+    sd = synth.waveglow_state(cfg)
+    m = WaveGlow(**cfg)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    gen = torch.Generator().manual_seed(3)
+    B, L = 2, 600
+    for k in (0, 5, 11):
+        n_half = m.WN[k].start.in_channels
+        audio = torch.randn(B, n_half, L, generator=gen)
+        spect = torch.randn(B, 640, L, generator=gen)
+        got = m.WN[k]((audio.to(DEV), spect.to(DEV)))
+        with torch.no_grad():
+            want = O.wn_forward(sd, cfg, k, audio, spect)
+        assert tuple(got.shape) == tuple(want.shape) == (B, 2 * n_half, L)
+        assert _rel(got, want) < 1e-3, (k, _rel(got, want))
+    conv = m.convinv[4]
+    c = conv.conv.weight.size(0)
+    z = torch.randn(B, c, L, generator=gen)
+    out, log_det = conv(z.to(DEV))
+    W = sd["convinv.4.conv.weight"]
+    assert _rel(out, F.conv1d(z, W)) < 1e-5
+    assert abs(float(log_det) - float(B * L * torch.logdet(W.squeeze(-1)))) < 1e-3 * abs(float(B * L * torch.logdet(W.squeeze(-1)))) + 1e-3
+    back = conv(out, reverse=True)
+    assert _rel(back, z) < 1e-4 and hasattr(conv, "W_inverse")

@@ -98,6 +98,30 @@ class Invertible1x1Conv(torch.nn.Module):
             W[:, 0] = -1 * W[:, 0]
         self.conv.weight.data = W.contiguous().view(c, c, 1)
 
+    def forward(self, z, reverse=False):
+        """Reference glow.py:82-102 for callers that use the module directly (WaveGlow.forward / infer drive the same kernels
+        through the engine): z [B, c, T] -> (W z, B * T * log|det W|), or with reverse=True -> W^-1 z, the inverse computed on
+        first use and cached as ``W_inverse`` exactly as the reference caches it."""
+        if not z.is_cuda:
+            raise _lib.T2SError("Invertible1x1Conv (MI355X build) needs tensors in HBM; there is no CPU path")
+        B, c, T = z.shape
+        st = _lib.current_stream()
+        out = z.detach().to(torch.float32).contiguous().clone()
+        W = _f32c(self.conv.weight).view(c, c)
+        with torch.no_grad():
+            if reverse:
+                if not hasattr(self, "W_inverse"):
+                    Winv = torch.empty(c, c, dtype=torch.float32, device=z.device)
+                    _lib.call("t2s_small_logdet_inv", _lib.ptr(W), c, 1.0, None, _lib.ptr(Winv), st)
+                    self.W_inverse = Winv.view(c, c, 1)
+                Wi = self.W_inverse.detach().to(torch.float32).contiguous()
+                _lib.call("t2s_wg_convinv", _lib.ptr(out), _lib.ptr(Wi), B, c, 0, c, T, st)
+                return out.to(z.dtype)
+            log_det = torch.empty(1, dtype=torch.float32, device=z.device)
+            _lib.call("t2s_small_logdet_inv", _lib.ptr(W), c, float(B * T), _lib.ptr(log_det), None, st)
+            _lib.call("t2s_wg_convinv", _lib.ptr(out), _lib.ptr(W), B, c, 0, c, T, st)
+            return out.to(z.dtype), log_det[0]
+
 
 class WN(torch.nn.Module):
     """Parameter container for the coupling network (reference glow.py:105-152):
@@ -128,6 +152,22 @@ class WN(torch.nn.Module):
             self.cond_layers.append(wn(torch.nn.Conv1d(n_mel_channels, 2 * n_channels, 1), name="weight"))
             rs = 2 * n_channels if i < n_layers - 1 else n_channels
             self.res_skip_layers.append(wn(torch.nn.Conv1d(n_channels, rs, 1), name="weight"))
+
+    def __getstate__(self):            # the back-reference to the owning WaveGlow (a weak reference) stays out of pickles / copies
+        d = self.__dict__.copy()
+        d.pop("_owner", None)
+        return d
+
+    def forward(self, forward_input):
+        """Reference glow.py:154-175: (audio [B, n_in, L], spect [B, n_mel * n_group, L]) -> WN.end's output [B, 2 n_in, L]
+        ((b ; log_s) of the coupling).  Runs on the engine of the WaveGlow this module belongs to (forward only)."""
+        ref = self.__dict__.get("_owner")
+        owner = ref() if ref is not None else None
+        if owner is None:
+            raise _lib.T2SError("WN.forward runs on the engine of the WaveGlow it belongs to; build it through WaveGlow(...)")
+        audio, spect = forward_input
+        with torch.no_grad():
+            return owner._eng().wn_forward(self.__dict__["_flow"], audio, spect)
 
 
 def _vg(conv):
@@ -426,6 +466,35 @@ class _Engine:
                           _lib.ptr(w["Ah"]), _lib.ptr(w["Al"]), _lib.ptr(w["Xh"]), _lib.ptr(w["Xl"]), _lib.ptr(w["skip"]),
                           B, C, n_res, 1 if i == 0 else 0, L, w["Lp"], g["halo"], ly["Mpad2"], st)
 
+    def wn_forward(self, k, audio, spect):
+        """WN[k].forward((audio, spect)) (reference glow.py:154-175) on the no-grad kernels: start, n_layers x (gate GEMM with
+        WN.end folded in, residual GEMM), then WN.end's output (b ; log_s) without applying the coupling."""
+        m = self.m
+        self._check_inputs(audio, spect)
+        dev = audio.device
+        B, n_in, L = audio.shape
+        c_off, n_rem, n_half = self._flow_geom(k)
+        g = self.geom()
+        if n_in != n_half or spect.size(1) != g["n_cond"] or spect.size(2) != L:
+            raise ValueError("WN[%d] takes audio [B, %d, L] and spect [B, %d, L]" % (k, n_half, g["n_cond"]))
+        self.pack_weights(dev, force=False, res_pair8=self.use_fold)
+        w = self.workspace(B, L, dev)
+        st = _lib.current_stream()
+        spect32 = _f32c(spect)
+        _lib.call("t2s_f32_to_planes", _lib.ptr(spect32), B, g["n_cond"], L, w["Lp"], g["halo"], _lib.ptr(w["Sh"]), _lib.ptr(w["Sl"]), st)
+        z = torch.zeros(B, m.n_group, L, dtype=torch.float32, device=dev)
+        z[:, c_off:c_off + n_half] = audio.detach().to(torch.float32)
+        self._wn(k, z, B, L, w, c_off, n_half)
+        wn_out = torch.empty(B, 2 * n_half, L, dtype=torch.float32, device=dev)
+        if self.use_fold:
+            w2 = dict(w)
+            w2["wn_out"] = wn_out
+            self._end(k, z, None, B, L, w2, c_off, n_half, reverse=False)
+        else:
+            self._end(k, z, None, B, L, w, c_off, n_half, reverse=False, wn_out=wn_out)
+        self._keep_wnf = (spect32, z)
+        return wn_out.to(audio.dtype)
+
     def _end(self, k, z, log_s, B, L, w, c_off, n_half, reverse, wn_out=None, skip=None):
         m, g = self.m, self.geom()
         wn = m.WN[k]
@@ -607,6 +676,20 @@ class WaveGlow(torch.nn.Module):
             self.WN.append(WN(n_half, n_mel_channels * n_group, **WN_config))
         self.n_remaining_channels = n_remaining_channels
         self.__dict__["_engine"] = None
+        self._adopt()
+
+    def _adopt(self):
+        """WN[k].forward reaches the engine through a weak reference to its owner (kept out of the module tree)."""
+        import weakref
+        for k, wn_k in enumerate(self.WN):
+            wn_k.__dict__["_owner"] = weakref.ref(self)
+            wn_k.__dict__["_flow"] = k
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        if "_engine" not in self.__dict__:
+            self.__dict__["_engine"] = None
+        self._adopt()
 
     def _eng(self):
         if self.__dict__.get("_engine") is None:

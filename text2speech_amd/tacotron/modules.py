@@ -6,6 +6,28 @@ import torch
 from torch import nn
 
 
+def owner_engine(mod):
+    """The engine of the Tacotron this sub-module belongs to.  The sub-modules are parameter containers; their ``forward`` (kept
+    for callers that use the reference's module surface directly, reference modules.py:19-22,131-137, tacotron.py:192-220,
+    395-466) runs the same kernels as the whole-model paths.  Forward only: training goes through ``Tacotron.forward``."""
+    ref = mod.__dict__.get("_owner")
+    owner = ref() if ref is not None else None
+    if owner is None:
+        raise RuntimeError("%s.forward runs on the engine of the Tacotron it belongs to; build it through Tacotron(...)"
+                           % type(mod).__name__)
+    return owner._eng()
+
+
+class OwnedModule(nn.Module):
+    """nn.Module whose back-reference to its owner (a weak reference in __dict__) stays out of pickles and deep copies; the owner
+    re-establishes it (Tacotron._adopt)."""
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d.pop("_owner", None)
+        return d
+
+
 class LinearNorm(nn.Module):
     def __init__(self, in_dim, out_dim, bias=True, w_init_gain="linear"):
         super().__init__()
@@ -25,14 +47,20 @@ class ConvNorm(nn.Module):
         nn.init.xavier_uniform_(self.conv.weight, gain=nn.init.calculate_gain(w_init_gain))
 
 
-class Prenet(nn.Module):
+class Prenet(OwnedModule):
     def __init__(self, in_dim, sizes):
         super().__init__()
         in_sizes = [in_dim] + sizes[:-1]
         self.layers = nn.ModuleList([LinearNorm(i, o, bias=False) for i, o in zip(in_sizes, sizes)])
 
+    def forward(self, x, masks=None):
+        """Reference modules.py:19-22 (dropout 0.5 with training=True ALWAYS).  masks [items, 1, 2, prenet_dim] of {0,1} injects
+        the draws."""
+        with torch.no_grad():
+            return owner_engine(self).prenet_forward(x, masks)
 
-class Postnet(nn.Module):
+
+class Postnet(OwnedModule):
     """Five 1-d convolutions + BatchNorm (reference modules.py:94-129)."""
 
     def __init__(self, hparams):
@@ -47,6 +75,13 @@ class Postnet(nn.Module):
                 ConvNorm(dims[i], dims[i + 1], kernel_size=ks, stride=1, padding=(ks - 1) // 2, dilation=1,
                          w_init_gain=gain),
                 nn.BatchNorm1d(dims[i + 1])))
+
+    def forward(self, x, train_masks=None):
+        """Reference modules.py:131-137: x [B, n_mel, T] -> the postnet's residual (the caller adds it to x)."""
+        with torch.no_grad():
+            eng = owner_engine(self)
+            eng.prepare(x.device)
+            return eng.postnet(x.detach().to(torch.float32), train_masks, eng.fresh_seed())
 
 
 def get_mask_from_lengths(lengths):

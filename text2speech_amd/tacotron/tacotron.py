@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from .. import _lib
-from .modules import ConvNorm, LinearNorm, Postnet, Prenet, get_mask_from_lengths
+from .modules import ConvNorm, LinearNorm, Postnet, Prenet, get_mask_from_lengths, OwnedModule
 
 BN_EPS = 1e-5
 
@@ -46,7 +46,7 @@ class Attention(nn.Module):
         self.score_mask_value = -float("inf")
 
 
-class Encoder(nn.Module):
+class Encoder(OwnedModule):
     """3 x (Conv1d k5 + BatchNorm1d) + BiLSTM (reference tacotron.py:167-190)."""
 
     def __init__(self, hparams):
@@ -58,8 +58,25 @@ class Encoder(nn.Module):
             for _ in range(hparams["enc_conv_num_layers"])])
         self.lstm = nn.LSTM(C, C // 2, 1, batch_first=True, bidirectional=True)
 
+    def forward(self, x, input_lengths, train_masks=None):
+        """Reference tacotron.py:192-207: embedded inputs x [B, C, T] (batch sorted by decreasing length, as
+        pack_padded_sequence wants) -> [B, max(input_lengths), 2H], zero beyond each length."""
+        from .modules import owner_engine
+        with torch.no_grad():
+            eng = owner_engine(self)
+            eng.prepare(x.device)
+            return eng.encode(None, input_lengths, train_masks, eng.fresh_seed(), embedded=x)[0]
 
-class Decoder(nn.Module):
+    def inference(self, x, train_masks=None):
+        """Reference tacotron.py:209-220: the same without lengths."""
+        from .modules import owner_engine
+        with torch.no_grad():
+            eng = owner_engine(self)
+            eng.prepare(x.device)
+            return eng.encode(None, None, train_masks, eng.fresh_seed(), embedded=x)[0]
+
+
+class Decoder(OwnedModule):
     """Prenet, attention LSTMCell, attention, decoder LSTMCell, projection, gate (reference tacotron.py:223-260)."""
 
     def __init__(self, hparams):
@@ -84,6 +101,24 @@ class Decoder(nn.Module):
         self.linear_projection = LinearNorm(hp["decoder_rnn_dim"] + hp["enc_conv_channels"], n_out)
         self.gate_layer = LinearNorm(hp["decoder_rnn_dim"] + hp["enc_conv_channels"], 1, bias=True,
                                      w_init_gain="sigmoid")
+
+    def forward(self, memory, decoder_inputs, memory_lengths, prenet_masks=None, train_masks=None):
+        """Reference tacotron.py:395-429: teacher-forced decode.  memory [B, T_in, E], decoder_inputs [B, n_mel, T_out] ->
+        (mel_outputs [B, n_mel, T_out], gate_outputs [B, T_out], alignments [B, T_out, T_in])."""
+        from .modules import owner_engine
+        with torch.no_grad():
+            eng = owner_engine(self)
+            dev = memory.device
+            len32 = None if memory_lengths is None else memory_lengths.to(device=dev, dtype=torch.int32).contiguous()
+            mem = memory.detach().to(torch.float32).contiguous()
+            return eng.decode_teacher(mem, len32, decoder_inputs, prenet_masks, None, train_masks)
+
+    def inference(self, memory, prenet_masks=None, train_masks=None):
+        """Reference tacotron.py:431-466: autoregressive decode until the gate fires (or max_decoder_steps).  Returns
+        (mel_outputs [B, n_mel, T], gate_outputs [B, T, 1], alignments [B, T, T_in])."""
+        from .modules import owner_engine
+        with torch.no_grad():
+            return owner_engine(self).decode_free(memory, prenet_masks, None, 64, train_masks)
 
 
 class _DecoderStruct(ctypes.Structure):
@@ -253,21 +288,32 @@ class _TacoEngine:
                   layer["Cout"], layer.get("taps", 1), 1, act, L, Lp, halo, layer["Mpad"], _lib.current_stream())
         return Oh, Ol
 
-    def encode(self, ids, lengths, train_masks=None, seed=0, save=None):
+    def encode(self, ids, lengths, train_masks=None, seed=0, save=None, embedded=None):
         """Embedding + Encoder.forward / .inference (reference tacotron.py:40,192-220).  In training mode the
-        convolutions use batch statistics and dropout(0.5) (masks from ``train_masks['enc']`` or drawn here)."""
+        convolutions use batch statistics and dropout(0.5) (masks from ``train_masks['enc']`` or drawn here).
+        ``embedded`` [B, E, T] f32: start from embedded inputs instead of ids (Encoder.forward's own argument)."""
         m, P = self.m, self.prep
-        dev = ids.device
-        st = _lib.current_stream()
-        B, T = ids.shape
         E = m.embedding.embedding_dim
         halo = 2
-        Lp = _lib.plane_rows(T, halo)
-        ids64 = ids.to(torch.int64).contiguous()
-        Xh = torch.zeros(B, -(-E // 32), Lp, 32, dtype=torch.bfloat16, device=dev)
-        Xl = torch.zeros_like(Xh)
-        _lib.call("t2s_embed_planes", _lib.ptr(ids64), _lib.ptr(P["emb"]), B, T, E, m.embedding.num_embeddings, Lp, halo,
-                  _lib.ptr(Xh), _lib.ptr(Xl), st)
+        st = _lib.current_stream()
+        if embedded is not None:
+            dev = embedded.device
+            B, _, T = embedded.shape
+            Lp = _lib.plane_rows(T, halo)
+            ids64 = None
+            emb32 = embedded.detach().to(torch.float32).contiguous()
+            Xh = torch.zeros(B, -(-E // 32), Lp, 32, dtype=torch.bfloat16, device=dev)
+            Xl = torch.zeros_like(Xh)
+            _lib.call("t2s_f32_to_planes", _lib.ptr(emb32), B, E, T, Lp, halo, _lib.ptr(Xh), _lib.ptr(Xl), st)
+        else:
+            dev = ids.device
+            B, T = ids.shape
+            Lp = _lib.plane_rows(T, halo)
+            ids64 = ids.to(torch.int64).contiguous()
+            Xh = torch.zeros(B, -(-E // 32), Lp, 32, dtype=torch.bfloat16, device=dev)
+            Xl = torch.zeros_like(Xh)
+            _lib.call("t2s_embed_planes", _lib.ptr(ids64), _lib.ptr(P["emb"]), B, T, E, m.embedding.num_embeddings, Lp, halo,
+                      _lib.ptr(Xh), _lib.ptr(Xl), st)
         if m.training:
             given = None if train_masks is None else train_masks.get("enc")
             for i, (seq, layer) in enumerate(zip(m.encoder.convolutions, P["enc_convs_plain"])):
@@ -448,7 +494,22 @@ class _TacoEngine:
         dev = ids.device
         self.prepare(dev)
         memory, _ = self.encode(ids, None, train_masks, seed)
-        B = ids.size(0)
+        mel, gate, align = self.decode_free(memory, prenet_masks, seed, chunk, train_masks)
+        mel_post = mel + self.postnet(mel, train_masks, seed)
+        return [mel, mel_post, gate, align]
+
+    def decode_free(self, memory, prenet_masks=None, seed=None, chunk=64, train_masks=None):
+        """Decoder.inference (reference tacotron.py:431-466): autoregressive decode of encoder outputs ``memory`` [B, T_in, E]
+        until every entry's gate passes the threshold or max_decoder_steps.  Returns (mel [B, n_mel, T], gate [B, T, 1],
+        alignments [B, T, T_in])."""
+        if seed is None:
+            seed = self.fresh_seed()
+        m = self.m
+        dec = m.decoder
+        dev = memory.device
+        self.prepare(dev)
+        memory = memory.detach().to(torch.float32).contiguous()
+        B = memory.size(0)
         T_cap = int(dec.max_decoder_steps)
         n_mel = dec.n_mel_channels * dec.n_frames_per_step
         mk = self._masks(prenet_masks, T_cap, B, dec.prenet_dim, dev, seed)
@@ -482,8 +543,7 @@ class _TacoEngine:
         mel = mel_gate[:, :n_mel, :n_done].contiguous()
         gate = mel_gate[:, n_mel, :n_done].unsqueeze(-1).contiguous()          # [B, T, 1] as the reference returns
         align = S["align_out"][:, :n_done].contiguous()
-        mel_post = mel + self.postnet(mel, train_masks, seed)
-        return [mel, mel_post, gate, align]
+        return mel, gate, align
 
     def forward(self, text, text_lengths, mels, output_lengths, prenet_masks=None, seed=None, train_masks=None, save=None):
         if seed is None:
@@ -493,6 +553,21 @@ class _TacoEngine:
         dev = text.device
         self.prepare(dev)
         memory, len32 = self.encode(text, text_lengths, train_masks, seed, save=save)
+        mel, gate, align = self.decode_teacher(memory, len32, mels, prenet_masks, seed, train_masks, save)
+        B, n_mel, T_out = mels.shape
+        mel_post = mel + self.postnet(mel, train_masks, seed, save=save)
+        return self._finish_forward(mel, mel_post, gate, align, output_lengths, save)
+
+    def decode_teacher(self, memory, len32, mels, prenet_masks=None, seed=None, train_masks=None, save=None):
+        """Decoder.forward (reference tacotron.py:395-429): teacher-forced decode of ``memory`` [B, T_in, E] against the target
+        frames ``mels`` [B, n_mel, T_out] (``len32``: int32 memory lengths on the device, or None).  Returns (mel [B, n_mel, T_out],
+        gate [B, T_out], alignments [B, T_out, T_in])."""
+        if seed is None:
+            seed = self.fresh_seed()
+        m = self.m
+        dec = m.decoder
+        dev = memory.device
+        self.prepare(dev)
         B, n_mel, T_out = mels.shape
         Pd, D, E = dec.prenet_dim, dec.decoder_rnn_dim, memory.size(2)
         P = self.prep
@@ -538,7 +613,15 @@ class _TacoEngine:
         proj = proj.view(T_out, B, n_mel + 1)
         mel = proj[:, :, :n_mel].permute(1, 2, 0).contiguous()
         gate = proj[:, :, n_mel].permute(1, 0).contiguous()
-        mel_post = mel + self.postnet(mel, train_masks, seed, save=save)
+        if save is not None:
+            save.update(S=S, frames=frames, p1=p1, pre_all=pre_all, hc_all=hc_all, prenet_masks=mk, len32=len32, B=B, T_out=T_out,
+                        n_mel=n_mel)
+        return mel, gate, S["align_out"]
+
+    def _finish_forward(self, mel, mel_post, gate, align, output_lengths, save):
+        m = self.m
+        dev = mel.device
+        B, n_mel, T_out = mel.shape
         # Tacotron.parse_output (reference tacotron.py:67-76) here, in one launch.  The reference fills through `.data` AFTER the
         # postnet has run, on the tensor the postnet's first convolution saved for backward: that convolution's weight gradient
         # is taken against the MASKED mel.  Same here: its saved input planes are re-derived from the masked tensor.
@@ -551,10 +634,26 @@ class _TacoEngine:
                 _lib.call("t2s_f32_to_planes", _lib.ptr(mel), B, n_mel, T_out, s0["Lp"], s0["halo"], _lib.ptr(s0["Xh"]),
                           _lib.ptr(s0["Xl"]), _lib.current_stream())
             self._keep_olen = olen32
-        if save is not None:
-            save.update(S=S, frames=frames, p1=p1, pre_all=pre_all, hc_all=hc_all, prenet_masks=mk, len32=len32, B=B, T_out=T_out,
-                        n_mel=n_mel)
-        return [mel, mel_post, gate, S["align_out"]]
+        return [mel, mel_post, gate, align]
+
+    def prenet_forward(self, x, masks=None, seed=None):
+        """Prenet.forward (reference modules.py:19-22): two Linear + ReLU + dropout(0.5), the dropout ALWAYS on.  x [..., n_in]."""
+        if seed is None:
+            seed = self.fresh_seed()
+        P = self.prep
+        dev = x.device
+        self.prepare(dev)
+        P = self.prep
+        Pd = self.m.decoder.prenet_dim
+        n_in = x.shape[-1]
+        x2 = x.detach().to(torch.float32).reshape(-1, n_in).contiguous()
+        items = x2.size(0)
+        mk = self._masks(masks, items, 1, Pd, dev, seed)
+        p1 = torch.empty(items, Pd, dtype=torch.float32, device=dev)
+        out = torch.empty(items, Pd, dtype=torch.float32, device=dev)
+        self._gemv(P["w_pre1"], x2, Pd, items, n_in, p1, act=1, mask=mk, smask=2 * Pd, mask_scale=2.0)
+        self._gemv(P["w_pre2"], p1, Pd, items, Pd, out, act=1, mask=mk.view(-1)[Pd:], smask=2 * Pd, mask_scale=2.0)
+        return out.view(*x.shape[:-1], Pd)
 
 
 class Tacotron(nn.Module):
@@ -575,6 +674,13 @@ class Tacotron(nn.Module):
         self.decoder = Decoder(hparams)
         self.postnet = Postnet(hparams)
         self.__dict__["_engine"] = None
+        self._adopt()
+
+    def _adopt(self):
+        """The sub-modules reach the engine through a weak reference to their owner (kept out of the module tree)."""
+        import weakref
+        for sub in (self.encoder, self.decoder, self.decoder.prenet, self.postnet):
+            sub.__dict__["_owner"] = weakref.ref(self)
 
     def _eng(self):
         if self.__dict__.get("_engine") is None:
@@ -585,6 +691,10 @@ class Tacotron(nn.Module):
         d = self.__dict__.copy()
         d["_engine"] = None
         return d
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._adopt()           # unpickled / deep-copied sub-modules belong to THIS object
 
     def _check(self, t):
         if not t.is_cuda:

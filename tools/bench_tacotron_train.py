@@ -43,6 +43,8 @@ def main():
         return loss
 
     l0 = float(step())
+    for _ in range(2):          # the pooled save / scratch buffers exist in two sets (one is held until the next backward ends)
+        step()
     torch.cuda.synchronize()
     print("[bench] warm-up done, loss %.4f" % l0, file=sys.stderr, flush=True)
     n = 3
