@@ -12,18 +12,24 @@ B="python3 $R/bench.py --no-cpu-baseline --no-tacotron --no-train"
 rocprofv3 --kernel-trace --stats -d "$OUT/fwd" -o fw -- $B --steps 5 --warmup 1 > "$OUT/fwd_under_rocprof.json" 2> "$OUT/fwd.err"
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o f -- $B --steps 2 --warmup 1 > /dev/null 2> "$OUT/pmc_f.err"
 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o w -- $B --steps 2 --warmup 1 > /dev/null 2> "$OUT/pmc_w.err"
-rocprofv3 --kernel-trace --stats -d "$OUT/train" -o wt -- python3 $R/bench.py --mode train --steps 3 --warmup 1 --no-train > "$OUT/train_under_rocprof.json" 2> "$OUT/train.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/train" -o wt -- python3 $R/bench.py --mode train --steps 3 --warmup 1 --no-train --no-cpu-baseline --no-tacotron > "$OUT/train_under_rocprof.json" 2> "$OUT/train.err"
+T2S_WG_BWD_ONE_STREAM=1 rocprofv3 --kernel-trace --stats -d "$OUT/train1" -o w1 -- python3 $R/bench.py --mode train --steps 3 --warmup 1 --no-train --no-cpu-baseline --no-tacotron > /dev/null 2> "$OUT/train1.err"
 rocprofv3 --kernel-trace --stats -d "$OUT/taco_inf" -o ti -- python3 $R/tools/bench_tacotron.py > "$OUT/taco_inf_under_rocprof.json" 2> "$OUT/taco_inf.err"
 rocprofv3 --kernel-trace --stats -d "$OUT/taco_train" -o tt -- python3 $R/tools/bench_tacotron_train.py > "$OUT/taco_train_under_rocprof.json" 2> "$OUT/taco_train.err"
 cd "$R"
 python3 tools/rocpd_stats.py "$OUT/fwd/fw_results.db" 6 16 > "$OUT/fwd_kernels.md"
 python3 tools/rocpd_stats.py "$OUT/train/wt_results.db" 4 16 > "$OUT/train_kernels.md"
+python3 tools/rocpd_by_grid.py "$OUT/train/wt_results.db" 4 24 > "$OUT/train_two_streams_by_grid.md"
+python3 tools/rocpd_by_grid.py "$OUT/train1/w1_results.db" 4 30 > "$OUT/train_one_stream_by_grid.md"
 python3 tools/rocpd_stats.py "$OUT/taco_inf/ti_results.db" 1 14 > "$OUT/taco_inf_kernels.md"
-python3 tools/rocpd_stats.py "$OUT/taco_train/tt_results.db" 4 16 > "$OUT/taco_train_kernels.md"
+python3 tools/rocpd_stats.py "$OUT/taco_train/tt_results.db" 6 20 > "$OUT/taco_train_kernels.md"
 python3 tools/pmc_traffic.py "$OUT/pmc_fetch/f_results.db" "$OUT/pmc_write/w_results.db" > "$OUT/pmc_traffic.json"
+rm -rf "$OUT"/train1
 rm -rf "$OUT"/fwd "$OUT"/train "$OUT"/taco_inf "$OUT"/taco_train "$OUT"/pmc_fetch "$OUT"/pmc_write     # databases are large
 python3 tools/bench_e2e.py > "$OUT/e2e.json" 2> /dev/null
 python3 tools/bench_infer_lengths.py > "$OUT/infer_lengths.json" 2> /dev/null
 python3 tools/microbench/sbgemm_bench.py > "$OUT/sbgemm_bench.json" 2> /dev/null
+python3 tools/prof_ops.py waveglow_train > "$OUT/ops_waveglow_train.txt" 2> /dev/null
+python3 tools/prof_ops.py tacotron_train > "$OUT/ops_tacotron_train.txt" 2> /dev/null
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "wrote $OUT"
