@@ -9,6 +9,8 @@
 #include "t2s_kernels.h"
 #include "taco_bwd_ops.h"
 
+#include <stdlib.h>
+
 static __device__ __forceinline__ float sum3(const float* a, long sa, const float* b, long sb, const float* c, long sc,
                                               int item, int j) {
     float v = 0.f;
@@ -330,6 +332,196 @@ __global__ __launch_bounds__(512) void att_bwd_energy_kernel(const AttBwdArgs a)
     }
 }
 
+// The same stage with its four small matrix products on the exact-f32 matrix cores (v_mfma_f32_16x16x4_f32: f32 operands,
+// f32 accumulate), for the reference's shape (attention_dim 128, 32 location filters, kernel <= 31).  The VALU kernel above is
+// LDS-bound: ~1200 ds_read_b32 per thread (two per MAC of the location convolution, the energies, dD^T and d_f) - 10 of its
+// 22 us at 128 B/clk (profiles/r03_taco_step_kernel_counters_before.json).  Per 32-position chunk the products are
+//   F[t][f]     = sum_k cat-window[t][k] K[k][f]          [32 x 64] x [64 x 32]     (location features, recomputed)
+//   P[t][a]     = sum_f F[t][f] D^T[f][a]                 [32 x 32] x [32 x 128]    -> tanh, d_pre in the epilogue
+//   dD^T[f][a] += sum_t F[t][f] d_pre[t][a]               [32 x 32] x [32 x 128]
+//   d_f[t][f]   = sum_a d_pre[t][a] D[a][f]               [32 x 128] x [128 x 32]
+// 448 MFMAs per workgroup instead of ~0.6 M LDS-fed FMAs; every fragment read is a conflict-free ds_read_b32 (row strides 33
+// for operands read down a column, 144 for operands read along a row; d_pre is kept in both).  A wave owns 16 attention
+// channels over all 32 positions of the chunk, so d_q / dv need no cross-wave reduction.
+// LDS, 58.9 KB (two workgroups per CU): the convolution kernel's space is reused for d_pre[a][t], D^T's for D.
+#define ATTB_LDS_FLOATS (2 * (ATTB_CH + 64) + 128 * 33 + ATTB_CH * 33 + 32 * 144 + ATTB_CH * 144 + ATTB_CH + 8)
+__global__ __launch_bounds__(512) void att_bwd_energy_mfma_kernel(const AttBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_all[ATTB_LDS_FLOATS];
+    constexpr int AD = 128, F = 32;
+    float* s_cat = s_all;                          // [2][ATTB_CH + 64]
+    float* s_kb = s_cat + 2 * (ATTB_CH + 64);      // [64][48]   conv kernel as B operand [k = c * KS + j][f], rows >= 2 KS zero
+    float* s_dpT = s_kb;                           // [128][33]  d_pre[a][t]   (after stage 1)
+    float* s_f = s_kb + 128 * 33;                  // [32][33]   F[t][f]
+    float* s_dT = s_f + ATTB_CH * 33;              // [32][144]  D^T[f][a]
+    float* s_dn = s_dT;                            // [128][33]  D[a][f]       (after stage 2)
+    float* s_dp = s_dT + 32 * 144;                 // [32][144]  d_pre[t][a]
+    float* s_de = s_dp + ATTB_CH * 144;            // [32]
+    float* s_red = s_de + ATTB_CH;                 // [8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * ATTB_CH;
+    const int T = a.T, KS = a.loc_ks, pad = KS >> 1, K2 = 2 * KS;
+    const int len = a.lengths ? a.lengths[b] : T;
+    const size_t slot = (size_t)b * gridDim.x + chunk;
+    // ---- loads ----
+    for (int i = tid; i < 64 * 48; i += 512) s_kb[i] = 0.f;
+    for (int i = tid; i < 2 * (ATTB_CH + KS - 1); i += 512) {
+        const int c = i / (ATTB_CH + KS - 1), j = i - c * (ATTB_CH + KS - 1);
+        const int t = t0 + j - pad;
+        const float* src = c ? a.wc_prev : a.w_prev;
+        s_cat[c * (ATTB_CH + 64) + j] = (src && t >= 0 && t < T) ? src[(size_t)b * (c ? a.s_wcprev : a.s_wprev) + t] : 0.f;
+    }
+    float rk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + j * 512;
+        rk[j] = i < F * K2 ? a.w_loc_conv[i] : 0.f;
+    }
+    float rd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                  // D [a][f], 4096 floats, coalesced
+        const int i = tid + j * 512;
+        rd[j] = a.w_loc_dense[i];
+        s_dT[(i & 31) * 144 + (i >> 5)] = rd[j];
+    }
+    // stage-2 / stage-3 ownership of this wave: attention channels 16 wave .. 16 wave + 15 (tile column `wave`)
+    const int ach = 16 * wave + lr;
+    const float qv = a.q[(size_t)b * AD + ach], vv = a.w_v[ach];
+    float pm[2][4], dpm[2][4], dD_old[2][4];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = t0 + 16 * tt + 4 * lq + r;
+            const size_t po = ((size_t)b * T + (t < T ? t : 0)) * AD + ach;
+            pm[tt][r] = a.pmem[po];
+            dpm[tt][r] = a.d_pmem[po];
+            dD_old[tt][r] = a.dD_part[slot * AD * F + (size_t)(16 * tt + 4 * lq + r) * AD + ach];      // (here tt = f tile)
+        }
+    const float dv_old = a.dv_part[slot * AD + ach];
+    // softmax backward needs sum_t w[t] d_w[t] over the whole row
+    float part = 0.f;
+    for (int t = tid; t < T; t += 512) part += a.w_cur[(size_t)b * a.s_wcur + t] * a.dw_buf[(size_t)b * T + t];
+    part = attb_wave_sum(part);
+    if (lane == 0) s_red[wave] = part;
+    __syncthreads();                               // s_kb zeroed, s_red complete
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + j * 512;
+        if (i < F * K2) {
+            const int f = i / K2, k = i - f * K2;  // K[f][c][j] -> B operand [k = c * KS + j][f]
+            s_kb[k * 48 + f] = rk[j];
+        }
+    }
+    const float sdot = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
+    if (tid < ATTB_CH) {
+        const int t = t0 + tid;
+        s_de[tid] = (t < T && t < len) ? a.w_cur[(size_t)b * a.s_wcur + t] * (a.dw_buf[(size_t)b * T + t] - sdot) : 0.f;
+    }
+    __syncthreads();
+    // ---- stage 1: location features, 4 tiles (t tile, f tile) on waves 0-3 ----
+    if (wave < 4) {
+        const int tt = wave >> 1, ft = wave & 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = 4 * u + lq;
+            const int kc = k < K2 ? k : 0;         // (B rows >= 2 KS are zero)
+            const int c = kc >= KS ? 1 : 0, j = kc - c * KS;
+            av[u] = s_cat[c * (ATTB_CH + 64) + 16 * tt + lr + j];
+            bv[u] = s_kb[k * 48 + 16 * ft + lr];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_f[(16 * tt + 4 * lq + r) * 33 + 16 * ft + lr] = acc[r];
+    }
+    __syncthreads();
+    // ---- stage 2: P = F D^T, energies backward in the epilogue; this wave: channels `ach`, both position tiles ----
+    float dq = 0.f, dvs = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            av[u] = s_f[(16 * tt + lr) * 33 + 4 * u + lq];
+            bv[u] = s_dT[(4 * u + lq) * 144 + ach];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tq = 16 * tt + 4 * lq + r, t = t0 + tq;
+            float dp = 0.f;
+            if (t < T) {
+                const float th = tanhf(acc[r] + qv + pm[tt][r]);
+                const float de = s_de[tq];
+                dp = de * vv * (1.f - th * th);
+                dq += dp;
+                dvs += de * th;
+                a.d_pmem[((size_t)b * T + t) * AD + ach] = dpm[tt][r] + dp;
+            }
+            s_dp[tq * 144 + ach] = dp;
+            s_dpT[ach * 33 + tq] = dp;
+        }
+    }
+    dq += __shfl_xor(dq, 16, 64);
+    dq += __shfl_xor(dq, 32, 64);
+    dvs += __shfl_xor(dvs, 16, 64);
+    dvs += __shfl_xor(dvs, 32, 64);
+    if (lq == 0) {
+        a.dq_part[slot * AD + ach] = dq;
+        a.dv_part[slot * AD + ach] = dv_old + dvs;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = tid + j * 512;
+        s_dn[(i >> 5) * 33 + (i & 31)] = rd[j];
+    }
+    // ---- stage 3: dD^T[f][a] += F^T d_pre; this wave: channels `ach`, both filter tiles ----
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            av[u] = s_f[(4 * u + lq) * 33 + 16 * ft + lr];          // A[row f][k = t] = F[t][f]
+            bv[u] = s_dp[(4 * u + lq) * 144 + ach];                // B[k = t][col a]
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            a.dD_part[slot * AD * F + (size_t)(16 * ft + 4 * lq + r) * AD + ach] = dD_old[ft][r] + acc[r];
+    }
+    __syncthreads();
+    // ---- stage 4: d_f[t][f] = d_pre D, 4 tiles (t tile, f tile) on waves 0-3, K = 128 ----
+    if (wave < 4) {
+        const int tt = wave >> 1, ft = wave & 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float av[16], bv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = 64 * h + 4 * u + lq;
+                av[u] = s_dpT[k * 33 + 16 * tt + lr];               // A[row t][k = a] = d_pre[t][a]
+                bv[u] = s_dn[k * 33 + 16 * ft + lr];                // B[k = a][col f] = D[a][f]
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = t0 + 16 * tt + 4 * lq + r;
+            if (t < T) a.df_buf[((size_t)b * T + t) * 32 + 16 * ft + lr] = acc[r];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void att_bwd_conv_kernel(const AttBwdArgs a) {
     __shared__ float s_cat[2][ATTB_CH + 64];
     __shared__ float s_k[32 * 2 * 63];
@@ -383,6 +575,110 @@ __global__ __launch_bounds__(256) void att_bwd_conv_kernel(const AttBwdArgs a) {
     }
 }
 
+// The same stage on the exact-f32 matrix cores, for 32 location filters and kernel <= 31.  Both sums are small matrix products
+// once the shift is taken out of the carries (profiles/r03_taco_step_kernel_counters_before.json: the VALU kernel spends a
+// third of its LDS cycles in bank conflicts and 22 us per decoder step):
+//   G[m = (c, j)][row] = sum_f K[f][c][j] d_f[row][f]            [64 x 32] x [32 x 64]; then d cat[c][tp] = sum_j G[(c, j)][tp - j + 2 pad]
+//   dK[f][m = (c, j)] += sum_tl d_f[tl + pad][f] cat[c][tl + j]  [32 x 32] x [32 x 64]  (B read straight from the window: Toeplitz)
+__global__ __launch_bounds__(256) void att_bwd_conv_mfma_kernel(const AttBwdArgs a) {
+    constexpr int F = 32, SK = 80, SD = 34, SG = 66;
+    __shared__ float s_cat[2][ATTB_CH + 64];
+    __shared__ float s_k[F * SK];                 // K[f][m], columns >= 2 KS zero
+    __shared__ float s_df[64 * SD];               // d_f[row][f], row <-> t0 - pad + row; rows past the window zero
+    __shared__ float s_g[64 * SG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * ATTB_CH, nchunk = gridDim.x;
+    const int T = a.T, AD = a.att_dim, KS = a.loc_ks, pad = KS >> 1, K2 = 2 * KS;
+    const size_t slot = (size_t)b * nchunk + chunk;
+    for (int i = tid; i < F * SK; i += 256) {
+        const int f = i / SK, m = i - f * SK;
+        s_k[i] = m < K2 ? a.w_loc_conv[f * K2 + m] : 0.f;
+    }
+    for (int i = tid; i < 2 * (ATTB_CH + KS - 1); i += 256) {
+        const int c = i / (ATTB_CH + KS - 1), j = i - c * (ATTB_CH + KS - 1);
+        const int t = t0 + j - pad;
+        const float* src = c ? a.wc_prev : a.w_prev;
+        s_cat[c][j] = (src && t >= 0 && t < T) ? src[(size_t)b * (c ? a.s_wcprev : a.s_wprev) + t] : 0.f;
+    }
+    for (int i = tid; i < 64 * 32; i += 256) {
+        const int j = i >> 5, f = i & 31;
+        const int t = t0 + j - pad;
+        s_df[j * SD + f] = (j < ATTB_CH + KS - 1 && t >= 0 && t < T) ? a.df_buf[((size_t)b * T + t) * 32 + f] : 0.f;
+    }
+    // this wave's columns m = 16 wave + lr of the kernel gradient, fetched early (read-modify-write at the end)
+    const int mcol = 16 * wave + lr;
+    float dK_old[2][4];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            dK_old[ft][r] = mcol < K2 ? a.dK_part[slot * F * K2 + (size_t)(16 * ft + 4 * lq + r) * K2 + mcol] : 0.f;
+    __syncthreads();
+    // ---- G: this wave owns rows m = 16 wave .. 16 wave + 15, all four row tiles of d_f ----
+    {
+        float av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) av[u] = s_k[(4 * u + lq) * SK + 16 * wave + lr];       // A[row m][k = f]
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            float bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bv[u] = s_df[(16 * nt + lr) * SD + 4 * u + lq];    // B[k = f][col row]
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_g[(16 * wave + 4 * lq + r) * SG + 16 * nt + lr] = acc[r];
+        }
+    }
+    // ---- kernel gradient partial: this wave owns columns m = 16 wave + lr, both filter tiles ----
+    {
+        const int mc = mcol < K2 ? mcol : 0;
+        const int c = mc >= KS ? 1 : 0, j = mc - c * KS;
+        float bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bv[u] = s_cat[c][4 * u + lq + j];                       // B[k = tl][col m] = cat[c][tl + j]
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft) {
+            float av[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = s_df[(4 * u + lq + pad) * SD + 16 * ft + lr];   // A[row f][k = tl] = d_f[tl + pad][f]
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+            if (mcol < K2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    a.dK_part[slot * F * K2 + (size_t)(16 * ft + 4 * lq + r) * K2 + mcol] = dK_old[ft][r] + acc[r];
+        }
+    }
+    __syncthreads();
+    // ---- carries: 64 outputs x 4 threads (8 taps each) ----
+    {
+        const int o = tid >> 2, jg = tid & 3;
+        const int c = o >> 5, tl = o & 31;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = jg * 8 + i;
+            if (j < KS) acc += s_g[(c * KS + j) * SG + tl - j + 2 * pad];
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        const int tp = t0 + tl;
+        if (jg == 0 && tp < T) {
+            if (c == 0) a.dw_carry[(size_t)b * T + tp] = acc;
+            else a.dwc_carry[(size_t)b * T + tp] += acc;
+        }
+    }
+    if (chunk == 0 && tid < AD) {
+        float sum = 0.f;
+        for (int ch = 0; ch < nchunk; ++ch) sum += a.dq_part[((size_t)b * nchunk + ch) * AD + tid];
+        a.d_q[(size_t)b * AD + tid] = sum;
+    }
+}
+
 static bool att_bwd_ok(const AttBwdArgs& a) {
     return !(a.enc_dim > 1024 || (a.enc_dim & 3) || a.att_dim > 128 || a.loc_f > 32 || a.loc_ks > 63 || !(a.loc_ks & 1) ||
              !a.dw_buf || !a.df_buf || !a.dq_part);
@@ -391,13 +687,23 @@ hipError_t t2s_launch_att_bwd_front(const AttBwdArgs& a, hipStream_t stream) {
     if (!att_bwd_ok(a)) return hipErrorInvalidValue;
     const dim3 grid((a.T + ATTB_CH - 1) / ATTB_CH, a.B);
     hipLaunchKernelGGL(att_bwd_dw_kernel, grid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(att_bwd_energy_kernel, grid, dim3(512), 0, stream, a);
+    // matrix-core form for the reference's shape (T2S_ATTB_VALU bit 0 / bit 1: the VALU energies / convolution kernel, for A/B runs)
+    static const int valu = getenv("T2S_ATTB_VALU") ? atoi(getenv("T2S_ATTB_VALU")) : 0;
+    if (!(valu & 1) && a.att_dim == 128 && a.loc_f == 32 && a.loc_ks <= 31) {
+        hipLaunchKernelGGL(att_bwd_energy_mfma_kernel, grid, dim3(512), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(att_bwd_energy_kernel, grid, dim3(512), 0, stream, a);
+    }
     return hipGetLastError();
 }
 hipError_t t2s_launch_att_bwd_conv(const AttBwdArgs& a, hipStream_t stream) {
     if (!att_bwd_ok(a)) return hipErrorInvalidValue;
     const dim3 grid((a.T + ATTB_CH - 1) / ATTB_CH, a.B);
-    hipLaunchKernelGGL(att_bwd_conv_kernel, grid, dim3(256), 0, stream, a);
+    static const int valu = getenv("T2S_ATTB_VALU") ? atoi(getenv("T2S_ATTB_VALU")) : 0;
+    if (!(valu & 2) && a.loc_f == 32 && a.loc_ks <= 31)
+        hipLaunchKernelGGL(att_bwd_conv_mfma_kernel, grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(att_bwd_conv_kernel, grid, dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 hipError_t t2s_launch_att_bwd(const AttBwdArgs& a, hipStream_t stream) {

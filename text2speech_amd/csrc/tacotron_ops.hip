@@ -466,7 +466,113 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_kernel(const AttArgs a) {
     }
 }
 
+// The energies on the exact-f32 matrix cores (v_mfma_f32_16x16x4_f32), for the reference's shape (attention_dim 128, 32 location
+// filters, kernel <= 31) with the transposed dense weight at hand.  One workgroup = 32 positions of one batch element:
+//   F[t][f] = sum_k window[t][k] K[k][f]     [32 x 64] x [64 x 32]   (4 tiles on waves 0-3)
+//   P[t][a] = sum_f F[t][f] D^T[f][a]        [32 x 32] x [32 x 128]  (wave w: channels 16 w .. 16 w + 15; B fragments straight from
+//                                                                     global memory, coalesced over the channel)
+// then e[t] = sum_a v[a] tanh(P + q + pm) by a 16-lane butterfly and an 8-wave sum through LDS.  The VALU kernel above spends its
+// time on two LDS reads per MAC of the convolution (profiles/r03_taco_step_kernel_counters_before.json).
+#define ATT_MQ 32
+__global__ __launch_bounds__(512) void att_energy_mfma_kernel(const AttArgs a) {
+    constexpr int AD = 128;
+    __shared__ float s_cat[2][ATT_MQ + 64];
+    __shared__ float s_kb[64 * 48];            // conv kernel as B operand [k = c * KS + j][f], rows >= 2 KS zero
+    __shared__ float s_f[ATT_MQ * 33];
+    __shared__ float s_e[8][ATT_MQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.y, t0 = blockIdx.x * ATT_MQ;
+    const int T = a.T, KS = a.loc_ks, pad = KS >> 1, K2 = 2 * KS;
+    for (int i = tid; i < 64 * 48; i += 512) s_kb[i] = 0.f;
+    for (int i = tid; i < 2 * (ATT_MQ + KS - 1); i += 512) {
+        const int c = i / (ATT_MQ + KS - 1), j = i - c * (ATT_MQ + KS - 1);
+        const int t = t0 + j - pad;
+        const float* src = c ? a.w_cum : a.w_prev;
+        s_cat[c][j] = (t >= 0 && t < T) ? src[(size_t)b * T + t] : 0.f;
+    }
+    float rk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + j * 512;
+        rk[j] = i < 32 * K2 ? a.w_loc_conv[i] : 0.f;
+    }
+    const int ach = 16 * wave + lr;
+    float bd[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) bd[u] = a.w_loc_denseT[(4 * u + lq) * AD + ach];      // B[k = f][col a] = D[a][f]
+    const float qv = a.q[(size_t)b * AD + ach], vv = a.w_v[ach];
+    float pm[2][4];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = t0 + 16 * tt + 4 * lq + r;
+            pm[tt][r] = t < T ? a.pmem[((size_t)b * T + t) * AD + ach] : 0.f;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + j * 512;
+        if (i < 32 * K2) {
+            const int f = i / K2, k = i - f * K2;
+            s_kb[k * 48 + f] = rk[j];
+        }
+    }
+    __syncthreads();
+    if (wave < 4) {
+        const int tt = wave >> 1, ft = wave & 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = 4 * u + lq;
+            const int kc = k < K2 ? k : 0;     // (B rows >= 2 KS are zero)
+            const int c = kc >= KS ? 1 : 0, j = kc - c * KS;
+            av[u] = s_cat[c][16 * tt + lr + j];
+            bv[u] = s_kb[k * 48 + 16 * ft + lr];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_f[(16 * tt + 4 * lq + r) * 33 + 16 * ft + lr] = acc[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) av[u] = s_f[(16 * tt + lr) * 33 + 4 * u + lq];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bd[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float e = vv * tanhf(acc[r] + qv + pm[tt][r]);
+            e += __shfl_xor(e, 1, 64);
+            e += __shfl_xor(e, 2, 64);
+            e += __shfl_xor(e, 4, 64);
+            e += __shfl_xor(e, 8, 64);
+            if (lr == 0) s_e[wave][16 * tt + 4 * lq + r] = e;
+        }
+    }
+    __syncthreads();
+    if (tid < ATT_MQ) {
+        const int t = t0 + tid;
+        const int len = a.lengths ? a.lengths[b] : T;
+        const float e = ((s_e[0][tid] + s_e[1][tid]) + (s_e[2][tid] + s_e[3][tid])) + ((s_e[4][tid] + s_e[5][tid]) + (s_e[6][tid] + s_e[7][tid]));
+        if (t < T) a.energies[(size_t)b * T + t] = t < len ? e : -INFINITY;
+    }
+}
+
 hipError_t t2s_launch_att_energy(const AttArgs& a, hipStream_t stream) {
+    // T2S_ATT_VALU set: the VALU kernel (A/B switch, shared with the fused small-batch form)
+    static const bool no_mfma = getenv("T2S_ATT_VALU") != nullptr;
+    if (!no_mfma && a.att_dim == 128 && a.loc_f == 32 && a.loc_ks <= 31 && a.w_loc_denseT) {
+        dim3 grid((a.T + ATT_MQ - 1) / ATT_MQ, a.B);
+        hipLaunchKernelGGL(att_energy_mfma_kernel, grid, dim3(512), 0, stream, a);
+        return hipGetLastError();
+    }
     dim3 grid((a.T + ATT_TQ - 1) / ATT_TQ, a.B);
     hipLaunchKernelGGL(att_energy_kernel, grid, dim3(256), (size_t)a.loc_f * 2 * a.loc_ks * sizeof(float), stream, a);
     return hipGetLastError();
