@@ -131,6 +131,20 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
             !d->mel_gate_out || !d->prenet_masks)
             return T2S_EINVAL;
     }
+    // Teacher-forced decoding with the per-step saves at hand (training): the decoder cell of step s feeds only the decoder
+    // cell of step s + 1 and the projection after the loop - never the attention chain (attention cell -> query -> energies ->
+    // softmax + context), whose next prenet input is given.  So it runs on the library's helper stream from the saved copies
+    // of h_att[s] and ctx[s] (att_h_all, hc_all) and drops out of the serial chain.  T2S_DECODE_ONE_STREAM=1: off.
+    static const bool one_stream = getenv("T2S_DECODE_ONE_STREAM") != nullptr;
+    const bool split = d->teacher_forced && d->att_h_all && d->hc_all && !one_stream;
+    T2sHelperStream hs;
+    if (split) T2S_CHECK_HIP(t2s_helper_stream_acquire(hs));
+    struct Join {           // whatever happens below, the caller's stream waits for the helper before this call returns
+        T2sHelperStream& hs; hipStream_t stream; bool on;
+        ~Join() {
+            if (on && hipEventRecord(hs.ev_join, hs.side) == hipSuccess) (void)hipStreamWaitEvent(stream, hs.ev_join, 0);
+        }
+    } join{hs, stream, split};
     for (int s = step0; s < step0 + n_steps; ++s) {
         float* ah_in = (s & 1) ? d->att_h1 : d->att_h0;
         float* ah_out = (s & 1) ? d->att_h0 : d->att_h1;
@@ -188,11 +202,19 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         memset(&cd, 0, sizeof(cd));
         cd.W_ih = d->dec_w_ih; cd.W_hh = d->dec_w_hh; cd.b_ih = d->dec_b_ih; cd.b_hh = d->dec_b_hh;
         cd.x1 = ah_out; cd.n1 = A; cd.sx1 = A; cd.x2 = d->ctx; cd.n2 = E; cd.sx2 = E;
+        hipStream_t dstream = stream;
+        if (split) {
+            cd.x1 = d->att_h_all + (size_t)s * B * A;
+            cd.x2 = d->hc_all + (size_t)s * B * (D + E) + D; cd.sx2 = D + E;
+            T2S_CHECK_HIP(hipEventRecord(hs.ev_step, stream));        // h_att[s], ctx[s] saved (and all earlier work of the caller)
+            T2S_CHECK_HIP(hipStreamWaitEvent(hs.side, hs.ev_step, 0));
+            dstream = hs.side;
+        }
         cd.h_in = dh_in; cd.h_out = dh_out; cd.c = d->dec_c; cd.B = B; cd.H = D;
         if (d->dec_drop) { cd.drop_mask = d->dec_drop + (size_t)s * B * D; cd.drop_scale = d->dec_drop_scale; }
         if (d->teacher_forced) { cd.h_copy = d->hc_all + (size_t)s * B * (D + E); cd.s_copy = D + E; }
         if (d->dec_gates_all) { cd.gates_out = d->dec_gates_all + (size_t)s * B * 4 * D; cd.c_out = d->dec_c_all + (size_t)s * B * D; }
-        T2S_CHECK_HIP(t2s_launch_lstm_cell(cd, stream));
+        T2S_CHECK_HIP(t2s_launch_lstm_cell(cd, dstream));
         if (!d->teacher_forced) {
             // 6./7. mel frame + gate logit = W_proj [h_dec | ctx] + b, and (same launch, second row block) layer 0
             //       of the next step's prenet through the precomposed matrix W_pre0 . W_proj (always-on dropout,

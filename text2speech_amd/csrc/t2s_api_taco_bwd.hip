@@ -42,6 +42,20 @@ hipError_t bptt_streams_init(BpttStreams& s) {      // caller holds s.mu; the cu
 }
 }  // namespace
 
+// The forward decoder loop in teacher-forced mode borrows the first helper stream (t2s_api_taco.hip): the lock is held while
+// the call enqueues, as in the BPTT driver.
+hipError_t t2s_helper_stream_acquire(T2sHelperStream& h) {
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    BpttStreams& S = g_bptt[device];
+    h.lock = std::unique_lock<std::mutex>(S.mu);
+    if ((e = bptt_streams_init(S)) != hipSuccess) return e;
+    h.side = S.side; h.ev_step = S.ev_main; h.ev_join = S.ev_join;
+    return hipSuccess;
+}
+
 extern "C" {
 
 int t2s_rows_to_tm(const float* x, long ld, int items, int items_pad, int shift, int C, void* dst_hi, void* dst_lo,

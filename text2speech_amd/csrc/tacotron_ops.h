@@ -3,6 +3,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
+// Library-owned helper stream (one set per device, t2s_api_taco_bwd.hip): `lock` is held while a call enqueues on it.
+struct T2sHelperStream {
+    std::unique_lock<std::mutex> lock;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_step = nullptr, ev_join = nullptr;
+};
+hipError_t t2s_helper_stream_acquire(T2sHelperStream& h);
+
 struct GemvArgs {
     const float* W1; int ld1; int k1;     // weight row = [W1[row][:k1] | W2[row][:k2]]
     const float* W2; int ld2; int k2;
