@@ -457,6 +457,10 @@ typedef struct t2s_att_bwd {
     float *dctx_out;                      /* optional [B][enc]: d_ctx of this step; with it d_memory may be NULL and the caller
                                            * forms d_memory = sum_t w_t (x) d_ctx_t once after the loop */
     int B, T, att_dim, enc_dim, loc_f, loc_ks;
+    /* used by t2s_taco_bptt_steps' one-launch form only (leave 0 here): the step's saved context [B][.] (row stride s_ctx) and
+     * the carry buffers the step WRITES (it reads dw_carry / dwc_carry) */
+    const float *ctx; long s_ctx;
+    float *dw_carry_out, *dwc_carry_out;
 } t2s_att_bwd;
 /* one decoder step of the location-sensitive attention, backward (tacotron.py:124-166,379) */
 int t2s_taco_att_bwd(const t2s_att_bwd* a, void* stream);
@@ -481,6 +485,12 @@ typedef struct t2s_taco_bptt {
     float *dD_part, *dK_part, *dv_part, *dw_buf, *df_buf, *dq_part;   /* as in t2s_att_bwd */
     float *dctx_all;                                    /* optional [T_out][B][enc]: every step's d_ctx; then d_memory is not
                                                          * touched by the loop (deferred, see t2s_att_bwd.dctx_out) */
+    /* optional, all or none (needs dctx_all, attention_dim 128, 32 location filters, kernel <= 31): the attention backward of a
+     * step in ONE launch.  ctx_all = the forward's contexts, step t / item b at ctx_all + t * s_ctx_step + b * s_ctx_item;
+     * dw_c2 / dwc_c2 = a second pair of carry buffers [B][T_in], zero-initialised like dw_c / dwc_c (step t reads the pair of
+     * parity t & 1 - dw_c for even t - and writes the other). */
+    const float *ctx_all; long s_ctx_step, s_ctx_item;
+    float *dw_c2, *dwc_c2;
 } t2s_taco_bptt;
 /* Launch sequencing only.  Unless T2S_BPTT_ONE_STREAM is set, the decoder-cell chain and the location-conv part of the
  * attention backward run on two library-owned non-blocking streams (created on first use on the current device, kept for the

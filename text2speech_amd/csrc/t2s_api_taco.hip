@@ -134,9 +134,12 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
     // Teacher-forced decoding with the per-step saves at hand (training): the decoder cell of step s feeds only the decoder
     // cell of step s + 1 and the projection after the loop - never the attention chain (attention cell -> query -> energies ->
     // softmax + context), whose next prenet input is given.  So it runs on the library's helper stream from the saved copies
-    // of h_att[s] and ctx[s] (att_h_all, hc_all) and drops out of the serial chain.  T2S_DECODE_ONE_STREAM=1: off.
-    static const bool one_stream = getenv("T2S_DECODE_ONE_STREAM") != nullptr;
-    const bool split = d->teacher_forced && d->att_h_all && d->hc_all && !one_stream;
+    // of h_att[s] and ctx[s] (att_h_all, hc_all) and drops out of the serial chain.  OFF unless T2S_DECODE_SPLIT=1: measured
+    // 128.0 vs 128.2 ms per train step (profiles/r03_taco_timeline_fwd.md) - the event record on the critical stream opens a 7 us
+    // gap before the next attention cell, and the 8-workgroup query GEMM waits for a CU behind the decoder cell's 256 workgroups
+    // (both hold 96 KB of LDS: 7.3 -> 19 us), which together eat the 11.5 us the decoder cell no longer takes.
+    static const bool want_split = getenv("T2S_DECODE_SPLIT") && atoi(getenv("T2S_DECODE_SPLIT"));
+    const bool split = d->teacher_forced && d->att_h_all && d->hc_all && want_split;
     T2sHelperStream hs;
     if (split) T2S_CHECK_HIP(t2s_helper_stream_acquire(hs));
     struct Join {           // whatever happens below, the caller's stream waits for the helper before this call returns

@@ -4,6 +4,7 @@
 #include "taco_bwd_ops.h"
 #include "tacotron_ops.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -76,7 +77,7 @@ int t2s_lstm_cell_bwd(const float* dh1, long s1, const float* dh2, long s2, cons
     a.dh1 = dh1; a.s1 = s1; a.dh2 = dh2; a.s2 = s2; a.dh3 = dh3; a.s3 = s3;
     a.drop_mask = drop_mask; a.drop_scale = drop_scale; a.gates = gates; a.c_new = c_new; a.c_prev = c_prev;
     a.dc_carry = dc_carry; a.dgates = dgates; a.B = B; a.H = H;
-    a.wq = nullptr; a.dq = nullptr; a.q_dim = 0; a.dq_part = nullptr; a.dq_nchunk = 0;
+    a.wq = nullptr; a.dq = nullptr; a.q_dim = 0; a.dq_part = nullptr; a.dq_nchunk = 0; a.dq_out = nullptr;
     T2S_CHECK_HIP(t2s_launch_lstm_cell_bwd(a, (hipStream_t)stream));
     return T2S_OK;
 }
@@ -95,7 +96,7 @@ int t2s_taco_att_bwd(const t2s_att_bwd* p, void* stream) {
     static_assert(sizeof(t2s_att_bwd) == sizeof(AttBwdArgs), "t2s_att_bwd layout");
     AttBwdArgs a;
     memcpy(&a, p, sizeof(a));
-    T2S_CHECK_HIP(t2s_launch_att_bwd(a, (hipStream_t)stream));
+    T2S_CHECK_HIP(t2s_launch_att_bwd(a, (hipStream_t)stream));      // (the one-launch form is the BPTT driver's: it leaves d_q as partials)
     return T2S_OK;
 }
 
@@ -122,6 +123,10 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
     // A third stream takes the last part of the attention backward (location-conv backward): it only feeds the NEXT step's
     // carries and the kernel gradient, so it runs beside this step's attention-cell backward and GEMM.
     static const bool two_streams = !getenv("T2S_BPTT_ONE_STREAM");
+    // The location-conv backward stays on the caller's stream: with the matrix-core kernels it takes 10 us, while the event
+    // record on the critical stream and the wait for a third stream cost ~7 + ~5 us per step on this runtime
+    // (profiles/r03_taco_timeline_bwd.md; 128.7 -> 122.4 ms per train step).  T2S_BPTT_CONV_MAIN=0: the round-2 three-stream form.
+    static const bool conv_main = !getenv("T2S_BPTT_CONV_MAIN") || atoi(getenv("T2S_BPTT_CONV_MAIN"));
     int device = 0;
     T2S_CHECK_HIP(hipGetDevice(&device));
     if (device < 0 || device >= kMaxDevices) return T2S_EINVAL;
@@ -158,7 +163,7 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         cd.gates = p->dec_gates_all + (size_t)t * B * 4 * D; cd.c_new = p->dec_c_all + (size_t)t * B * D;
         cd.c_prev = t > 0 ? p->dec_c_all + (size_t)(t - 1) * B * D : nullptr;
         cd.dc_carry = p->dc_d; cd.dgates = p->dg_d + (size_t)t * B * 4 * D; cd.B = B; cd.H = D;
-        cd.wq = nullptr; cd.dq = nullptr; cd.q_dim = 0; cd.dq_part = nullptr; cd.dq_nchunk = 0;
+        cd.wq = nullptr; cd.dq = nullptr; cd.q_dim = 0; cd.dq_part = nullptr; cd.dq_nchunk = 0; cd.dq_out = nullptr;
         T2S_CHECK_HIP(t2s_launch_lstm_cell_bwd(cd, dstream));
         GemvArgs g;
         memset(&g, 0, sizeof(g));
@@ -185,7 +190,22 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         ab.dw_buf = p->dw_buf; ab.df_buf = p->df_buf; ab.dq_part = p->dq_part;
         if (p->dctx_all) { ab.dctx_out = p->dctx_all + (size_t)t * B * E; ab.d_memory = nullptr; }
         ab.B = B; ab.T = Tin; ab.att_dim = ad; ab.enc_dim = E; ab.loc_f = p->loc_filters; ab.loc_ks = p->loc_kernel;
-        if (two_streams) {
+        bool fused = false;
+        if (p->ctx_all && p->dw_c2 && p->dwc_c2 && (!two_streams || conv_main)) {
+            // one launch: reads the carries of parity t, writes those of parity t - 1; d_q stays in per-chunk partials
+            ab.ctx = p->ctx_all + (size_t)t * p->s_ctx_step; ab.s_ctx = p->s_ctx_item;
+            if (t & 1) { ab.dw_carry = p->dw_c2; ab.dwc_carry = p->dwc_c2; ab.dw_carry_out = p->dw_c; ab.dwc_carry_out = p->dwc_c; }
+            else { ab.dw_carry_out = p->dw_c2; ab.dwc_carry_out = p->dwc_c2; }
+            fused = t2s_att_bwd_fused_ok(ab);
+            if (!fused) {                           // shape not covered (or T2S_ATTB_FUSED=0): the three-launch form, carries in place
+                ab.ctx = nullptr; ab.dw_carry = p->dw_c; ab.dwc_carry = p->dwc_c; ab.dw_carry_out = nullptr; ab.dwc_carry_out = nullptr;
+            }
+        }
+        if (fused) {
+            T2S_CHECK_HIP(t2s_launch_att_bwd_fused(ab, stream));
+        } else if (two_streams && conv_main) {
+            T2S_CHECK_HIP(t2s_launch_att_bwd(ab, stream));
+        } else if (two_streams) {
             if (conv_pending) T2S_CHECK_HIP(hipStreamWaitEvent(stream, ev_conv, 0));   // carries of step t+1 are in place
             T2S_CHECK_HIP(t2s_launch_att_bwd_front(ab, stream));
             T2S_CHECK_HIP(hipEventRecord(ev_energy, stream));
@@ -202,9 +222,10 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         ca.dh2 = nxt ? p->out_a + (size_t)(t + 1) * B * KA + P + E : nullptr; ca.s2 = KA;
         ca.dh3 = nullptr; ca.s3 = 0;
         ca.wq = p->w_query; ca.dq = ab.d_q; ca.q_dim = ad;           // + W_query^T d_q, fused
-        ca.dq_part = nullptr; ca.dq_nchunk = 0;
-        if (two_streams) {       // d_q is folded on the other stream: sum the per-chunk partials here
+        ca.dq_part = nullptr; ca.dq_nchunk = 0; ca.dq_out = nullptr;
+        if (fused || (two_streams && !conv_main)) {       // d_q is not folded yet: sum the per-chunk partials here
             ca.dq_part = p->dq_part; ca.dq_nchunk = (Tin + 31) / 32;
+            if (fused) ca.dq_out = ab.d_q;
         }
         ca.drop_mask = p->att_drop ? p->att_drop + (size_t)t * B * A : nullptr; ca.drop_scale = p->att_drop_scale;
         ca.gates = p->att_gates_all + (size_t)t * B * 4 * A; ca.c_new = p->att_c_all + (size_t)t * B * A;

@@ -18,6 +18,7 @@ struct LstmBwdArgs {
     int B, H;
     const float* wq; const float* dq; int q_dim;   // optional: dh += wq^T dq  (wq [q_dim][H], dq [B][q_dim], q_dim <= 256)
     const float* dq_part; int dq_nchunk;           // optional instead of dq: dq[b][k] = sum_c dq_part[(b*dq_nchunk + c)*q_dim + k]
+    float* dq_out;                                 // optional with dq_part: the summed d_q [B][q_dim]
 };
 
 struct AttBwdArgs {
@@ -40,6 +41,10 @@ struct AttBwdArgs {
     float* dq_part;              // scratch [B][ceil(T/32)][att_dim]
     float* dctx_out;             // optional [B][enc]: d_ctx of this step (then d_memory may be null: deferred accumulation)
     int B, T, att_dim, enc_dim, loc_f, loc_ks;
+    // one-launch form (att_bwd_fused_kernel): the saved context of this step (row stride s_ctx) and a second pair of carry
+    // buffers - the step reads dw_carry / dwc_carry and writes dw_carry_out / dwc_carry_out
+    const float* ctx; long s_ctx;
+    float* dw_carry_out; float* dwc_carry_out;
 };
 
 struct BnBwdArgs {
@@ -61,6 +66,9 @@ hipError_t t2s_launch_att_bwd(const AttBwdArgs& a, hipStream_t stream);
 // the same in two parts: (d_w, energies) and (location-conv backward: carries for step t-1, kernel gradient, d_q fold)
 hipError_t t2s_launch_att_bwd_front(const AttBwdArgs& a, hipStream_t stream);
 hipError_t t2s_launch_att_bwd_conv(const AttBwdArgs& a, hipStream_t stream);
+// the three parts in one launch (needs ctx, the second carry pair, dctx_out; d_q is left as per-chunk partials in dq_part)
+bool t2s_att_bwd_fused_ok(const AttBwdArgs& a);
+hipError_t t2s_launch_att_bwd_fused(const AttBwdArgs& a, hipStream_t stream);
 hipError_t t2s_launch_bn_bwd(const BnBwdArgs& a, hipStream_t stream);
 hipError_t t2s_launch_planes_to_f32(const u16* X_hi, const u16* X_lo, int B, int C, int L, int Lp, int halo, float* out,
                                     int accumulate, hipStream_t stream);

@@ -79,6 +79,7 @@ __global__ void lstm_cell_bwd_kernel(const LstmBwdArgs a) {
                 v = a.dq[(size_t)b * a.q_dim + k];
             }
             s_dq[k] = v;
+            if (a.dq_part && a.dq_out && blockIdx.x == 0) a.dq_out[(size_t)b * a.q_dim + k] = v;
         }
     }
     if (a.wq) __syncthreads();
@@ -679,6 +680,291 @@ __global__ __launch_bounds__(256) void att_bwd_conv_mfma_kernel(const AttBwdArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The three parts above in ONE launch (attention_dim 128, 32 location filters, kernel <= 31, deferred d_memory).  What kept them
+// apart were two reductions across workgroups; both go away:
+//   * softmax backward needs sdot = sum_t w[t] d_w[t] over the whole row.  With d_w[t] = mem[t] . d_ctx + carry[t] and the saved
+//     context ctx = sum_t w[t] mem[t]:  sdot = ctx . d_ctx + sum_t w[t] carry[t]  - 512 + T multiply-adds, no pass over memory;
+//   * the location-conv backward needs d_f on a halo of kernel/2 positions either side: a workgroup recomputes d_w, the features,
+//     the energies backward and d_f for its 32 positions + halo (64 rows: twice the matrix-core work, still ~1.5 us of MFMA).
+//     Reading the neighbours' carries while they are rewritten is avoided by a second pair of carry buffers (in / out by step).
+// Row r of the window <-> position t0 - pad + r; "own" rows are pad .. pad + 31.  Per decoder step this replaces 12 + 10.5 + 10.5 us
+// of dependent launches (profiles/r03_taco_timeline_bwd.md) and the d_w / d_f round trips through global memory.
+#define ATTF_SP 130
+#define ATTF_LDS_FLOATS (192 + 64 * 33 + 32 * 144 + 64 * ATTF_SP + 64 * 34 + 64 * 66 + 1024 + 3 * 64 + 16)
+__global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) {
+    constexpr int AD = 128, F = 32, SP = ATTF_SP, SD = 34, SG = 66;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    float* s_cat = s_dyn;                          // [2][96]    window of [w_prev ; wc_prev]: entry i <-> t0 - 2 pad + i
+    float* s_f = s_cat + 192;                      // [64][33]   F[row][f]
+    float* s_dT = s_f + 64 * 33;                   // [32][144]  D^T[f][a]
+    float* s_dn = s_dT;                            // [128][33]  D[a][f]      (after the energies)
+    float* s_dp = s_dT + 32 * 144;                 // [64][130]  d_pre[row][a]
+    float* s_df = s_dp + 64 * SP;                  // [64][34]   d_f[row][f]
+    float* s_kb = s_df + 64 * SD;                  // [64][48]   conv kernel as B operand [k = c * KS + j][f], rows >= 2 KS zero
+    float* s_g = s_kb;                             // [64][66]   G[m][row]    (after the features)
+    float* s_dctx = s_kb + 64 * SG;                // [<= 1024]
+    float* s_dw = s_dctx + 1024;                   // [64]
+    float* s_de = s_dw + 64;                       // [64]
+    float* s_w = s_de + 64;                        // [64]
+    float* s_red = s_w + 64;                       // [16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * ATTB_CH;
+    const int T = a.T, E = a.enc_dim, KS = a.loc_ks, pad = KS >> 1, K2 = 2 * KS;
+    const int len = a.lengths ? a.lengths[b] : T;
+    const size_t slot = (size_t)b * gridDim.x + chunk;
+    const int tw0 = t0 - pad;                      // position of window row 0
+    // ---- loads ----
+    for (int i = tid; i < 64 * 48; i += 512) s_kb[i] = 0.f;
+    for (int c = tid; c < E; c += 512) {
+        const float v = sum3(a.dctx1, a.sc1, a.dctx2, a.sc2, a.dctx3, a.sc3, b, c);
+        s_dctx[c] = v;
+        if (chunk == 0) a.dctx_out[(size_t)b * E + c] = v;
+    }
+    for (int i = tid; i < 2 * 96; i += 512) {
+        const int c = i >= 96, j = i - c * 96;
+        const int t = tw0 - pad + j;
+        const float* src = c ? a.wc_prev : a.w_prev;
+        s_cat[i] = (src && t >= 0 && t < T) ? src[(size_t)b * (c ? a.s_wcprev : a.s_wprev) + t] : 0.f;
+    }
+    float rk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + j * 512;
+        rk[j] = i < F * K2 ? a.w_loc_conv[i] : 0.f;
+    }
+    float rd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                  // D [a][f], 4096 floats, coalesced
+        const int i = tid + j * 512;
+        rd[j] = a.w_loc_dense[i];
+        s_dT[(i & 31) * 144 + (i >> 5)] = rd[j];
+    }
+    const int ach = 16 * wave + lr;                // this lane's attention channel in the energies / dD stages
+    const float qv = a.q[(size_t)b * AD + ach], vv = a.w_v[ach];
+    float pm[4][4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = tw0 + 16 * tt + 4 * lq + r;
+            pm[tt][r] = (t >= 0 && t < T) ? a.pmem[((size_t)b * T + t) * AD + ach] : 0.f;
+        }
+    float dD_old[2][4];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dD_old[ft][r] = a.dD_part[slot * AD * F + (size_t)(16 * ft + 4 * lq + r) * AD + ach];
+    const float dv_old = a.dv_part[slot * AD + ach];
+    // the kernel-gradient tile of this wave: filters 16 (wave & 1) .., columns m = 16 (wave >> 1) + lr
+    const int mcol = 16 * (wave >> 1) + lr, kft = wave & 1;
+    float dK_old[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dK_old[r] = mcol < K2 ? a.dK_part[slot * F * K2 + (size_t)(16 * kft + 4 * lq + r) * K2 + mcol] : 0.f;
+    __syncthreads();                               // s_dctx, s_kb zeros
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = tid + j * 512;
+        if (i < F * K2) {
+            const int f = i / K2, k = i - f * K2;  // K[f][c][j] -> B operand [k = c * KS + j][f]
+            s_kb[k * 48 + f] = rk[j];
+        }
+    }
+    // ---- d_w of the 64 window rows: wave w takes rows 8 w .. 8 w + 7, channels on lanes ----
+    {
+        float acc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+        for (int c = lane * 4; c < E; c += 256) {
+            const f32x4 dc = *(const f32x4*)&s_dctx[c];
+            f32x4 m[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int t = tw0 + 8 * wave + r;
+                m[r] = (t >= 0 && t < T) ? *(const f32x4*)(a.memory + ((size_t)b * T + t) * E + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] += m[r][0] * dc[0] + m[r][1] * dc[1] + m[r][2] * dc[2] + m[r][3] * dc[3];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float v = attb_wave_sum(acc[r]);
+            const int row = 8 * wave + r, t = tw0 + row;
+            if (lane == 0) {
+                const bool ok = t >= 0 && t < T;
+                s_dw[row] = ok ? v + a.dw_carry[(size_t)b * T + t] + a.dwc_carry[(size_t)b * T + t] : 0.f;
+                s_w[row] = ok ? a.w_cur[(size_t)b * a.s_wcur + t] : 0.f;
+            }
+        }
+    }
+    // ---- sdot = ctx . d_ctx + sum_t w[t] carry[t] ----
+    {
+        float part = 0.f;
+        for (int c = tid; c < E; c += 512) part += a.ctx[(size_t)b * a.s_ctx + c] * s_dctx[c];
+        for (int t = tid; t < T; t += 512)
+            part += a.w_cur[(size_t)b * a.s_wcur + t] * (a.dw_carry[(size_t)b * T + t] + a.dwc_carry[(size_t)b * T + t]);
+        part = attb_wave_sum(part);
+        if (lane == 0) s_red[wave] = part;
+    }
+    __syncthreads();                               // s_kb, s_dw, s_w, s_red
+    const float sdot = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
+    if (tid < 64) {
+        const int t = tw0 + tid;
+        s_de[tid] = (t >= 0 && t < T && t < len) ? s_w[tid] * (s_dw[tid] - sdot) : 0.f;
+    }
+    // ---- location features of the 64 rows: tile (wave >> 1, wave & 1) ----
+    {
+        const int tt = wave >> 1, ft = wave & 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = 4 * u + lq;
+            const int kc = k < K2 ? k : 0;         // (B rows >= 2 KS are zero)
+            const int c = kc >= KS ? 1 : 0, j = kc - c * KS;
+            av[u] = s_cat[c * 96 + 16 * tt + lr + j];
+            bv[u] = s_kb[k * 48 + 16 * ft + lr];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_f[(16 * tt + 4 * lq + r) * 33 + 16 * ft + lr] = acc[r];
+    }
+    __syncthreads();                               // s_f, s_de
+    // ---- energies backward: P = F D^T for channels `ach`, four row tiles ----
+    {
+        float bT[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bT[u] = s_dT[(4 * u + lq) * 144 + ach];
+        float dq = 0.f, dvs = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            float av[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = s_f[(16 * tt + lr) * 33 + 4 * u + lq];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bT[u], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * tt + 4 * lq + r, t = tw0 + row;
+                const float th = tanhf(acc[r] + qv + pm[tt][r]);
+                const float de = s_de[row];        // 0 outside [0, min(T, len))
+                const float dp = de * vv * (1.f - th * th);
+                s_dp[row * SP + ach] = dp;
+                if (row >= pad && row < pad + ATTB_CH && t < T) {          // own rows (t >= 0 there)
+                    dq += dp;
+                    dvs += de * th;
+                    a.d_pmem[((size_t)b * T + t) * AD + ach] += dp;
+                }
+            }
+        }
+        dq += __shfl_xor(dq, 16, 64);
+        dq += __shfl_xor(dq, 32, 64);
+        dvs += __shfl_xor(dvs, 16, 64);
+        dvs += __shfl_xor(dvs, 32, 64);
+        if (lq == 0) {
+            a.dq_part[slot * AD + ach] = dq;
+            a.dv_part[slot * AD + ach] = dv_old + dvs;
+        }
+    }
+    __syncthreads();                               // s_dp complete, s_dT free
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = tid + j * 512;
+        s_dn[(i >> 5) * 33 + (i & 31)] = rd[j];
+    }
+    // ---- dD^T[f][a] += sum over own rows F[row][f] d_pre[row][a] ----
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int u = pad >> 2; u < (pad + ATTB_CH + 3) >> 2; ++u) {
+            const int row = 4 * u + lq;
+            const float av = (row >= pad && row < pad + ATTB_CH) ? s_f[row * 33 + 16 * ft + lr] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s_dp[row * SP + ach], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            a.dD_part[slot * AD * F + (size_t)(16 * ft + 4 * lq + r) * AD + ach] = dD_old[ft][r] + acc[r];
+    }
+    __syncthreads();                               // s_dn
+    // ---- d_f[row][f] = d_pre D: tile (wave >> 1, wave & 1), K = 128 ----
+    {
+        const int tt = wave >> 1, ft = wave & 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float av[16], bv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = 64 * h + 4 * u + lq;
+                av[u] = s_dp[(16 * tt + lr) * SP + k];
+                bv[u] = s_dn[k * 33 + 16 * ft + lr];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_df[(16 * tt + 4 * lq + r) * SD + 16 * ft + lr] = acc[r];
+    }
+    __syncthreads();                               // s_df
+    // ---- location-conv backward.  G[m][row] = sum_f K[f][m] d_f[row][f]: rows m = 16 (wave >> 1) .., row tiles 2 (wave & 1) + {0, 1} ----
+    {
+        float ak[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ak[u] = mcol < K2 ? a.w_loc_conv[(4 * u + lq) * K2 + mcol] : 0.f;       // A[row m][k = f]
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int nt = 2 * (wave & 1) + i;
+            float bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bv[u] = s_df[(16 * nt + lr) * SD + 4 * u + lq];
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ak[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_g[(16 * (wave >> 1) + 4 * lq + r) * SG + 16 * nt + lr] = acc[r];
+        }
+        // kernel gradient: dK[f][m] += sum_tl d_f[tl + pad][f] cat[c][tl + j]   (own rows; window entry tl + j + pad)
+        const int mc = mcol < K2 ? mcol : 0;
+        const int c = mc >= KS ? 1 : 0, j = mc - c * KS;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            av[u] = s_df[(4 * u + lq + pad) * SD + 16 * kft + lr];
+            bv[u] = s_cat[c * 96 + 4 * u + lq + j + pad];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        if (mcol < K2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                a.dK_part[slot * F * K2 + (size_t)(16 * kft + 4 * lq + r) * K2 + mcol] = dK_old[r] + acc[r];
+    }
+    __syncthreads();                               // s_g
+    // ---- carries for step t - 1: 64 outputs x 8 threads (4 taps each) ----
+    {
+        const int o = tid >> 3, jg = tid & 7;
+        const int c = o >> 5, tl = o & 31;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = jg * 4 + i;
+            if (j < KS) acc += s_g[(c * KS + j) * SG + tl - j + 2 * pad];
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        const int tp = t0 + tl;
+        if (jg == 0 && tp < T) {
+            if (c == 0) a.dw_carry_out[(size_t)b * T + tp] = acc;
+            else a.dwc_carry_out[(size_t)b * T + tp] = a.dwc_carry[(size_t)b * T + tp] + acc;
+        }
+    }
+}
+
 static bool att_bwd_ok(const AttBwdArgs& a) {
     return !(a.enc_dim > 1024 || (a.enc_dim & 3) || a.att_dim > 128 || a.loc_f > 32 || a.loc_ks > 63 || !(a.loc_ks & 1) ||
              !a.dw_buf || !a.df_buf || !a.dq_part);
@@ -704,6 +990,21 @@ hipError_t t2s_launch_att_bwd_conv(const AttBwdArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(att_bwd_conv_mfma_kernel, grid, dim3(256), 0, stream, a);
     else
         hipLaunchKernelGGL(att_bwd_conv_kernel, grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+bool t2s_att_bwd_fused_ok(const AttBwdArgs& a) {
+    static const int off = getenv("T2S_ATTB_FUSED") ? !atoi(getenv("T2S_ATTB_FUSED")) : 0;
+    return !off && att_bwd_ok(a) && a.att_dim == 128 && a.loc_f == 32 && a.loc_ks <= 31 && a.ctx && a.dw_carry_out &&
+           a.dwc_carry_out && a.dctx_out && !a.d_memory && a.dw_carry_out != a.dw_carry && a.dwc_carry_out != a.dwc_carry;
+}
+hipError_t t2s_launch_att_bwd_fused(const AttBwdArgs& a, hipStream_t stream) {
+    if (!t2s_att_bwd_fused_ok(a)) return hipErrorInvalidValue;
+    constexpr int lds = ATTF_LDS_FLOATS * (int)sizeof(float);
+    static std::atomic<unsigned long long> attr_mask{0};
+    const hipError_t e = t2s_raise_lds_limit((const void*)att_bwd_fused_kernel, lds, attr_mask);
+    if (e != hipSuccess) return e;
+    const dim3 grid((a.T + ATTB_CH - 1) / ATTB_CH, a.B);
+    hipLaunchKernelGGL(att_bwd_fused_kernel, grid, dim3(512), lds, stream, a);
     return hipGetLastError();
 }
 hipError_t t2s_launch_att_bwd(const AttBwdArgs& a, hipStream_t stream) {

@@ -31,7 +31,8 @@ class _AttBwd(ctypes.Structure):
                  ("w_v", vp), ("dw_carry", vp), ("dwc_carry", vp), ("d_q", vp), ("d_pmem", vp), ("d_memory", vp),
                  ("dD_part", vp), ("dK_part", vp), ("dv_part", vp), ("dw_buf", vp), ("df_buf", vp), ("dq_part", vp),
                  ("dctx_out", vp)] +
-                [(n, i32) for n in ("B", "T", "att_dim", "enc_dim", "loc_f", "loc_ks")])
+                [(n, i32) for n in ("B", "T", "att_dim", "enc_dim", "loc_f", "loc_ks")] +
+                [("ctx", vp), ("s_ctx", lng), ("dw_carry_out", vp), ("dwc_carry_out", vp)])
 
 
 class _Bptt(ctypes.Structure):
@@ -44,7 +45,8 @@ class _Bptt(ctypes.Structure):
                 [("att_drop_scale", f32c), ("dec_drop_scale", f32c)] +
                 [(n, vp) for n in ("d_hc", "out_d", "out_a", "dg_d", "dg_a", "dq_all", "dc_d", "dc_a", "dw_c",
                                    "dwc_c", "d_pmem", "d_memory", "dD_part", "dK_part", "dv_part", "dw_buf", "df_buf",
-                                   "dq_part", "dctx_all")])
+                                   "dq_part", "dctx_all", "ctx_all")] +
+                [("s_ctx_step", lng), ("s_ctx_item", lng), ("dw_c2", vp), ("dwc_c2", vp)])
 
 
 class _BnBwd(ctypes.Structure):
@@ -278,6 +280,7 @@ class _Bwd:
         dq_all = self.new(T, B, ad, tag="bptt_dq_all")
         dc_d, dc_a = self.zeros(B, D), self.zeros(B, A)
         dw_c, dwc_c = self.zeros(B, T_in), self.zeros(B, T_in)
+        dw_c2, dwc_c2 = self.zeros(B, T_in), self.zeros(B, T_in)      # second carry pair: the one-launch attention backward
         d_pmem, d_memory = self.zeros(B, T_in, ad), self.zeros(B, T_in, E)
         nch = (T_in + 31) // 32                     # partial parameter gradients: one slot per (batch element, 32-position chunk)
         dD_p, dK_p, dv_p = self.zeros(B * nch, ad * F_), self.zeros(B * nch, F_ * 2 * KS), self.zeros(B * nch, ad)
@@ -299,6 +302,9 @@ class _Bwd:
                    dc_d=_p(dc_d), dc_a=_p(dc_a), dw_c=_p(dw_c), dwc_c=_p(dwc_c), d_pmem=_p(d_pmem),
                    d_memory=_p(d_memory), dD_part=_p(dD_p), dK_part=_p(dK_p), dv_part=_p(dv_p), dw_buf=_p(dw_buf),
                    df_buf=_p(df_buf), dq_part=_p(dq_part), dctx_all=_p(dctx_all))
+        if dctx_all is not None:                   # the forward's contexts: hc_all[t][b] = [h_dec | ctx]
+            bp.ctx_all, bp.s_ctx_step, bp.s_ctx_item = _p(sv["hc_all"], D), B * (D + E), D + E
+            bp.dw_c2, bp.dwc_c2 = _p(dw_c2), _p(dwc_c2)
         _lib.call("t2s_taco_bptt_steps", ctypes.byref(bp), T, 0, st)        # the whole reversed loop, enqueued from C++
         if dctx_all is not None:
             # d_memory[b] = sum_t w[t][b][:] (x) d_ctx[t][b][:]: one contraction over the decoder steps per batch element
@@ -308,7 +314,7 @@ class _Bwd:
                 _lib.call("t2s_wn_backward", _p(Pm_), ks_, M4_, N_, 0, 0, 0, N_ - 1, 1, _p(memory), None, T_in, E, 1,
                           _p(d_memory, b * T_in * E), None, None, 0, st)
             self.keep.append(dctx_all)
-        self.keep += [dw_buf, df_buf, dq_part]
+        self.keep += [dw_buf, df_buf, dq_part, dw_c2, dwc_c2]
         # ---- weight gradients over all (step, batch) items ----
         ar = dec.attention_rnn
         Pa, ks, M4, N = self.items_wgrad(items, [(_p(dg_a), 4 * A, 4 * A, 0, 0)],
