@@ -8,7 +8,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libt2s_hip.so")
+LIB_PATH = os.environ.get("T2S_LIB_PATH") or os.path.join(HERE, "libt2s_hip.so")      # (override: diagnostic builds)
 
 c_int, c_float, c_vp, c_long = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_long
 

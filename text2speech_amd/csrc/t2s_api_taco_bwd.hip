@@ -152,7 +152,13 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         T2S_CHECK_HIP(hipEventRecord(ev_main, stream));
         T2S_CHECK_HIP(hipStreamWaitEvent(side, ev_main, 0));
     }
-    for (int t = t_hi - 1; t >= t_lo; --t) {
+    // The decoder-cell chain never waits for the attention chain, so it is enqueued `chunk` steps at a time and the caller's
+    // stream waits once per chunk: a cross-stream wait costs ~6 us on the critical stream (profiles/r03_taco_timeline_bwd_fused.md).
+    static const int chunk_env = getenv("T2S_BPTT_CHUNK") ? atoi(getenv("T2S_BPTT_CHUNK")) : 16;
+    const int chunk = two_streams ? (chunk_env > 0 ? chunk_env : 1) : 1;
+    for (int tc = t_hi - 1; tc >= t_lo; tc -= chunk) {
+    const int tl = tc - chunk + 1 > t_lo ? tc - chunk + 1 : t_lo;
+    for (int t = tc; t >= tl; --t) {
         const bool nxt = t + 1 < T;
         // decoder LSTMCell: dh = d[h_dec] from the projection + from step t+1's decoder cell (through W_hh)
         LstmBwdArgs cd;
@@ -170,10 +176,14 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         g.W1 = p->W_dT; g.ld1 = 4 * D; g.k1 = 4 * D; g.x1 = cd.dgates; g.n1 = 4 * D; g.sx1 = 4 * D;
         g.y = p->out_d + (size_t)t * B * KD; g.sy_item = KD; g.sy_row = 1; g.rows = KD; g.items = B; g.mask_scale = 1.f;
         T2S_CHECK_HIP(t2s_launch_gemv(g, dstream));
-        if (two_streams) {       // out_d[t] is ready: the wait below binds to THIS record, so one event object serves every step
-            T2S_CHECK_HIP(hipEventRecord(ev_side, side));
-            T2S_CHECK_HIP(hipStreamWaitEvent(stream, ev_side, 0));
-        }
+    }
+    if (two_streams) {       // out_d[tl .. tc] are ready: the wait below binds to THIS record, so one event object serves every chunk
+        T2S_CHECK_HIP(hipEventRecord(ev_side, side));
+        T2S_CHECK_HIP(hipStreamWaitEvent(stream, ev_side, 0));
+    }
+    for (int t = tc; t >= tl; --t) {
+        const bool nxt = t + 1 < T;
+        GemvArgs g;
         // attention: d_ctx = decoder-cell input part + projection part + step t+1's attention-cell input part
         AttBwdArgs ab;
         memset(&ab, 0, sizeof(ab));
@@ -236,6 +246,7 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         g.W1 = p->W_aT; g.ld1 = 4 * A; g.k1 = 4 * A; g.x1 = ca.dgates; g.n1 = 4 * A; g.sx1 = 4 * A;
         g.y = p->out_a + (size_t)t * B * KA; g.sy_item = KA; g.sy_row = 1; g.rows = KA; g.items = B; g.mask_scale = 1.f;
         T2S_CHECK_HIP(t2s_launch_gemv(g, stream));
+    }
     }
     if (conv_pending) T2S_CHECK_HIP(hipStreamWaitEvent(stream, ev_conv, 0));       // dq_all, carries, dK complete for the caller
     return T2S_OK;

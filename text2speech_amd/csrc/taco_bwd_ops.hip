@@ -113,7 +113,68 @@ __global__ void lstm_cell_bwd_kernel(const LstmBwdArgs a) {
     dg[3 * a.H] = dh * tc * go * (1.f - go);
     a.dc_carry[idx] = dc * gf;
 }
+// The attention cell's form (+ W_q^T d_q): 64 hidden units per workgroup, the query dimension split over the four waves - four
+// times the workgroups of the kernel above (512 at H = 1024, B = 32: it left half the CUs idle) and a quarter of the dependent
+// load batches per thread.
+__global__ __launch_bounds__(256) void lstm_cell_bwd_q_kernel(const LstmBwdArgs a) {
+    __shared__ float s_dq[256];
+    __shared__ float s_e[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, kq = tid >> 6;
+    const int u = blockIdx.x * 64 + lane, b = blockIdx.y;
+    const int kn = a.q_dim >> 2;                   // query rows per wave
+    // this wave's slice of W_q for unit u: requested before anything else
+    float w[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) w[i] = i < kn ? a.wq[(size_t)(kq * kn + i) * a.H + u] : 0.f;
+    for (int k = tid; k < a.q_dim; k += 256) {
+        float v = 0.f;
+        if (a.dq_part) {
+            for (int c = 0; c < a.dq_nchunk; ++c) v += a.dq_part[((size_t)b * a.dq_nchunk + c) * a.q_dim + k];
+            if (a.dq_out && blockIdx.x == 0) a.dq_out[(size_t)b * a.q_dim + k] = v;
+        } else {
+            v = a.dq[(size_t)b * a.q_dim + k];
+        }
+        s_dq[k] = v;
+    }
+    // the pointwise operands of the 64 finishing threads
+    const size_t idx = (size_t)b * a.H + u;
+    float dh = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, cn = 0.f, cp = 0.f, dcc = 0.f;
+    bool keep = true;
+    if (kq == 0) {
+        dh = sum3(a.dh1, a.s1, a.dh2, a.s2, a.dh3, a.s3, b, u);
+        const float* g4 = a.gates + (size_t)b * 4 * a.H + u;
+        gi = g4[0]; gf = g4[a.H]; gg = g4[2 * a.H]; go = g4[3 * a.H];
+        cn = a.c_new[idx];
+        cp = a.c_prev ? a.c_prev[idx] : 0.f;
+        dcc = a.dc_carry[idx];
+        if (a.drop_mask) keep = a.drop_mask[idx] != 0;
+    }
+    __syncthreads();
+    float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; i += 2) {
+        e0 += s_dq[kq * kn + i] * w[i];            // (w is 0 past kn; s_dq is read inside its 256 entries: kn <= 32)
+        e1 += s_dq[kq * kn + i + 1] * w[i + 1];
+    }
+    s_e[kq][lane] = e0 + e1;
+    __syncthreads();
+    if (kq != 0) return;
+    dh += (s_e[0][lane] + s_e[1][lane]) + (s_e[2][lane] + s_e[3][lane]);
+    if (a.drop_mask) dh = keep ? dh * a.drop_scale : 0.f;
+    const float tc = tanhf(cn);
+    const float dc = dcc + dh * go * (1.f - tc * tc);
+    float* dg = a.dgates + (size_t)b * 4 * a.H + u;
+    dg[0] = dc * gg * gi * (1.f - gi);
+    dg[a.H] = dc * cp * gf * (1.f - gf);
+    dg[2 * a.H] = dc * gi * (1.f - gg * gg);
+    dg[3 * a.H] = dh * tc * go * (1.f - go);
+    a.dc_carry[idx] = dc * gf;
+}
 hipError_t t2s_launch_lstm_cell_bwd(const LstmBwdArgs& a, hipStream_t stream) {
+    if (a.wq && (a.H & 63) == 0 && a.q_dim == 128) {
+        hipLaunchKernelGGL(lstm_cell_bwd_q_kernel, dim3(a.H / 64, a.B), dim3(256), 0, stream, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((a.H + 255) / 256, a.B), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
@@ -690,6 +751,15 @@ __global__ __launch_bounds__(256) void att_bwd_conv_mfma_kernel(const AttBwdArgs
 //     Reading the neighbours' carries while they are rewritten is avoided by a second pair of carry buffers (in / out by step).
 // Row r of the window <-> position t0 - pad + r; "own" rows are pad .. pad + 31.  Per decoder step this replaces 12 + 10.5 + 10.5 us
 // of dependent launches (profiles/r03_taco_timeline_bwd.md) and the d_w / d_f round trips through global memory.
+#ifdef T2S_ATTF_STAMPS          // diagnostic build: phase boundaries of workgroup (0, 0), 100 MHz ticks (tools/attf_stamps.py)
+__device__ unsigned long long t2s_attf_stamps[16];
+#define ATTF_STAMP(i) if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) t2s_attf_stamps[i] = __builtin_amdgcn_s_memrealtime();
+extern "C" int t2s_debug_read_attf_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(t2s_attf_stamps), sizeof(unsigned long long) * 16);
+}
+#else
+#define ATTF_STAMP(i)
+#endif
 #define ATTF_SP 130
 #define ATTF_LDS_FLOATS (192 + 64 * 33 + 32 * 144 + 64 * ATTF_SP + 64 * 34 + 64 * 66 + 1024 + 3 * 64 + 16)
 __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) {
@@ -710,17 +780,54 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
     float* s_red = s_w + 64;                       // [16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * ATTB_CH;
+    // batch element on blockIdx.x: workgroups go to the 8 XCDs round-robin by linear id, so the chunks of one batch element share
+    // an L2 and the halo rows of `memory` / `pmem` (read by two or three of them) come from HBM / MALL once
+    const int b = blockIdx.x, chunk = blockIdx.y, t0 = chunk * ATTB_CH;
     const int T = a.T, E = a.enc_dim, KS = a.loc_ks, pad = KS >> 1, K2 = 2 * KS;
     const int len = a.lengths ? a.lengths[b] : T;
-    const size_t slot = (size_t)b * gridDim.x + chunk;
+    const size_t slot = (size_t)b * gridDim.y + chunk;
     const int tw0 = t0 - pad;                      // position of window row 0
-    // ---- loads ----
+    ATTF_STAMP(0)
+    // ---- loads: everything the kernel reads from global memory is requested here, in the order it is consumed ----
+    // d_ctx first (its three sources return before the 128 KB of memory rows requested next, so the LDS copy and the barrier do
+    // not wait for those); then the d_w operands: wave w takes window rows 8 w .. 8 w + 7, channels on lanes (registers for
+    // enc_dim 512, else a loop below)
+    float dctx_r[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) dctx_r[h] = tid + 512 * h < E ? sum3(a.dctx1, a.sc1, a.dctx2, a.sc2, a.dctx3, a.sc3, b, tid + 512 * h) : 0.f;
+    const bool e512 = E == 512;
+    f32x4 mrow[2][8];
+    if (e512) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int t = tw0 + 8 * wave + r;
+                const int tc = t < 0 ? 0 : (t < T ? t : T - 1);          // clamped, unconditional load; rows outside [0, T) have d_e = 0
+                mrow[h][r] = *(const f32x4*)(a.memory + ((size_t)b * T + tc) * E + lane * 4 + 256 * h);
+            }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        if (tid + 512 * h < E) {
+            s_dctx[tid + 512 * h] = dctx_r[h];
+            if (chunk == 0) a.dctx_out[(size_t)b * E + tid + 512 * h] = dctx_r[h];
+        }
     for (int i = tid; i < 64 * 48; i += 512) s_kb[i] = 0.f;
-    for (int c = tid; c < E; c += 512) {
-        const float v = sum3(a.dctx1, a.sc1, a.dctx2, a.sc2, a.dctx3, a.sc3, b, c);
-        s_dctx[c] = v;
-        if (chunk == 0) a.dctx_out[(size_t)b * E + c] = v;
+    // sdot = ctx . d_ctx + sum_t w[t] carry[t]: this thread's terms
+    float ctx_r[2], wc_r = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) ctx_r[h] = tid + 512 * h < E ? a.ctx[(size_t)b * a.s_ctx + tid + 512 * h] : 0.f;
+    for (int t = tid; t < T; t += 512)
+        wc_r += a.w_cur[(size_t)b * a.s_wcur + t] * (a.dw_carry[(size_t)b * T + t] + a.dwc_carry[(size_t)b * T + t]);
+    // window row `tid` (threads 0-63): attention weight and carries
+    float row_w = 0.f, row_c = 0.f;
+    if (tid < 64) {
+        const int t = tw0 + tid;
+        if (t >= 0 && t < T) {
+            row_w = a.w_cur[(size_t)b * a.s_wcur + t];
+            row_c = a.dw_carry[(size_t)b * T + t] + a.dwc_carry[(size_t)b * T + t];
+        }
     }
     for (int i = tid; i < 2 * 96; i += 512) {
         const int c = i >= 96, j = i - c * 96;
@@ -741,27 +848,7 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
         rd[j] = a.w_loc_dense[i];
         s_dT[(i & 31) * 144 + (i >> 5)] = rd[j];
     }
-    const int ach = 16 * wave + lr;                // this lane's attention channel in the energies / dD stages
-    const float qv = a.q[(size_t)b * AD + ach], vv = a.w_v[ach];
-    float pm[4][4];
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int t = tw0 + 16 * tt + 4 * lq + r;
-            pm[tt][r] = (t >= 0 && t < T) ? a.pmem[((size_t)b * T + t) * AD + ach] : 0.f;
-        }
-    float dD_old[2][4];
-#pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dD_old[ft][r] = a.dD_part[slot * AD * F + (size_t)(16 * ft + 4 * lq + r) * AD + ach];
-    const float dv_old = a.dv_part[slot * AD + ach];
-    // the kernel-gradient tile of this wave: filters 16 (wave & 1) .., columns m = 16 (wave >> 1) + lr
-    const int mcol = 16 * (wave >> 1) + lr, kft = wave & 1;
-    float dK_old[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dK_old[r] = mcol < K2 ? a.dK_part[slot * F * K2 + (size_t)(16 * kft + 4 * lq + r) * K2 + mcol] : 0.f;
+    ATTF_STAMP(1)
     __syncthreads();                               // s_dctx, s_kb zeros
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -771,48 +858,84 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
             s_kb[k * 48 + f] = rk[j];
         }
     }
-    // ---- d_w of the 64 window rows: wave w takes rows 8 w .. 8 w + 7, channels on lanes ----
+    ATTF_STAMP(2)
+    // ---- d_w of the 64 window rows (without the carries) ----
     {
         float acc[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) acc[r] = 0.f;
-        for (int c = lane * 4; c < E; c += 256) {
-            const f32x4 dc = *(const f32x4*)&s_dctx[c];
-            f32x4 m[8];
+        if (e512) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int t = tw0 + 8 * wave + r;
-                m[r] = (t >= 0 && t < T) ? *(const f32x4*)(a.memory + ((size_t)b * T + t) * E + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 dc = *(const f32x4*)&s_dctx[lane * 4 + 256 * h];
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    acc[r] += mrow[h][r][0] * dc[0] + mrow[h][r][1] * dc[1] + mrow[h][r][2] * dc[2] + mrow[h][r][3] * dc[3];
             }
+        } else {
+            for (int c = lane * 4; c < E; c += 256) {
+                const f32x4 dc = *(const f32x4*)&s_dctx[c];
+                f32x4 m[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) acc[r] += m[r][0] * dc[0] + m[r][1] * dc[1] + m[r][2] * dc[2] + m[r][3] * dc[3];
+                for (int r = 0; r < 8; ++r) {
+                    const int t = tw0 + 8 * wave + r;
+                    m[r] = (t >= 0 && t < T) ? *(const f32x4*)(a.memory + ((size_t)b * T + t) * E + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) acc[r] += m[r][0] * dc[0] + m[r][1] * dc[1] + m[r][2] * dc[2] + m[r][3] * dc[3];
+            }
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const float v = attb_wave_sum(acc[r]);
-            const int row = 8 * wave + r, t = tw0 + row;
-            if (lane == 0) {
-                const bool ok = t >= 0 && t < T;
-                s_dw[row] = ok ? v + a.dw_carry[(size_t)b * T + t] + a.dwc_carry[(size_t)b * T + t] : 0.f;
-                s_w[row] = ok ? a.w_cur[(size_t)b * a.s_wcur + t] : 0.f;
-            }
+            if (lane == 0) s_dw[8 * wave + r] = v;
         }
-    }
-    // ---- sdot = ctx . d_ctx + sum_t w[t] carry[t] ----
-    {
-        float part = 0.f;
-        for (int c = tid; c < E; c += 512) part += a.ctx[(size_t)b * a.s_ctx + c] * s_dctx[c];
-        for (int t = tid; t < T; t += 512)
-            part += a.w_cur[(size_t)b * a.s_wcur + t] * (a.dw_carry[(size_t)b * T + t] + a.dwc_carry[(size_t)b * T + t]);
+        float part = wc_r;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (tid + 512 * h < E) part += ctx_r[h] * s_dctx[tid + 512 * h];
         part = attb_wave_sum(part);
         if (lane == 0) s_red[wave] = part;
     }
-    __syncthreads();                               // s_kb, s_dw, s_w, s_red
-    const float sdot = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
+    ATTF_STAMP(3)
+    // operands of the later stages: requested now (the d_w registers are free), consumed after the next barriers
+    const int ach = 16 * wave + lr;                // this lane's attention channel in the energies / dD stages
+    const float qv = a.q[(size_t)b * AD + ach], vv = a.w_v[ach];
+    float pm[4][4], dpm[4][4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * tt + 4 * lq + r, t = tw0 + row;
+            const size_t po = ((size_t)b * T + (t < 0 ? 0 : (t < T ? t : T - 1))) * AD + ach;     // clamped, unconditional loads
+            pm[tt][r] = a.pmem[po];
+            if (row >= pad && row < pad + ATTB_CH) dpm[tt][r] = a.d_pmem[po];      // read-modify-write on own rows only
+            else dpm[tt][r] = 0.f;
+        }
+    float dD_old[2][4];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dD_old[ft][r] = a.dD_part[slot * AD * F + (size_t)(16 * ft + 4 * lq + r) * AD + ach];
+    const float dv_old = a.dv_part[slot * AD + ach];
+    // the kernel-gradient tile of this wave: filters 16 (wave & 1) .., columns m = 16 (wave >> 1) + lr
+    const int mcol = 16 * (wave >> 1) + lr, kft = wave & 1;
+    float dK_old[4], ak[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dK_old[r] = mcol < K2 ? a.dK_part[slot * F * K2 + (size_t)(16 * kft + 4 * lq + r) * K2 + mcol] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ak[u] = mcol < K2 ? a.w_loc_conv[(4 * u + lq) * K2 + mcol] : 0.f;       // G stage: A[row m][k = f]
+    // carries: output (c, tl) = tid >> 3
+    const int co = tid >> 8, ctl = (tid >> 3) & 31;
+    const float dwc_old = (co == 1 && (tid & 7) == 0 && t0 + ctl < T) ? a.dwc_carry[(size_t)b * T + t0 + ctl] : 0.f;
+    ATTF_STAMP(4)
+    __syncthreads();                               // s_kb, s_dw, s_red
     if (tid < 64) {
+        const float sdot = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
         const int t = tw0 + tid;
-        s_de[tid] = (t >= 0 && t < T && t < len) ? s_w[tid] * (s_dw[tid] - sdot) : 0.f;
+        s_de[tid] = (t >= 0 && t < T && t < len) ? row_w * (s_dw[tid] + row_c - sdot) : 0.f;
     }
+    ATTF_STAMP(5)
     // ---- location features of the 64 rows: tile (wave >> 1, wave & 1) ----
     {
         const int tt = wave >> 1, ft = wave & 1;
@@ -831,6 +954,7 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_f[(16 * tt + 4 * lq + r) * 33 + 16 * ft + lr] = acc[r];
     }
+    ATTF_STAMP(6)
     __syncthreads();                               // s_f, s_de
     // ---- energies backward: P = F D^T for channels `ach`, four row tiles ----
     {
@@ -856,7 +980,7 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
                 if (row >= pad && row < pad + ATTB_CH && t < T) {          // own rows (t >= 0 there)
                     dq += dp;
                     dvs += de * th;
-                    a.d_pmem[((size_t)b * T + t) * AD + ach] += dp;
+                    a.d_pmem[((size_t)b * T + t) * AD + ach] = dpm[tt][r] + dp;
                 }
             }
         }
@@ -869,6 +993,7 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
             a.dv_part[slot * AD + ach] = dv_old + dvs;
         }
     }
+    ATTF_STAMP(7)
     __syncthreads();                               // s_dp complete, s_dT free
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -879,15 +1004,22 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int u = pad >> 2; u < (pad + ATTB_CH + 3) >> 2; ++u) {
-            const int row = 4 * u + lq;
-            const float av = (row >= pad && row < pad + ATTB_CH) ? s_f[row * 33 + 16 * ft + lr] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s_dp[row * SP + ach], acc, 0, 0, 0);
+        float av[12], bv[12];                      // own rows lie in 4 u0 .. 4 u0 + 47 for any pad (kernel <= 31)
+        const int u0 = pad >> 2;
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int row = 4 * (u0 + u) + lq;
+            const bool own = row >= pad && row < pad + ATTB_CH;
+            av[u] = own ? s_f[row * 33 + 16 * ft + lr] : 0.f;
+            bv[u] = own ? s_dp[row * SP + ach] : 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             a.dD_part[slot * AD * F + (size_t)(16 * ft + 4 * lq + r) * AD + ach] = dD_old[ft][r] + acc[r];
     }
+    ATTF_STAMP(8)
     __syncthreads();                               // s_dn
     // ---- d_f[row][f] = d_pre D: tile (wave >> 1, wave & 1), K = 128 ----
     {
@@ -908,12 +1040,10 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_df[(16 * tt + 4 * lq + r) * SD + 16 * ft + lr] = acc[r];
     }
+    ATTF_STAMP(9)
     __syncthreads();                               // s_df
     // ---- location-conv backward.  G[m][row] = sum_f K[f][m] d_f[row][f]: rows m = 16 (wave >> 1) .., row tiles 2 (wave & 1) + {0, 1} ----
     {
-        float ak[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) ak[u] = mcol < K2 ? a.w_loc_conv[(4 * u + lq) * K2 + mcol] : 0.f;       // A[row m][k = f]
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int nt = 2 * (wave & 1) + i;
@@ -943,6 +1073,7 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
             for (int r = 0; r < 4; ++r)
                 a.dK_part[slot * F * K2 + (size_t)(16 * kft + 4 * lq + r) * K2 + mcol] = dK_old[r] + acc[r];
     }
+    ATTF_STAMP(10)
     __syncthreads();                               // s_g
     // ---- carries for step t - 1: 64 outputs x 8 threads (4 taps each) ----
     {
@@ -960,9 +1091,10 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
         const int tp = t0 + tl;
         if (jg == 0 && tp < T) {
             if (c == 0) a.dw_carry_out[(size_t)b * T + tp] = acc;
-            else a.dwc_carry_out[(size_t)b * T + tp] = a.dwc_carry[(size_t)b * T + tp] + acc;
+            else a.dwc_carry_out[(size_t)b * T + tp] = dwc_old + acc;
         }
     }
+    ATTF_STAMP(11)
 }
 
 static bool att_bwd_ok(const AttBwdArgs& a) {
@@ -1003,7 +1135,7 @@ hipError_t t2s_launch_att_bwd_fused(const AttBwdArgs& a, hipStream_t stream) {
     static std::atomic<unsigned long long> attr_mask{0};
     const hipError_t e = t2s_raise_lds_limit((const void*)att_bwd_fused_kernel, lds, attr_mask);
     if (e != hipSuccess) return e;
-    const dim3 grid((a.T + ATTB_CH - 1) / ATTB_CH, a.B);
+    const dim3 grid(a.B, (a.T + ATTB_CH - 1) / ATTB_CH);
     hipLaunchKernelGGL(att_bwd_fused_kernel, grid, dim3(512), lds, stream, a);
     return hipGetLastError();
 }

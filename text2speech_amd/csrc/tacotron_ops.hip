@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void att_energy_kernel(const AttArgs a) {
 __global__ __launch_bounds__(256) void att_softmax_ctx_kernel(const AttArgs a) {
     extern __shared__ float s_w[];                       // [T]
     __shared__ float red[4];
-    __shared__ float s_part[4][64];
+    __shared__ __attribute__((aligned(16))) float s_part[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
     const int T = a.T;
@@ -447,17 +447,45 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_kernel(const AttArgs a) {
     }
     __syncthreads();
     const int c = blockIdx.y * 64 + lane;
-    float a4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c < a.enc_dim) {
-        const float* mem = a.memory + (size_t)b * T * a.enc_dim + c;
-        int t = wave;
-        for (; t + 12 < T; t += 16) {
+    if ((a.enc_dim & 63) == 0) {
+        // 16 lanes x 16 bytes cover the 64 channels of a row; the four lane groups of the four waves take 16 rows per round, eight
+        // rounds of loads in flight (the scalar form below waited for memory once per 16 rows: 16 round trips at T = 256 - 9 of
+        // the kernel's 10.5 us, profiles/r03_taco_timeline_fwd.md)
+        const int cg = lane & 15, rg = lane >> 4;
+        const float* mem = a.memory + (size_t)b * T * a.enc_dim + blockIdx.y * 64 + cg * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int t0 = 4 * wave + rg; t0 < T; t0 += 128) {
+            f32x4 m[8];
+            float w[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a4[u] += s_w[t + 4 * u] * mem[(size_t)(t + 4 * u) * a.enc_dim];
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + 16 * u;
+                const int tc = t < T ? t : T - 1;
+                m[u] = *(const f32x4*)(mem + (size_t)tc * a.enc_dim);
+                w[u] = t < T ? s_w[tc] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += w[u] * m[u];
         }
-        for (; t < T; t += 4) a4[0] += s_w[t] * mem[(size_t)t * a.enc_dim];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] += __shfl_xor(acc[i], 16, 64);
+            acc[i] += __shfl_xor(acc[i], 32, 64);
+        }
+        if (rg == 0) *(f32x4*)&s_part[wave][cg * 4] = acc;
+    } else {
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c < a.enc_dim) {
+            const float* mem = a.memory + (size_t)b * T * a.enc_dim + c;
+            int t = wave;
+            for (; t + 12 < T; t += 16) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a4[u] += s_w[t + 4 * u] * mem[(size_t)(t + 4 * u) * a.enc_dim];
+            }
+            for (; t < T; t += 4) a4[0] += s_w[t] * mem[(size_t)t * a.enc_dim];
+        }
+        s_part[wave][lane] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     }
-    s_part[wave][lane] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     __syncthreads();
     if (wave == 0 && c < a.enc_dim) {
         const float acc = (s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]);

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Diagnostic: where one launch of the one-launch attention backward (att_bwd_fused_kernel) spends its time.  Needs a library built
+with -DT2S_ATTF_STAMPS (T2S_LIB_PATH points at it): workgroup (0, 0) records the 100 MHz clock at its phase boundaries; this runs
+a few Tacotron train steps (B = 32, T_in = 256) and prints the deltas of the last launch in us."""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("T_OUT", "64")
+import torch  # noqa: E402
+from text2speech_amd import _lib  # noqa: E402
+import tools.bench_tacotron_train as bt  # noqa: E402
+
+NAMES = ["entry -> loads requested", "wait: barrier 1 (d_ctx in LDS)", "conv kernel to LDS", "d_w dots + sdot partial",
+         "later-stage loads requested; barrier 2", "d_e", "features MFMA; barrier 3", "energies backward; barrier 4",
+         "D to LDS + dD^T; barrier 5", "d_f; barrier 6", "G + dK; barrier 7", "carries"]
+
+
+def main():
+    sys.argv = sys.argv[:1]
+    bt.main()                                       # a few warm-up + timed steps; the stamps of the last launch remain
+    lib = _lib.load()
+    buf = (ctypes.c_ulonglong * 16)()
+    torch.cuda.synchronize()
+    lib.t2s_debug_read_attf_stamps(buf)
+    v = list(buf)
+    print("total %.2f us" % ((v[11] - v[0]) / 100.0))
+    for i in range(11):
+        print("%-44s %6.2f us" % (NAMES[i + 1], (v[i + 1] - v[i]) / 100.0))
+
+
+if __name__ == "__main__":
+    main()
