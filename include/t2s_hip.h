@@ -229,6 +229,13 @@ int t2s_bn_train(const float* x, const float* gamma, const float* beta, float ep
                  float mask_scale, int B, int C, int T, int Lp, int halo, float* mean, float* var, void* O_hi, void* O_lo,
                  float* out_f32, void* stream);
 
+/* nn.BatchNorm1d's bookkeeping in .train() mode after t2s_bn_train: running_x = (1 - momentum) running_x + momentum batch_x, the
+ * variance unbiased by n / (n - 1) (n = B * T); *num_batches_tracked (int64, optional) += 1.  One launch per layer. */
+int t2s_bn_running_update(const float* mean, const float* var, float* running_mean, float* running_var,
+                          long long* num_batches_tracked, float momentum, long long n, int C, void* stream);
+/* clears `bytes` bytes at p (16-byte aligned): the single fill of a training step's accumulator arena */
+int t2s_zero_fill(void* p, size_t bytes, void* stream);
+
 /* Encoder BiLSTM recurrence with packed-sequence semantics (tacotron.py:199-207).  gx[B][T][8H] = W_ih x + b_ih + b_hh
  * for both directions (fwd gates then reverse gates), whhT_* = W_hh^T [H][4H]; out[B][T_out][2H]; 4H must be 1024. */
 int t2s_taco_encoder_lstm(const float* gx, const float* whhT_fwd, const float* whhT_rev, const int* lengths, float* out,
@@ -458,7 +465,7 @@ typedef struct t2s_att_bwd {
                                            * forms d_memory = sum_t w_t (x) d_ctx_t once after the loop */
     int B, T, att_dim, enc_dim, loc_f, loc_ks;
     /* used by t2s_taco_bptt_steps' one-launch form only (leave 0 here): the step's saved context [B][.] (row stride s_ctx) and
-     * the carry buffers the step WRITES (it reads dw_carry / dwc_carry) */
+     * the carry buffers the step WRITES (it reads dw_carry / dwc_carry); all four are then [3][B][T] (see t2s_taco_bptt) */
     const float *ctx; long s_ctx;
     float *dw_carry_out, *dwc_carry_out;
 } t2s_att_bwd;
@@ -487,8 +494,9 @@ typedef struct t2s_taco_bptt {
                                                          * touched by the loop (deferred, see t2s_att_bwd.dctx_out) */
     /* optional, all or none (needs dctx_all, attention_dim 128, 32 location filters, kernel <= 31): the attention backward of a
      * step in ONE launch.  ctx_all = the forward's contexts, step t / item b at ctx_all + t * s_ctx_step + b * s_ctx_item;
-     * dw_c2 / dwc_c2 = a second pair of carry buffers [B][T_in], zero-initialised like dw_c / dwc_c (step t reads the pair of
-     * parity t & 1 - dw_c for even t - and writes the other). */
+     * dw_c2 / dwc_c2 = a second pair of carry buffers, zero-initialised like dw_c / dwc_c (step t reads the pair of parity
+     * t & 1 - dw_c for even t - and writes the other).  With these, all four carry buffers are [3][B][T_in]: slot 0 the part
+     * a 32-position chunk computes for itself, slots 1 / 2 the parts reaching in from the chunk to the right / left. */
     const float *ctx_all; long s_ctx_step, s_ctx_item;
     float *dw_c2, *dwc_c2;
 } t2s_taco_bptt;

@@ -89,6 +89,22 @@ int t2s_bn_train(const float* x, const float* gamma, const float* beta, float ep
     return T2S_OK;
 }
 
+int t2s_bn_running_update(const float* mean, const float* var, float* running_mean, float* running_var,
+                          long long* num_batches_tracked, float momentum, long long n, int C, void* stream) {
+    if (!mean || !var || !running_mean || !running_var || C <= 0 || n <= 0 || !(momentum >= 0.f && momentum <= 1.f)) return T2S_EINVAL;
+    const float unbias = n > 1 ? (float)((double)n / (double)(n - 1)) : 1.f;
+    T2S_CHECK_HIP(t2s_launch_bn_running_update(mean, var, running_mean, running_var, num_batches_tracked, momentum, unbias, C,
+                                               (hipStream_t)stream));
+    return T2S_OK;
+}
+
+int t2s_zero_fill(void* p, size_t bytes, void* stream) {
+    if (!p || ((uintptr_t)p & 15)) return T2S_EINVAL;
+    if (bytes == 0) return T2S_OK;
+    T2S_CHECK_HIP(t2s_launch_zero_fill(p, bytes, (hipStream_t)stream));
+    return T2S_OK;
+}
+
 int t2s_taco_encoder_lstm(const float* gx, const float* whhT_fwd, const float* whhT_rev, const int* lengths, float* out,
                           int B, int T, int H, int T_out, float* gates_save, float* c_save, void* stream) {
     if (!gx || !whhT_fwd || !whhT_rev || !out || B <= 0 || T <= 0 || T_out <= 0 || T_out > T || 4 * H != 1024) return T2S_EINVAL;

@@ -13,10 +13,18 @@
 
 static __device__ __forceinline__ float sum3(const float* a, long sa, const float* b, long sb, const float* c, long sc,
                                               int item, int j) {
+    // three independent loads, then selects: written as `if (a) v += a[..]` three times, each load sat behind its own branch and
+    // a full wait - three (six, for two values per thread) round trips to memory at the head of every kernel that starts with it
+    const float* any = a ? a : (b ? b : c);
+    if (!any) return 0.f;
+    const long sany = a ? sa : (b ? sb : sc);
+    const float xa = (a ? a : any)[(size_t)item * (a ? sa : sany) + j];
+    const float xb = (b ? b : any)[(size_t)item * (b ? sb : sany) + j];
+    const float xc = (c ? c : any)[(size_t)item * (c ? sc : sany) + j];
     float v = 0.f;
-    if (a) v += a[(size_t)item * sa + j];
-    if (b) v += b[(size_t)item * sb + j];
-    if (c) v += c[(size_t)item * sc + j];
+    v += a ? xa : 0.f;
+    v += b ? xb : 0.f;
+    v += c ? xc : 0.f;
     return v;
 }
 
@@ -743,14 +751,16 @@ __global__ __launch_bounds__(256) void att_bwd_conv_mfma_kernel(const AttBwdArgs
 
 // ------------------------------------------------------------------------------------------------
 // The three parts above in ONE launch (attention_dim 128, 32 location filters, kernel <= 31, deferred d_memory).  What kept them
-// apart were two reductions across workgroups; both go away:
+// apart were two exchanges across workgroups; both go away:
 //   * softmax backward needs sdot = sum_t w[t] d_w[t] over the whole row.  With d_w[t] = mem[t] . d_ctx + carry[t] and the saved
 //     context ctx = sum_t w[t] mem[t]:  sdot = ctx . d_ctx + sum_t w[t] carry[t]  - 512 + T multiply-adds, no pass over memory;
-//   * the location-conv backward needs d_f on a halo of kernel/2 positions either side: a workgroup recomputes d_w, the features,
-//     the energies backward and d_f for its 32 positions + halo (64 rows: twice the matrix-core work, still ~1.5 us of MFMA).
-//     Reading the neighbours' carries while they are rewritten is avoided by a second pair of carry buffers (in / out by step).
-// Row r of the window <-> position t0 - pad + r; "own" rows are pad .. pad + 31.  Per decoder step this replaces 12 + 10.5 + 10.5 us
-// of dependent launches (profiles/r03_taco_timeline_bwd.md) and the d_w / d_f round trips through global memory.
+//   * the location-conv backward needs d_f on a halo of kernel/2 positions either side of a chunk.  Turned round: a workgroup
+//     scatters what ITS 32 rows of d_f contribute to the carries of the 32 + 2 pad positions they reach, into three slots per
+//     position - [0] the chunk's own part, [1] the part from the chunk to the right, [2] from the chunk to the left - and the
+//     next step's launch adds the slots that exist for a position (a fixed rule, a fixed order: bitwise reproducible, no
+//     atomics).  A first version recomputed d_w .. d_f on the halo instead: twice the loads per CU (250 KB at the ~50 GB/s a
+//     CU draws from L2) made its prologue 5 of 19 us (profiles/r03_att_bwd_fused_halo_stamps.txt).
+// Carry buffers are [3][B][T] and come in two sets: a step reads one and writes the other.
 #ifdef T2S_ATTF_STAMPS          // diagnostic build: phase boundaries of workgroup (0, 0), 100 MHz ticks (tools/attf_stamps.py)
 __device__ unsigned long long t2s_attf_stamps[16];
 #define ATTF_STAMP(i) if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) t2s_attf_stamps[i] = __builtin_amdgcn_s_memrealtime();
@@ -760,80 +770,75 @@ extern "C" int t2s_debug_read_attf_stamps(unsigned long long* host_out) {
 #else
 #define ATTF_STAMP(i)
 #endif
+// total carry at position t of batch row b: own slot + the neighbours' slots that exist for it
+static __device__ __forceinline__ float attf_carry(const float* c, size_t BT, size_t bt, int t, int T, int pad) {
+    const int l = t & (ATTB_CH - 1), t0 = t - l;
+    float v = c[bt];
+    if (l >= ATTB_CH - pad && t0 + ATTB_CH < T) v += c[BT + bt];
+    if (l < pad && t0 > 0) v += c[2 * BT + bt];
+    return v;
+}
 #define ATTF_SP 130
-#define ATTF_LDS_FLOATS (192 + 64 * 33 + 32 * 144 + 64 * ATTF_SP + 64 * 34 + 64 * 66 + 1024 + 3 * 64 + 16)
 __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) {
-    constexpr int AD = 128, F = 32, SP = ATTF_SP, SD = 34, SG = 66;
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    float* s_cat = s_dyn;                          // [2][96]    window of [w_prev ; wc_prev]: entry i <-> t0 - 2 pad + i
-    float* s_f = s_cat + 192;                      // [64][33]   F[row][f]
-    float* s_dT = s_f + 64 * 33;                   // [32][144]  D^T[f][a]
+    constexpr int AD = 128, F = 32, SP = ATTF_SP, SD = 34, SG = 34;
+    __shared__ __attribute__((aligned(16))) float s_all[128 + 64 * 48 + ATTB_CH * 33 + 32 * 144 + ATTB_CH * ATTF_SP + ATTB_CH * 34 + 1024 + 2 * ATTB_CH + 16];
+    float* s_cat = s_all;                          // [2][64]    window of [w_prev ; wc_prev]: entry i <-> t0 - pad + i
+    float* s_kb = s_cat + 128;                     // [64][48]   conv kernel as B operand [k = c * KS + j][f], rows >= 2 KS zero
+    float* s_g = s_kb;                             // [64][34]   G[m][row]    (after the features)
+    float* s_f = s_kb + 64 * 48;                   // [32][33]   F[row][f]
+    float* s_dT = s_f + ATTB_CH * 33;              // [32][144]  D^T[f][a]
     float* s_dn = s_dT;                            // [128][33]  D[a][f]      (after the energies)
-    float* s_dp = s_dT + 32 * 144;                 // [64][130]  d_pre[row][a]
-    float* s_df = s_dp + 64 * SP;                  // [64][34]   d_f[row][f]
-    float* s_kb = s_df + 64 * SD;                  // [64][48]   conv kernel as B operand [k = c * KS + j][f], rows >= 2 KS zero
-    float* s_g = s_kb;                             // [64][66]   G[m][row]    (after the features)
-    float* s_dctx = s_kb + 64 * SG;                // [<= 1024]
-    float* s_dw = s_dctx + 1024;                   // [64]
-    float* s_de = s_dw + 64;                       // [64]
-    float* s_w = s_de + 64;                        // [64]
-    float* s_red = s_w + 64;                       // [16]
+    float* s_dp = s_dT + 32 * 144;                 // [32][130]  d_pre[row][a]
+    float* s_df = s_dp + ATTB_CH * SP;             // [32][34]   d_f[row][f]
+    float* s_dctx = s_df + ATTB_CH * SD;           // [<= 1024]
+    float* s_dw = s_dctx + 1024;                   // [32]
+    float* s_de = s_dw + ATTB_CH;                  // [32]
+    float* s_red = s_de + ATTB_CH;                 // [16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    // batch element on blockIdx.x: workgroups go to the 8 XCDs round-robin by linear id, so the chunks of one batch element share
-    // an L2 and the halo rows of `memory` / `pmem` (read by two or three of them) come from HBM / MALL once
+    // batch element on blockIdx.x: workgroups go to the 8 XCDs round-robin by linear id, so the chunks of one batch element share an L2
     const int b = blockIdx.x, chunk = blockIdx.y, t0 = chunk * ATTB_CH;
     const int T = a.T, E = a.enc_dim, KS = a.loc_ks, pad = KS >> 1, K2 = 2 * KS;
     const int len = a.lengths ? a.lengths[b] : T;
-    const size_t slot = (size_t)b * gridDim.y + chunk;
-    const int tw0 = t0 - pad;                      // position of window row 0
+    const size_t slot = (size_t)b * gridDim.y + chunk, BT = (size_t)a.B * T;
     ATTF_STAMP(0)
-    // ---- loads: everything the kernel reads from global memory is requested here, in the order it is consumed ----
-    // d_ctx first (its three sources return before the 128 KB of memory rows requested next, so the LDS copy and the barrier do
-    // not wait for those); then the d_w operands: wave w takes window rows 8 w .. 8 w + 7, channels on lanes (registers for
-    // enc_dim 512, else a loop below)
-    float dctx_r[2];
+    // ---- loads: everything the kernel reads from global memory is requested here, unconditionally (clamped addresses, selects
+    //      afterwards) and before the first use of any of it: one round trip to memory, not one per dependent group ----
+    // (d_ctx sources: a null one reads the first non-null one and is dropped by a select - no branch between the loads)
+    const float* dany = a.dctx1 ? a.dctx1 : (a.dctx2 ? a.dctx2 : a.dctx3);
+    const long sany = a.dctx1 ? a.sc1 : (a.dctx2 ? a.sc2 : a.sc3);
+    float dsrc[2][3];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) dctx_r[h] = tid + 512 * h < E ? sum3(a.dctx1, a.sc1, a.dctx2, a.sc2, a.dctx3, a.sc3, b, tid + 512 * h) : 0.f;
+    for (int h = 0; h < 2; ++h) {
+        const int j = tid + 512 * h < E ? tid + 512 * h : 0;
+        dsrc[h][0] = (a.dctx1 ? a.dctx1 : dany)[(size_t)b * (a.dctx1 ? a.sc1 : sany) + j];
+        dsrc[h][1] = (a.dctx2 ? a.dctx2 : dany)[(size_t)b * (a.dctx2 ? a.sc2 : sany) + j];
+        dsrc[h][2] = (a.dctx3 ? a.dctx3 : dany)[(size_t)b * (a.dctx3 ? a.sc3 : sany) + j];
+    }
+    // d_w operands: wave w takes rows 4 w .. 4 w + 3, channels on lanes (registers for enc_dim 512, else a loop below)
     const bool e512 = E == 512;
-    f32x4 mrow[2][8];
+    f32x4 mrow[2][4];
     if (e512) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int t = tw0 + 8 * wave + r;
-                const int tc = t < 0 ? 0 : (t < T ? t : T - 1);          // clamped, unconditional load; rows outside [0, T) have d_e = 0
-                mrow[h][r] = *(const f32x4*)(a.memory + ((size_t)b * T + tc) * E + lane * 4 + 256 * h);
+            for (int r = 0; r < 4; ++r) {
+                const int t = t0 + 4 * wave + r;
+                mrow[h][r] = *(const f32x4*)(a.memory + ((size_t)b * T + (t < T ? t : T - 1)) * E + lane * 4 + 256 * h);
             }
     }
+    float ctx_r[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-        if (tid + 512 * h < E) {
-            s_dctx[tid + 512 * h] = dctx_r[h];
-            if (chunk == 0) a.dctx_out[(size_t)b * E + tid + 512 * h] = dctx_r[h];
-        }
-    for (int i = tid; i < 64 * 48; i += 512) s_kb[i] = 0.f;
-    // sdot = ctx . d_ctx + sum_t w[t] carry[t]: this thread's terms
-    float ctx_r[2], wc_r = 0.f;
+    for (int h = 0; h < 2; ++h) ctx_r[h] = a.ctx[(size_t)b * a.s_ctx + (tid + 512 * h < E ? tid + 512 * h : 0)];
+    // carries: position `tid` of the row (the sdot term) and position t0 + (tid & 31) (the chunk's rows), three slots each
+    const int ta = tid < T ? tid : T - 1, tb = t0 + (tid & 31) < T ? t0 + (tid & 31) : T - 1;
+    const size_t bta = (size_t)b * T + ta, btb = (size_t)b * T + tb;
+    const float wa = a.w_cur[(size_t)b * a.s_wcur + ta], wb = a.w_cur[(size_t)b * a.s_wcur + tb];
+    float ca[2][3], cb[2][3];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) ctx_r[h] = tid + 512 * h < E ? a.ctx[(size_t)b * a.s_ctx + tid + 512 * h] : 0.f;
-    for (int t = tid; t < T; t += 512)
-        wc_r += a.w_cur[(size_t)b * a.s_wcur + t] * (a.dw_carry[(size_t)b * T + t] + a.dwc_carry[(size_t)b * T + t]);
-    // window row `tid` (threads 0-63): attention weight and carries
-    float row_w = 0.f, row_c = 0.f;
-    if (tid < 64) {
-        const int t = tw0 + tid;
-        if (t >= 0 && t < T) {
-            row_w = a.w_cur[(size_t)b * a.s_wcur + t];
-            row_c = a.dw_carry[(size_t)b * T + t] + a.dwc_carry[(size_t)b * T + t];
-        }
-    }
-    for (int i = tid; i < 2 * 96; i += 512) {
-        const int c = i >= 96, j = i - c * 96;
-        const int t = tw0 - pad + j;
-        const float* src = c ? a.wc_prev : a.w_prev;
-        s_cat[i] = (src && t >= 0 && t < T) ? src[(size_t)b * (c ? a.s_wcprev : a.s_wprev) + t] : 0.f;
+    for (int k = 0; k < 3; ++k) {
+        ca[0][k] = a.dw_carry[k * BT + bta]; ca[1][k] = a.dwc_carry[k * BT + bta];
+        cb[0][k] = a.dw_carry[k * BT + btb]; cb[1][k] = a.dwc_carry[k * BT + btb];
     }
     float rk[4];
 #pragma unroll
@@ -846,10 +851,86 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
     for (int j = 0; j < 8; ++j) {                  // D [a][f], 4096 floats, coalesced
         const int i = tid + j * 512;
         rd[j] = a.w_loc_dense[i];
+    }
+    const int ach = 16 * wave + lr;                // this lane's attention channel in the energies / dD stages
+    const float qv = a.q[(size_t)b * AD + ach], vv = a.w_v[ach];
+    float pm[2][4], dpm[2][4];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = t0 + 16 * tt + 4 * lq + r;
+            const size_t po = ((size_t)b * T + (t < T ? t : T - 1)) * AD + ach;
+            pm[tt][r] = a.pmem[po];
+            dpm[tt][r] = a.d_pmem[po];
+        }
+    float dD_old[2][4];
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dD_old[ft][r] = a.dD_part[slot * AD * F + (size_t)(16 * ft + 4 * lq + r) * AD + ach];
+    const float dv_old = a.dv_part[slot * AD + ach];
+    // the conv-backward tiles of this wave: G rows m = 16 (wave >> 1) + lr (all), kernel-gradient filters 16 (wave & 1) ..
+    const int mcol = 16 * (wave >> 1) + lr, kft = wave & 1;
+    float dK_old[4], ak[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dK_old[r] = mcol < K2 ? a.dK_part[slot * F * K2 + (size_t)(16 * kft + 4 * lq + r) * K2 + mcol] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ak[u] = mcol < K2 ? a.w_loc_conv[(4 * u + lq) * K2 + mcol] : 0.f;       // G stage: A[row m][k = f]
+    // (last: hipcc keeps this one behind a branch with a full wait, which here coincides with the wait for everything)
+    float cat_r;
+    bool cat_ok;
+    {
+        const int c = (tid >> 6) & 1, j = tid & 63;
+        const int t = t0 - pad + j;
+        const float* src = c ? a.wc_prev : a.w_prev;                 // null at decoder step 0: read w_cur, drop it
+        const long ss = src ? (c ? a.s_wcprev : a.s_wprev) : a.s_wcur;
+        cat_r = (src ? src : a.w_cur)[(size_t)b * ss + (t < 0 ? 0 : (t < T ? t : T - 1))];
+        cat_ok = src && j < ATTB_CH + KS - 1 && t >= 0 && t < T;     // (applied at the LDS store: no write to a register in flight)
+    }
+    // ---- first uses ----
+    float dctx_r[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float v = 0.f;                              // (same order of additions as sum3)
+        v += a.dctx1 ? dsrc[h][0] : 0.f;
+        v += a.dctx2 ? dsrc[h][1] : 0.f;
+        v += a.dctx3 ? dsrc[h][2] : 0.f;
+        dctx_r[h] = v;
+        if (tid + 512 * h < E) s_dctx[tid + 512 * h] = v;
+    }
+    for (int i = tid; i < 64 * 48; i += 512) s_kb[i] = 0.f;
+    if (tid < 128) s_cat[tid] = cat_ok ? cat_r : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = tid + j * 512;
         s_dT[(i & 31) * 144 + (i >> 5)] = rd[j];
+    }
+    // total carry = own slot + the neighbours' slots that exist for the position
+    float wc_r = 0.f, row_w = 0.f, row_c = 0.f, row_dwc = 0.f;
+    {
+        const int la = ta & (ATTB_CH - 1), lb = tb & (ATTB_CH - 1);
+        const bool ra = la >= ATTB_CH - pad && ta - la + ATTB_CH < T, lfa = la < pad && ta - la > 0;
+        const bool rb = lb >= ATTB_CH - pad && tb - lb + ATTB_CH < T, lfb = lb < pad && tb - lb > 0;
+        const float sa = (ca[0][0] + (ra ? ca[0][1] : 0.f) + (lfa ? ca[0][2] : 0.f)) + (ca[1][0] + (ra ? ca[1][1] : 0.f) + (lfa ? ca[1][2] : 0.f));
+        if (tid < T) wc_r = wa * sa;
+        for (int t = tid + 512; t < T; t += 512)    // (rows longer than 512)
+            wc_r += a.w_cur[(size_t)b * a.s_wcur + t] *
+                    (attf_carry(a.dw_carry, BT, (size_t)b * T + t, t, T, pad) + attf_carry(a.dwc_carry, BT, (size_t)b * T + t, t, T, pad));
+        if (tid < ATTB_CH && t0 + tid < T) {
+            row_w = wb;
+            row_dwc = cb[1][0] + (rb ? cb[1][1] : 0.f) + (lfb ? cb[1][2] : 0.f);
+            row_c = (cb[0][0] + (rb ? cb[0][1] : 0.f) + (lfb ? cb[0][2] : 0.f)) + row_dwc;
+        }
     }
     ATTF_STAMP(1)
     __syncthreads();                               // s_dctx, s_kb zeros
+    ATTF_STAMP(2)
+    if (chunk == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (tid + 512 * h < E) a.dctx_out[(size_t)b * E + tid + 512 * h] = dctx_r[h];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int i = tid + j * 512;
@@ -858,37 +939,32 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
             s_kb[k * 48 + f] = rk[j];
         }
     }
-    ATTF_STAMP(2)
-    // ---- d_w of the 64 window rows (without the carries) ----
+    // ---- d_w of the chunk's 32 rows (without the carries) ----
     {
-        float acc[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
         if (e512) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f32x4 dc = *(const f32x4*)&s_dctx[lane * 4 + 256 * h];
 #pragma unroll
-                for (int r = 0; r < 8; ++r)
+                for (int r = 0; r < 4; ++r)
                     acc[r] += mrow[h][r][0] * dc[0] + mrow[h][r][1] * dc[1] + mrow[h][r][2] * dc[2] + mrow[h][r][3] * dc[3];
             }
         } else {
             for (int c = lane * 4; c < E; c += 256) {
                 const f32x4 dc = *(const f32x4*)&s_dctx[c];
-                f32x4 m[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int t = tw0 + 8 * wave + r;
-                    m[r] = (t >= 0 && t < T) ? *(const f32x4*)(a.memory + ((size_t)b * T + t) * E + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < 4; ++r) {
+                    const int t = t0 + 4 * wave + r;
+                    const f32x4 m = *(const f32x4*)(a.memory + ((size_t)b * T + (t < T ? t : T - 1)) * E + c);
+                    acc[r] += m[0] * dc[0] + m[1] * dc[1] + m[2] * dc[2] + m[3] * dc[3];
                 }
-#pragma unroll
-                for (int r = 0; r < 8; ++r) acc[r] += m[r][0] * dc[0] + m[r][1] * dc[1] + m[r][2] * dc[2] + m[r][3] * dc[3];
             }
         }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < 4; ++r) {
             const float v = attb_wave_sum(acc[r]);
-            if (lane == 0) s_dw[8 * wave + r] = v;
+            if (lane == 0) s_dw[4 * wave + r] = v;
         }
         float part = wc_r;
 #pragma unroll
@@ -898,46 +974,15 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
         if (lane == 0) s_red[wave] = part;
     }
     ATTF_STAMP(3)
-    // operands of the later stages: requested now (the d_w registers are free), consumed after the next barriers
-    const int ach = 16 * wave + lr;                // this lane's attention channel in the energies / dD stages
-    const float qv = a.q[(size_t)b * AD + ach], vv = a.w_v[ach];
-    float pm[4][4], dpm[4][4];
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * tt + 4 * lq + r, t = tw0 + row;
-            const size_t po = ((size_t)b * T + (t < 0 ? 0 : (t < T ? t : T - 1))) * AD + ach;     // clamped, unconditional loads
-            pm[tt][r] = a.pmem[po];
-            if (row >= pad && row < pad + ATTB_CH) dpm[tt][r] = a.d_pmem[po];      // read-modify-write on own rows only
-            else dpm[tt][r] = 0.f;
-        }
-    float dD_old[2][4];
-#pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dD_old[ft][r] = a.dD_part[slot * AD * F + (size_t)(16 * ft + 4 * lq + r) * AD + ach];
-    const float dv_old = a.dv_part[slot * AD + ach];
-    // the kernel-gradient tile of this wave: filters 16 (wave & 1) .., columns m = 16 (wave >> 1) + lr
-    const int mcol = 16 * (wave >> 1) + lr, kft = wave & 1;
-    float dK_old[4], ak[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dK_old[r] = mcol < K2 ? a.dK_part[slot * F * K2 + (size_t)(16 * kft + 4 * lq + r) * K2 + mcol] : 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) ak[u] = mcol < K2 ? a.w_loc_conv[(4 * u + lq) * K2 + mcol] : 0.f;       // G stage: A[row m][k = f]
-    // carries: output (c, tl) = tid >> 3
-    const int co = tid >> 8, ctl = (tid >> 3) & 31;
-    const float dwc_old = (co == 1 && (tid & 7) == 0 && t0 + ctl < T) ? a.dwc_carry[(size_t)b * T + t0 + ctl] : 0.f;
-    ATTF_STAMP(4)
     __syncthreads();                               // s_kb, s_dw, s_red
-    if (tid < 64) {
+    ATTF_STAMP(4)
+    if (tid < ATTB_CH) {
         const float sdot = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7]));
-        const int t = tw0 + tid;
-        s_de[tid] = (t >= 0 && t < T && t < len) ? row_w * (s_dw[tid] + row_c - sdot) : 0.f;
+        const int t = t0 + tid;
+        s_de[tid] = (t < T && t < len) ? row_w * (s_dw[tid] + row_c - sdot) : 0.f;
     }
-    ATTF_STAMP(5)
-    // ---- location features of the 64 rows: tile (wave >> 1, wave & 1) ----
-    {
+    // ---- location features: 4 tiles (t tile, f tile) on waves 0-3 ----
+    if (wave < 4) {
         const int tt = wave >> 1, ft = wave & 1;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         float av[16], bv[16];
@@ -946,7 +991,7 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
             const int k = 4 * u + lq;
             const int kc = k < K2 ? k : 0;         // (B rows >= 2 KS are zero)
             const int c = kc >= KS ? 1 : 0, j = kc - c * KS;
-            av[u] = s_cat[c * 96 + 16 * tt + lr + j];
+            av[u] = s_cat[c * 64 + 16 * tt + lr + j];
             bv[u] = s_kb[k * 48 + 16 * ft + lr];
         }
 #pragma unroll
@@ -954,16 +999,17 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_f[(16 * tt + 4 * lq + r) * 33 + 16 * ft + lr] = acc[r];
     }
-    ATTF_STAMP(6)
+    ATTF_STAMP(5)
     __syncthreads();                               // s_f, s_de
-    // ---- energies backward: P = F D^T for channels `ach`, four row tiles ----
+    ATTF_STAMP(6)
+    // ---- energies backward: P = F D^T for channels `ach`, two row tiles ----
     {
         float bT[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) bT[u] = s_dT[(4 * u + lq) * 144 + ach];
         float dq = 0.f, dvs = 0.f;
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
+        for (int tt = 0; tt < 2; ++tt) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             float av[8];
 #pragma unroll
@@ -972,16 +1018,14 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
             for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bT[u], acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * tt + 4 * lq + r, t = tw0 + row;
+                const int row = 16 * tt + 4 * lq + r, t = t0 + row;
                 const float th = tanhf(acc[r] + qv + pm[tt][r]);
                 const float de = s_de[row];        // 0 outside [0, min(T, len))
                 const float dp = de * vv * (1.f - th * th);
                 s_dp[row * SP + ach] = dp;
-                if (row >= pad && row < pad + ATTB_CH && t < T) {          // own rows (t >= 0 there)
-                    dq += dp;
-                    dvs += de * th;
-                    a.d_pmem[((size_t)b * T + t) * AD + ach] = dpm[tt][r] + dp;
-                }
+                dq += dp;
+                dvs += de * th;
+                if (t < T) a.d_pmem[((size_t)b * T + t) * AD + ach] = dpm[tt][r] + dp;
             }
         }
         dq += __shfl_xor(dq, 16, 64);
@@ -1000,98 +1044,103 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
         const int i = tid + j * 512;
         s_dn[(i >> 5) * 33 + (i & 31)] = rd[j];
     }
-    // ---- dD^T[f][a] += sum over own rows F[row][f] d_pre[row][a] ----
+    // ---- dD^T[f][a] += sum over the rows F[row][f] d_pre[row][a] ----
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        float av[12], bv[12];                      // own rows lie in 4 u0 .. 4 u0 + 47 for any pad (kernel <= 31)
-        const int u0 = pad >> 2;
+        float av[8], bv[8];
 #pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            const int row = 4 * (u0 + u) + lq;
-            const bool own = row >= pad && row < pad + ATTB_CH;
-            av[u] = own ? s_f[row * 33 + 16 * ft + lr] : 0.f;
-            bv[u] = own ? s_dp[row * SP + ach] : 0.f;
+        for (int u = 0; u < 8; ++u) {
+            av[u] = s_f[(4 * u + lq) * 33 + 16 * ft + lr];
+            bv[u] = s_dp[(4 * u + lq) * SP + ach];
         }
 #pragma unroll
-        for (int u = 0; u < 12; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             a.dD_part[slot * AD * F + (size_t)(16 * ft + 4 * lq + r) * AD + ach] = dD_old[ft][r] + acc[r];
     }
     ATTF_STAMP(8)
     __syncthreads();                               // s_dn
-    // ---- d_f[row][f] = d_pre D: tile (wave >> 1, wave & 1), K = 128 ----
+    // ---- d_f[row][f] = d_pre D: tile (wave >> 1 & 1, wave & 1), K = 128 split over the two wave groups (waves 4-7: a >= 64) ----
     {
-        const int tt = wave >> 1, ft = wave & 1;
+        const int tt = (wave >> 1) & 1, ft = wave & 1, h = wave >> 2;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float av[16], bv[16];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float av[16], bv[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int k = 64 * h + 4 * u + lq;
-                av[u] = s_dp[(16 * tt + lr) * SP + k];
-                bv[u] = s_dn[k * 33 + 16 * ft + lr];
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        for (int u = 0; u < 16; ++u) {
+            const int k = 64 * h + 4 * u + lq;
+            av[u] = s_dp[(16 * tt + lr) * SP + k];
+            bv[u] = s_dn[k * 33 + 16 * ft + lr];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_df[(16 * tt + 4 * lq + r) * SD + 16 * ft + lr] = acc[r];
+        for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        if (h == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_df[(16 * tt + 4 * lq + r) * SD + 16 * ft + lr] = acc[r];
+        }
+        __syncthreads();                           // the upper half's partial sums
+        if (h == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_df[(16 * tt + 4 * lq + r) * SD + 16 * ft + lr] += acc[r];
+        }
     }
     ATTF_STAMP(9)
     __syncthreads();                               // s_df
-    // ---- location-conv backward.  G[m][row] = sum_f K[f][m] d_f[row][f]: rows m = 16 (wave >> 1) .., row tiles 2 (wave & 1) + {0, 1} ----
+    // ---- location-conv backward.  G[m][row] = sum_f K[f][m] d_f[row][f]: rows m = 16 (wave >> 1) .., row tile wave & 1 ----
     {
+        const int nt = wave & 1;
+        float bv[8];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int nt = 2 * (wave & 1) + i;
-            float bv[8];
+        for (int u = 0; u < 8; ++u) bv[u] = s_df[(16 * nt + lr) * SD + 4 * u + lq];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 8; ++u) bv[u] = s_df[(16 * nt + lr) * SD + 4 * u + lq];
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ak[u], bv[u], acc, 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ak[u], bv[u], acc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s_g[(16 * (wave >> 1) + 4 * lq + r) * SG + 16 * nt + lr] = acc[r];
-        }
-        // kernel gradient: dK[f][m] += sum_tl d_f[tl + pad][f] cat[c][tl + j]   (own rows; window entry tl + j + pad)
+        for (int r = 0; r < 4; ++r) s_g[(16 * (wave >> 1) + 4 * lq + r) * SG + 16 * nt + lr] = acc[r];
+        // kernel gradient: dK[f][m] += sum_tl d_f[tl][f] cat[c][tl + j]
         const int mc = mcol < K2 ? mcol : 0;
         const int c = mc >= KS ? 1 : 0, j = mc - c * KS;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        float av[8], bv[8];
+        f32x4 acck = {0.f, 0.f, 0.f, 0.f};
+        float av[8], bk[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            av[u] = s_df[(4 * u + lq + pad) * SD + 16 * kft + lr];
-            bv[u] = s_cat[c * 96 + 4 * u + lq + j + pad];
+            av[u] = s_df[(4 * u + lq) * SD + 16 * kft + lr];
+            bk[u] = s_cat[c * 64 + 4 * u + lq + j];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        for (int u = 0; u < 8; ++u) acck = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bk[u], acck, 0, 0, 0);
         if (mcol < K2)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                a.dK_part[slot * F * K2 + (size_t)(16 * kft + 4 * lq + r) * K2 + mcol] = dK_old[r] + acc[r];
+                a.dK_part[slot * F * K2 + (size_t)(16 * kft + 4 * lq + r) * K2 + mcol] = dK_old[r] + acck[r];
     }
     ATTF_STAMP(10)
     __syncthreads();                               // s_g
-    // ---- carries for step t - 1: 64 outputs x 8 threads (4 taps each) ----
+    // ---- what the chunk's rows contribute to the carries of step t - 1: positions q <-> t0 - pad + q, q < 32 + 2 pad; output
+    //      (c, q) on 4 threads (8 taps each):  P[c][q] = sum_j G[(c, j)][q - j] over the rows 0 <= q - j < 32 ----
     {
-        const int o = tid >> 3, jg = tid & 7;
-        const int c = o >> 5, tl = o & 31;
+        const int o = tid >> 2, jg = tid & 3;
+        const int c = o >= 64, q = o - 64 * c;      // (o < 128; q < 32 + 2 pad <= 62 used)
         float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = jg * 4 + i;
-            if (j < KS) acc += s_g[(c * KS + j) * SG + tl - j + 2 * pad];
+        for (int i = 0; i < 8; ++i) {
+            const int j = jg * 8 + i, row = q - j;
+            if (j < KS && row >= 0 && row < ATTB_CH) acc += s_g[(c * KS + j) * SG + row];
         }
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
-        const int tp = t0 + tl;
-        if (jg == 0 && tp < T) {
-            if (c == 0) a.dw_carry_out[(size_t)b * T + tp] = acc;
-            else a.dwc_carry_out[(size_t)b * T + tp] = dwc_old + acc;
+        // the running dwc total of the chunk's own positions sits in threads 0-31 (row_dwc): own-slot threads fetch it by shuffle
+        // within... (different waves) -> through LDS
+        if (tid < ATTB_CH) s_dw[tid] = row_dwc;
+        __syncthreads();
+        const int tp = t0 - pad + q;
+        if (jg == 0 && q < ATTB_CH + 2 * pad && tp >= 0 && tp < T) {
+            float* dst = c ? a.dwc_carry_out : a.dw_carry_out;
+            const size_t bt = (size_t)b * T + tp;
+            if (q < pad) dst[BT + bt] = acc;                                     // reaches the chunk to the left: its slot [1]
+            else if (q >= pad + ATTB_CH) dst[2 * BT + bt] = acc;                // the chunk to the right: its slot [2]
+            else dst[bt] = c ? s_dw[q - pad] + acc : acc;                       // own slot (dwc: + the running total)
         }
     }
     ATTF_STAMP(11)
@@ -1131,12 +1180,8 @@ bool t2s_att_bwd_fused_ok(const AttBwdArgs& a) {
 }
 hipError_t t2s_launch_att_bwd_fused(const AttBwdArgs& a, hipStream_t stream) {
     if (!t2s_att_bwd_fused_ok(a)) return hipErrorInvalidValue;
-    constexpr int lds = ATTF_LDS_FLOATS * (int)sizeof(float);
-    static std::atomic<unsigned long long> attr_mask{0};
-    const hipError_t e = t2s_raise_lds_limit((const void*)att_bwd_fused_kernel, lds, attr_mask);
-    if (e != hipSuccess) return e;
     const dim3 grid(a.B, (a.T + ATTB_CH - 1) / ATTB_CH);
-    hipLaunchKernelGGL(att_bwd_fused_kernel, grid, dim3(512), lds, stream, a);
+    hipLaunchKernelGGL(att_bwd_fused_kernel, grid, dim3(512), 0, stream, a);
     return hipGetLastError();
 }
 hipError_t t2s_launch_att_bwd(const AttBwdArgs& a, hipStream_t stream) {

@@ -107,3 +107,6 @@ hipError_t t2s_launch_bn_train(const float* x, const float* gamma, const float* 
                                const unsigned char* mask, float mask_scale, int B, int C, int T, int Lp, int halo,
                                float* mean, float* var, unsigned short* O_hi, unsigned short* O_lo, float* out_f32,
                                hipStream_t stream);
+hipError_t t2s_launch_bn_running_update(const float* mean, const float* var, float* running_mean, float* running_var,
+                                        long long* num_batches_tracked, float momentum, float unbias, int C, hipStream_t stream);
+hipError_t t2s_launch_zero_fill(void* p, size_t bytes, hipStream_t stream);

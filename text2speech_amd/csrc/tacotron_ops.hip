@@ -1421,6 +1421,38 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
         var[c] = (float)(q - m * m);
     }
 }
+// nn.BatchNorm1d's training-mode bookkeeping: running = (1 - momentum) running + momentum batch (the variance unbiased, n / (n - 1)),
+// num_batches_tracked += 1 - one launch instead of six [C]-sized eager operators per layer
+__global__ void bn_running_update_kernel(const float* mean, const float* var, float* running_mean, float* running_var,
+                                         long long* num_batches_tracked, float momentum, float unbias, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        running_mean[c] = running_mean[c] * (1.f - momentum) + momentum * mean[c];
+        running_var[c] = running_var[c] * (1.f - momentum) + momentum * (var[c] * unbias);
+    }
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+}
+hipError_t t2s_launch_bn_running_update(const float* mean, const float* var, float* running_mean, float* running_var,
+                                        long long* num_batches_tracked, float momentum, float unbias, int C, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, mean, var, running_mean,
+                       running_var, num_batches_tracked, momentum, unbias, C);
+    return hipGetLastError();
+}
+// clears n16 16-byte pieces (+ tail bytes): the one fill of a step's accumulator arena
+__global__ void zero_fill_kernel(uint4* p, size_t n16, unsigned char* tail, int ntail) {
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+hipError_t t2s_launch_zero_fill(void* p, size_t bytes, hipStream_t stream) {
+    const size_t n16 = bytes / 16;
+    const int ntail = (int)(bytes - n16 * 16);
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint4*)p, n16, (unsigned char*)p + n16 * 16, ntail);
+    return hipGetLastError();
+}
 // y = act((x - mean) / sqrt(var + eps) * gamma + beta) * mask * mask_scale -> planes (and optional f32 copy)
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act,

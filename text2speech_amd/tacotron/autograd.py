@@ -80,6 +80,13 @@ class _Bwd:
         self.leases = []            # buffers of this backward pass, back in the engine's pool when it is released
         self.zero_bias = pool_take(eng.pool, self.leases, "zero_bias", (8192,), torch.float32, self.dev, zero_once=True)
         self._seq = 0
+        # accumulators / carries of this pass come out of one arena cleared by ONE launch; its size is what the previous pass of
+        # this engine asked for (the first pass, and any request that does not fit, falls back to a fill per buffer)
+        self._za, self._za_off, self._za_need = None, 0, 0
+        cap = getattr(eng, "zero_arena_elems", 0)
+        if cap:
+            self._za = pool_take(eng.pool, self.leases, "zero_arena", (cap,), torch.float32, self.dev)
+            _lib.call("t2s_zero_fill", _p(self._za), cap * 4, self.st)
 
     def new(self, *shape, tag=None):
         """f32 scratch every element of which its producer writes.  tag: take it from the engine's pool (large buffers)."""
@@ -88,8 +95,21 @@ class _Bwd:
         return torch.empty(*shape, dtype=torch.float32, device=self.dev)
 
     def zeros(self, *shape):
-        """f32 scratch that must START at zero (accumulators, carries): cleared every step."""
+        """f32 scratch that must START at zero (accumulators, carries): cleared every step.  Never handed out as a gradient."""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = _ru(max(n, 1), 64)                   # 256-byte granules
+        self._za_need += n_al
+        if self._za is not None and self._za_off + n_al <= self._za.numel():
+            t = self._za[self._za_off:self._za_off + n].view(*shape)
+            self._za_off += n_al
+            return t
         return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+
+    def close(self):
+        """Remember the arena size this pass needed (the next pass of this engine allocates it)."""
+        self.eng.zero_arena_elems = max(getattr(self.eng, "zero_arena_elems", 0), self._za_need)
 
     def bf(self, *shape, tag=None):
         """bf16 operand planes.  Their producers write the valid region and leave padding (halo rows, rows / columns / K-blocks
@@ -279,8 +299,11 @@ class _Bwd:
         dg_d, dg_a = self.new(T, B, 4 * D, tag="bptt_dg_d"), self.new(T, B, 4 * A, tag="bptt_dg_a")
         dq_all = self.new(T, B, ad, tag="bptt_dq_all")
         dc_d, dc_a = self.zeros(B, D), self.zeros(B, A)
-        dw_c, dwc_c = self.zeros(B, T_in), self.zeros(B, T_in)
-        dw_c2, dwc_c2 = self.zeros(B, T_in), self.zeros(B, T_in)      # second carry pair: the one-launch attention backward
+        # carries of the attention weights: [3][B][T_in] (own part + the parts reaching in from the neighbouring 32-position
+        # chunks) in two sets - the one-launch attention backward reads one and writes the other; the three-launch form works
+        # in place on the first [B][T_in] of dw_c / dwc_c
+        dw_c, dwc_c = self.zeros(3, B, T_in), self.zeros(3, B, T_in)
+        dw_c2, dwc_c2 = self.zeros(3, B, T_in), self.zeros(3, B, T_in)
         d_pmem, d_memory = self.zeros(B, T_in, ad), self.zeros(B, T_in, E)
         nch = (T_in + 31) // 32                     # partial parameter gradients: one slot per (batch element, 32-position chunk)
         dD_p, dK_p, dv_p = self.zeros(B * nch, ad * F_), self.zeros(B * nch, F_ * 2 * KS), self.zeros(B * nch, ad)
@@ -388,6 +411,7 @@ class _TacotronFn(torch.autograd.Function):
             grads = bw.run(g_mel, g_mel_post, g_gate)
             from .autograd_encoder import encoder_backward
             encoder_backward(bw, bw.d_memory)
+            bw.close()
         outs = []
         for p in ctx.params:
             g = grads.get(id(p))

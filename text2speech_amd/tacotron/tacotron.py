@@ -276,6 +276,18 @@ class _TacoEngine:
         return P
 
     # ------------------------------------------------------------------ building blocks
+    def _planes(self, shape, dev, leases=None, tag=None):
+        """A (hi, lo) pair of bf16 operand planes whose padding (halo rows, channels past the operand's extent) must read as
+        zero.  The kernels that fill them write the whole valid region whatever the data, so inside a training step (leases = the
+        step's lease list) they come from the engine's pool, zeroed once when created; otherwise fresh zero-filled tensors."""
+        if leases is None or tag is None:
+            hi = torch.zeros(*shape, dtype=torch.bfloat16, device=dev)
+            return hi, torch.zeros_like(hi)
+        if self.pool is None:
+            self.pool = {}
+        return (pool_take(self.pool, leases, tag + "_h", shape, torch.bfloat16, dev, zero_once=True),
+                pool_take(self.pool, leases, tag + "_l", shape, torch.bfloat16, dev, zero_once=True))
+
     def _conv(self, layer, Xh, Xl, B, L, Lp, halo, act, out_planes=True, out_f32=None, f32_cl=0):
         dev = Xh.device
         oc = -(-layer["Cout"] // 32)
@@ -296,22 +308,21 @@ class _TacoEngine:
         E = m.embedding.embedding_dim
         halo = 2
         st = _lib.current_stream()
+        leases = None if save is None else save.setdefault("_leases", [])
         if embedded is not None:
             dev = embedded.device
             B, _, T = embedded.shape
             Lp = _lib.plane_rows(T, halo)
             ids64 = None
             emb32 = embedded.detach().to(torch.float32).contiguous()
-            Xh = torch.zeros(B, -(-E // 32), Lp, 32, dtype=torch.bfloat16, device=dev)
-            Xl = torch.zeros_like(Xh)
+            Xh, Xl = self._planes((B, -(-E // 32), Lp, 32), dev, leases, "enc_x")
             _lib.call("t2s_f32_to_planes", _lib.ptr(emb32), B, E, T, Lp, halo, _lib.ptr(Xh), _lib.ptr(Xl), st)
         else:
             dev = ids.device
             B, T = ids.shape
             Lp = _lib.plane_rows(T, halo)
             ids64 = ids.to(torch.int64).contiguous()
-            Xh = torch.zeros(B, -(-E // 32), Lp, 32, dtype=torch.bfloat16, device=dev)
-            Xl = torch.zeros_like(Xh)
+            Xh, Xl = self._planes((B, -(-E // 32), Lp, 32), dev, leases, "enc_x")
             _lib.call("t2s_embed_planes", _lib.ptr(ids64), _lib.ptr(P["emb"]), B, T, E, m.embedding.num_embeddings, Lp, halo,
                       _lib.ptr(Xh), _lib.ptr(Xl), st)
         if m.training:
@@ -319,7 +330,8 @@ class _TacoEngine:
             for i, (seq, layer) in enumerate(zip(m.encoder.convolutions, P["enc_convs_plain"])):
                 mk = self._drop(None if given is None else given[i], (B, layer["Cout"], T), 0.5, dev, seed + 101 + i)
                 Xh, Xl = self._conv_bn_train(seq, layer, Xh, Xl, B, T, Lp, halo, 1, mk,
-                                             save=None if save is None else save.setdefault("enc_convs", []))
+                                             save=None if save is None else save.setdefault("enc_convs", []),
+                                             leases=leases, tag="enc_conv%d" % i)
         else:
             for layer in P["enc_convs"]:
                 Xh, Xl = self._conv(layer, Xh, Xl, B, T, Lp, halo, 1)
@@ -334,8 +346,11 @@ class _TacoEngine:
         memory = torch.empty(B, T_out, 2 * H, dtype=torch.float32, device=dev)
         gsave = csave = None
         if save is not None:
-            gsave = torch.zeros(B, T, 2, 4 * H, dtype=torch.float32, device=dev)
-            csave = torch.zeros(B, T, 2, H, dtype=torch.float32, device=dev)
+            # (the recurrence writes, and its backward reads, the steps below each entry's length only: no clearing)
+            if self.pool is None:
+                self.pool = {}
+            gsave = pool_take(self.pool, leases, "enc_gsave", (B, T, 2, 4 * H), torch.float32, dev)
+            csave = pool_take(self.pool, leases, "enc_csave", (B, T, 2, H), torch.float32, dev)
             save.update(enc_gates=gsave, enc_c=csave)
         _lib.call("t2s_taco_encoder_lstm", _lib.ptr(gx), _lib.ptr(P["whhT"][0][0]), _lib.ptr(P["whhT"][1][0]),
                   _lib.ptr(len32), _lib.ptr(memory), B, T, H, T_out, _lib.ptr(gsave), _lib.ptr(csave), st)
@@ -394,8 +409,8 @@ class _TacoEngine:
         Lp = _lib.plane_rows(T, halo)
         dev = mel.device
         mel = mel.contiguous()
-        Xh = torch.zeros(B, -(-C // 32), Lp, 32, dtype=torch.bfloat16, device=dev)
-        Xl = torch.zeros_like(Xh)
+        leases = None if save is None else save.setdefault("_leases", [])
+        Xh, Xl = self._planes((B, -(-C // 32), Lp, 32), dev, leases, "post_x")
         _lib.call("t2s_f32_to_planes", _lib.ptr(mel), B, C, T, Lp, halo, _lib.ptr(Xh), _lib.ptr(Xl), _lib.current_stream())
         n = len(P["post_convs"])
         out = torch.empty(B, C, T, dtype=torch.float32, device=dev)
@@ -405,7 +420,8 @@ class _TacoEngine:
                 mk = self._drop(None if given is None else given[i], (B, layer["Cout"], T), 0.5, dev, seed + 201 + i)
                 sv = None if save is None else save.setdefault("post_convs", [])
                 if i < n - 1:
-                    Xh, Xl = self._conv_bn_train(seq, layer, Xh, Xl, B, T, Lp, halo, 2, mk, save=sv)
+                    Xh, Xl = self._conv_bn_train(seq, layer, Xh, Xl, B, T, Lp, halo, 2, mk, save=sv, leases=leases,
+                                                 tag="post_conv%d" % i)
                 else:
                     self._conv_bn_train(seq, layer, Xh, Xl, B, T, Lp, halo, 0, mk, want_planes=False, out_f32=out, save=sv)
             return out
@@ -446,7 +462,8 @@ class _TacoEngine:
                   _lib.ptr(A_hi), _lib.ptr(A_lo), _lib.ptr(bias), 0, _lib.current_stream())
         return dict(A_hi=A_hi, A_lo=A_lo, bias=bias, Mpad=Mpad, Cin=Cin, Cout=O, taps=Kt, keep=(w, cb))
 
-    def _conv_bn_train(self, seq, layer, Xh, Xl, B, T, Lp, halo, act, mask, want_planes=True, out_f32=None, save=None):
+    def _conv_bn_train(self, seq, layer, Xh, Xl, B, T, Lp, halo, act, mask, want_planes=True, out_f32=None, save=None,
+                       leases=None, tag=None):
         """conv -> BatchNorm1d with batch statistics (+ running-stat update, as nn.BatchNorm1d.train() does) ->
         activation -> dropout mask (reference tacotron.py:193-194; modules.py:131-137)."""
         bn = seq[1]
@@ -458,17 +475,14 @@ class _TacoEngine:
         var = torch.empty(C, dtype=torch.float32, device=dev)
         Oh = Ol = None
         if want_planes:
-            Oh = torch.zeros(B, -(-C // 32), Lp, 32, dtype=torch.bfloat16, device=dev)
-            Ol = torch.zeros_like(Oh)
+            Oh, Ol = self._planes((B, -(-C // 32), Lp, 32), dev, leases, tag)
         g, be = _f32(bn.weight), _f32(bn.bias)
         _lib.call("t2s_bn_train", _lib.ptr(y), _lib.ptr(g), _lib.ptr(be), float(bn.eps), act, _lib.ptr(mask), 2.0, B, C, T, Lp,
                   halo, _lib.ptr(mean), _lib.ptr(var), _lib.ptr(Oh), _lib.ptr(Ol), _lib.ptr(out_f32), _lib.current_stream())
-        with torch.no_grad():          # bookkeeping of nn.BatchNorm1d in training mode ([C]-sized vectors)
-            n = B * T
-            mom = 0.1 if bn.momentum is None else bn.momentum
-            bn.running_mean.mul_(1 - mom).add_(mean, alpha=mom)
-            bn.running_var.mul_(1 - mom).add_(var * (n / max(1, n - 1)), alpha=mom)
-            bn.num_batches_tracked += 1
+        # bookkeeping of nn.BatchNorm1d in training mode: one launch
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        _lib.call("t2s_bn_running_update", _lib.ptr(mean), _lib.ptr(var), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
+                  _lib.ptr(bn.num_batches_tracked), float(mom), B * T, C, _lib.current_stream())
         if save is not None:
             save.append(dict(seq=seq, layer=layer, Xh=Xh, Xl=Xl, y=y, mean=mean, var=var, mask=mask, act=act, B=B, T=T, Lp=Lp,
                              halo=halo))

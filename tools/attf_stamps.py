@@ -12,9 +12,9 @@ import torch  # noqa: E402
 from text2speech_amd import _lib  # noqa: E402
 import tools.bench_tacotron_train as bt  # noqa: E402
 
-NAMES = ["entry -> loads requested", "wait: barrier 1 (d_ctx in LDS)", "conv kernel to LDS", "d_w dots + sdot partial",
-         "later-stage loads requested; barrier 2", "d_e", "features MFMA; barrier 3", "energies backward; barrier 4",
-         "D to LDS + dD^T; barrier 5", "d_f; barrier 6", "G + dK; barrier 7", "carries"]
+NAMES = ["entry", "loads requested (up to the first barrier)", "barrier 1 (waits for every outstanding load of the wave)",
+         "conv kernel -> LDS, d_w dots, sdot partial", "barrier 2", "d_e + features MFMA", "barrier 3", "energies backward",
+         "barrier 4, D -> LDS, dD^T", "barrier 5, d_f (+ its inner barrier)", "barrier 6, G + dK", "barrier 7, carries"]
 
 
 def main():
