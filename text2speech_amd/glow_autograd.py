@@ -100,9 +100,9 @@ def _alloc_train(eng, B, L, dev):
     st.k0, st.k1 = g["halo"] // 32, -(-(g["halo"] + L) // 32)
     ksteps = B * (st.k1 - st.k0)
 
-    def nsplit(M, N):
+    def nsplit(M, N, fill=256):
         tiles = -(-M // 256) * -(-N // 256)
-        ns = max(1, min(256 // tiles, ksteps // 8))
+        ns = max(1, min(fill // tiles, ksteps // 8))
         while ns > 1 and -(-ksteps // ns) * (ns - 1) >= ksteps:      # every slab owns at least one K-step
             ns -= 1
         return ns
@@ -115,9 +115,12 @@ def _alloc_train(eng, B, L, dev):
     st.bias_cols = 1 if (st.cl_ok and C % 256 == 0 and os.environ.get("T2S_WGRAD_PP", "1") != "0"
                          and os.environ.get("T2S_WGRAD_BIAS_COL") != "ones") else 0
     st.N1g = C if st.bias_cols else st.N1                  # columns of the GEMM proper
-    st.ks2, st.ks1 = nsplit(2 * C, st.N2), nsplit(2 * C, st.N1g)
+    # workgroups a weight-gradient launch aims for (T2S_WGRAD_FILL2 / _FILL1: the gate / the res-skip convolution's): next to the
+    # data-gradient stream what counts is CU-time per unit of work, and half the slabs are half the partial-sum traffic
+    fill2, fill1 = int(os.environ.get("T2S_WGRAD_FILL2", "256")), int(os.environ.get("T2S_WGRAD_FILL1", "256"))
+    st.ks2, st.ks1 = nsplit(2 * C, st.N2, fill2), nsplit(2 * C, st.N1g, fill1)
     # the last layer of a flow has no residual rows (M = C): twice the slabs of half the height, the same slab buffer
-    st.ks1_last = nsplit(C, st.N1g) if st.cl_ok and nsplit(C, st.N1g) * C <= st.ks1 * 2 * C else st.ks1
+    st.ks1_last = nsplit(C, st.N1g, fill1) if st.cl_ok and nsplit(C, st.N1g, fill1) * C <= st.ks1 * 2 * C else st.ks1
     # floats per slab row: a multiple of 4 so that the channel-last kernel's epilogue stores whole 16-byte pieces
     st.ld2, st.ld1 = (-(-st.N2 // 4) * 4, -(-(st.N1g + 4 * st.bias_cols) // 4) * 4) if st.cl_ok else (st.N2, st.N1)
     st.P2 = torch.empty(st.ks2, 2 * C, st.ld2, dtype=torch.float32, device=dev)

@@ -373,10 +373,24 @@ class _TacoEngine:
         al = dec.attention_layer
         ad = al.query_layer.linear_layer.out_features
         n_mel = dec.n_mel_channels * dec.n_frames_per_step
-        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
-        S = dict(att_h0=z(B, A), att_h1=z(B, A), att_c=z(B, A), dec_h0=z(B, D), dec_h1=z(B, D), dec_c=z(B, D),
-                 att_w=z(B, T_in), att_wcum=z(B, T_in), ctx=z(B, E), q=z(B, ad), energies=z(B, T_in),
-                 pre1=z(B, Pd), pre2=z(B, Pd), q_part=z(A // 2, B, ad), align_out=z(B, T_cap, T_in))
+        # recurrent state and scratch that must start at zero: views of one buffer cleared by one launch
+        shapes = dict(att_h0=(B, A), att_h1=(B, A), att_c=(B, A), dec_h0=(B, D), dec_h1=(B, D), dec_c=(B, D),
+                      att_w=(B, T_in), att_wcum=(B, T_in), ctx=(B, E), q=(B, ad), energies=(B, T_in),
+                      pre1=(B, Pd), pre2=(B, Pd), q_part=(A // 2, B, ad))
+        if not teacher:
+            shapes["align_out"] = (B, T_cap, T_in)          # rows past the stop step stay zero
+        offs, tot = {}, 0
+        for name, sh in shapes.items():
+            n = 1
+            for x in sh:
+                n *= int(x)
+            offs[name] = (tot, n)
+            tot += -(-n // 64) * 64                         # 256-byte granules
+        flat = torch.empty(tot, dtype=torch.float32, device=dev)
+        _lib.call("t2s_zero_fill", _lib.ptr(flat), tot * 4, _lib.current_stream())
+        S = {name: flat[o:o + n].view(*shapes[name]) for name, (o, n) in offs.items()}
+        if teacher:     # every (item, step) row is written by the attention kernel of its step
+            S["align_out"] = torch.empty(B, T_cap, T_in, dtype=torch.float32, device=dev)
         pmem = torch.empty(B, T_in, ad, dtype=torch.float32, device=dev)
         self._gemv(P["w_mem"], memory, ad, B * T_in, E, pmem)
         S["pmem"], S["memory"] = pmem, memory
@@ -454,13 +468,19 @@ class _TacoEngine:
         conv = seq[0].conv
         O, Cin, Kt = conv.weight.shape
         Cpad, Mpad = -(-Cin // 32) * 32, _lib.padded_rows(O)
-        A_hi = torch.zeros(Kt * Cpad // 32, Mpad, 32, dtype=torch.bfloat16, device=dev)
-        A_lo = torch.zeros_like(A_hi)
-        bias = torch.zeros(Mpad, dtype=torch.float32, device=dev)
+        # repacked every training step (the weights move): pooled, zeroed once - the pack writes every entry inside (O, Cin, Kt),
+        # the padding around it depends on that triple only (it is part of the tag).  The leases live in the layer dict, which
+        # the step's saves reference too, so a buffer is not recycled while a backward still reads it.
+        if self.pool is None:
+            self.pool = {}
+        leases, tag = [], "pack_plain_%d_%d_%d" % (O, Cin, Kt)
+        A_hi = pool_take(self.pool, leases, tag + "_h", (Kt * Cpad // 32, Mpad, 32), torch.bfloat16, dev, zero_once=True)
+        A_lo = pool_take(self.pool, leases, tag + "_l", (Kt * Cpad // 32, Mpad, 32), torch.bfloat16, dev, zero_once=True)
+        bias = pool_take(self.pool, leases, tag + "_b", (Mpad,), torch.float32, dev, zero_once=True)
         w, cb = _f32(conv.weight), (None if conv.bias is None else _f32(conv.bias))
         _lib.call("t2s_pack_conv_weight", _lib.ptr(w), None, 0, _lib.ptr(cb), O, Cin, Kt, 0, 0, 0, Mpad, 0, Cpad,
                   _lib.ptr(A_hi), _lib.ptr(A_lo), _lib.ptr(bias), 0, _lib.current_stream())
-        return dict(A_hi=A_hi, A_lo=A_lo, bias=bias, Mpad=Mpad, Cin=Cin, Cout=O, taps=Kt, keep=(w, cb))
+        return dict(A_hi=A_hi, A_lo=A_lo, bias=bias, Mpad=Mpad, Cin=Cin, Cout=O, taps=Kt, keep=(w, cb), _leases=leases)
 
     def _conv_bn_train(self, seq, layer, Xh, Xl, B, T, Lp, halo, act, mask, want_planes=True, out_f32=None, save=None,
                        leases=None, tag=None):

@@ -23,6 +23,8 @@ python3 tools/rocpd_by_grid.py "$OUT/train/wt_results.db" 4 24 > "$OUT/train_two
 python3 tools/rocpd_by_grid.py "$OUT/train1/w1_results.db" 4 30 > "$OUT/train_one_stream_by_grid.md"
 python3 tools/rocpd_stats.py "$OUT/taco_inf/ti_results.db" 1 14 > "$OUT/taco_inf_kernels.md"
 python3 tools/rocpd_stats.py "$OUT/taco_train/tt_results.db" 6 20 > "$OUT/taco_train_kernels.md"
+python3 tools/rocpd_timeline.py "$OUT/taco_train/tt_results.db" sbgemm_lstm 0.80 24 > "$OUT/taco_timeline_fwd.md"
+python3 tools/rocpd_timeline.py "$OUT/taco_train/tt_results.db" att_bwd_fused 0.92 30 > "$OUT/taco_timeline_bwd.md"
 python3 tools/pmc_traffic.py "$OUT/pmc_fetch/f_results.db" "$OUT/pmc_write/w_results.db" > "$OUT/pmc_traffic.json"
 rm -rf "$OUT"/train1
 rm -rf "$OUT"/fwd "$OUT"/train "$OUT"/taco_inf "$OUT"/taco_train "$OUT"/pmc_fetch "$OUT"/pmc_write     # databases are large
