@@ -465,7 +465,8 @@ typedef struct t2s_att_bwd {
     float *dctx_out;                      /* optional [B][enc]: d_ctx of this step; with it d_memory may be NULL and the caller
                                            * forms d_memory = sum_t w_t (x) d_ctx_t once after the loop */
     int B, T, att_dim, enc_dim, loc_f, loc_ks;
-    /* used by t2s_taco_bptt_steps' one-launch form only (leave 0 here): the step's saved context [B][.] (row stride s_ctx) and
+    /* the one-launch form (all three set; needs dctx_out, d_memory NULL, attention_dim 128, 32 filters, kernel <= 31; d_q is then
+     * NOT written - sum dq_part over the chunks): the step's saved context [B][.] (row stride s_ctx) and
      * the carry buffers the step WRITES (it reads dw_carry / dwc_carry); all four are then [3][B][T] (see t2s_taco_bptt) */
     const float *ctx; long s_ctx;
     float *dw_carry_out, *dwc_carry_out;

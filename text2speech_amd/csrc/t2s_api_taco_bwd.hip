@@ -96,7 +96,12 @@ int t2s_taco_att_bwd(const t2s_att_bwd* p, void* stream) {
     static_assert(sizeof(t2s_att_bwd) == sizeof(AttBwdArgs), "t2s_att_bwd layout");
     AttBwdArgs a;
     memcpy(&a, p, sizeof(a));
-    T2S_CHECK_HIP(t2s_launch_att_bwd(a, (hipStream_t)stream));      // (the one-launch form is the BPTT driver's: it leaves d_q as partials)
+    if (a.ctx || a.dw_carry_out || a.dwc_carry_out) {      // the one-launch form (the BPTT driver's): d_q stays in dq_part
+        if (!t2s_att_bwd_fused_ok(a)) return T2S_EINVAL;
+        T2S_CHECK_HIP(t2s_launch_att_bwd_fused(a, (hipStream_t)stream));
+        return T2S_OK;
+    }
+    T2S_CHECK_HIP(t2s_launch_att_bwd(a, (hipStream_t)stream));
     return T2S_OK;
 }
 

@@ -117,7 +117,7 @@ def _alloc_train(eng, B, L, dev):
     st.N1g = C if st.bias_cols else st.N1                  # columns of the GEMM proper
     # workgroups a weight-gradient launch aims for (T2S_WGRAD_FILL2 / _FILL1: the gate / the res-skip convolution's): next to the
     # data-gradient stream what counts is CU-time per unit of work, and half the slabs are half the partial-sum traffic
-    fill2, fill1 = int(os.environ.get("T2S_WGRAD_FILL2", "256")), int(os.environ.get("T2S_WGRAD_FILL1", "256"))
+    fill2, fill1 = int(os.environ.get("T2S_WGRAD_FILL2", "256")), int(os.environ.get("T2S_WGRAD_FILL1", "128"))
     st.ks2, st.ks1 = nsplit(2 * C, st.N2, fill2), nsplit(2 * C, st.N1g, fill1)
     # the last layer of a flow has no residual rows (M = C): twice the slabs of half the height, the same slab buffer
     st.ks1_last = nsplit(C, st.N1g, fill1) if st.cl_ok and nsplit(C, st.N1g, fill1) * C <= st.ks1 * 2 * C else st.ks1
@@ -340,7 +340,8 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
     two = not os.environ.get("T2S_WG_BWD_ONE_STREAM")
     side_s = getattr(eng, "bwd_side_stream", None)
     if two and side_s is None:
-        side_s = eng.bwd_side_stream = torch.cuda.Stream(device=dev)
+        # T2S_WG_SIDE_PRIO=-1: the weight-gradient stream at high priority (it is the longer of the two chains)
+        side_s = eng.bwd_side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("T2S_WG_SIDE_PRIO", "0")))
     if not two:
         side_s = main_s
     st2 = _lib.c_vp(side_s.cuda_stream)

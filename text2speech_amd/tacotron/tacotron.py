@@ -207,7 +207,8 @@ class _TacoEngine:
         enc, dec = m.encoder, m.decoder
         P = {}
         P["emb"] = _f32(m.embedding.weight)
-        P["enc_convs"] = [self._pack_conv_bn(seq, dev, 2) for seq in enc.convolutions]
+        # (eval-mode packs fold the BatchNorm running statistics; training mode uses batch statistics and the plain packs)
+        P["enc_convs"] = None if m.training else [self._pack_conv_bn(seq, dev, 2) for seq in enc.convolutions]
         if m.training:
             P["enc_convs_plain"] = [self._pack_conv_plain(seq, dev) for seq in enc.convolutions]
             P["post_convs_plain"] = [self._pack_conv_plain(seq, dev) for seq in m.postnet.convolutions]
@@ -232,7 +233,7 @@ class _TacoEngine:
             wt = torch.empty(H, 4 * H, dtype=torch.float32, device=dev)
             _lib.call("t2s_transpose", _lib.ptr(w), _lib.ptr(wt), 4 * H, H, st)
             P["whhT"].append((wt, w))
-        P["post_convs"] = [self._pack_conv_bn(seq, dev, 2) for seq in m.postnet.convolutions]
+        P["post_convs"] = None if m.training else [self._pack_conv_bn(seq, dev, 2) for seq in m.postnet.convolutions]
         # decoder
         al = dec.attention_layer
         P["w_mem"] = _f32(al.memory_layer.linear_layer.weight)
@@ -426,7 +427,7 @@ class _TacoEngine:
         leases = None if save is None else save.setdefault("_leases", [])
         Xh, Xl = self._planes((B, -(-C // 32), Lp, 32), dev, leases, "post_x")
         _lib.call("t2s_f32_to_planes", _lib.ptr(mel), B, C, T, Lp, halo, _lib.ptr(Xh), _lib.ptr(Xl), _lib.current_stream())
-        n = len(P["post_convs"])
+        n = len(m.postnet.convolutions)
         out = torch.empty(B, C, T, dtype=torch.float32, device=dev)
         if m.training:
             given = None if train_masks is None else train_masks.get("post")
