@@ -37,7 +37,7 @@ BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s HBM3E
 WG_FWD_FLOP_PER_SAMPLE = 65.36e6  # 8.3666 TFLOP per 8 x 16000 forward
 TACO_FWD_FLOP_PER_FRAME = 52.1e6  # 1.334 TFLOP per 32 x 800 teacher-forced forward
-GEMM_PMC = "r02_pmc_traffic.json"  # profiles/: HBM-side bytes per launch of the gate GEMM (separate --pmc passes)
+GEMM_PMC = "r03_pmc_traffic.json"  # profiles/: HBM-side bytes per launch of the gate GEMM (separate --pmc passes)
 
 
 def log(msg):
@@ -381,7 +381,7 @@ def main():
             # HBM-side bytes per launch of this kernel come from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
             # --pmc WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note in MI355X_MICROARCH.md)
             traffic, tsrc = None, None
-            for name in (GEMM_PMC, "r01_pmc_traffic_v5.json"):
+            for name in (GEMM_PMC, "r02_pmc_traffic.json", "r01_pmc_traffic_v5.json"):
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", name)))
                     # the gate GEMM: the ping-pong kernel (round 2), or the two lockstep instantiations of round 1
