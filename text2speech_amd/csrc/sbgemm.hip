@@ -257,7 +257,7 @@ static __device__ __forceinline__ float sb_sum(float (*)[2][4][64], const char* 
 #define SB_DECL_PART float (*s_part)[2][4][64] = nullptr;
 #endif
 
-// ---- plain epilogue: GemvArgs semantics (no split_row / masks) -------------------------------------------------------
+// ---- plain epilogue: GemvArgs semantics (no split_row) -------------------------------------------------------
 template <int KW>
 __global__ __launch_bounds__(512) void sbgemm_plain_kernel(const GemvArgs a) {
     SB_DECL_PART
@@ -278,13 +278,14 @@ __global__ __launch_bounds__(512) void sbgemm_plain_kernel(const GemvArgs a) {
         float y = sb_sum<KW>(s_part, sb_ring, r, it) + (a.bias1 ? a.bias1[row] : 0.f) + (a.bias2 ? a.bias2[row] : 0.f);
         if (a.act == ACT_RELU) y = fmaxf(y, 0.f);
         else if (a.act == ACT_TANH) y = tanhf(y);
+        if (a.mask) y *= a.mask[(size_t)item * a.smask_item + row] ? a.mask_scale : 0.f;      // dropout draw (the hoisted prenet)
         a.y[(size_t)item * a.sy_item + (size_t)row * a.sy_row] = y;
     }
 }
 
 bool t2s_sbgemm_plain_ok(const GemvArgs& a) {
     const int K = a.n1 + a.n2 + a.n3;
-    if (a.items <= 8 || a.split_row > 0 || a.mask || K < 16) return false;
+    if (a.items <= 8 || a.split_row > 0 || K < 16) return false;
     if ((K & 15) || (a.n1 & 15) || (a.n2 & 15) || (a.n3 & 15) || (a.k1 & 15)) return false;
     if (a.k1 + a.k2 != K) return false;
     if ((a.ld1 & 3) || (a.W2 && (a.ld2 & 3)) || (a.sx1 & 3) || (a.x2 && (a.sx2 & 3)) || (a.x3 && (a.sx3 & 3))) return false;
