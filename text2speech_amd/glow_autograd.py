@@ -125,6 +125,7 @@ def _alloc_train(eng, B, L, dev):
     st.ld2, st.ld1 = (-(-st.N2 // 4) * 4, -(-(st.N1g + 4 * st.bias_cols) // 4) * 4) if st.cl_ok else (st.N2, st.N1)
     st.P2 = torch.empty(st.ks2, 2 * C, st.ld2, dtype=torch.float32, device=dev)
     st.P1 = torch.empty(st.ks1, 2 * C, st.ld1, dtype=torch.float32, device=dev)
+    st.P1b = torch.empty_like(st.P1)        # second slab set: the res/skip weight gradient on the data-gradient stream (backward_train)
     st.Mc = _lib.padded_rows(C)
     st.Ms = _lib.padded_rows(g["n_cond"])
     # Transposed weight operands of the backward's data-gradient GEMMs, one set per (flow, layer) (0.8 GB at config.json
@@ -410,6 +411,9 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         keep.append(v32)
         return v32, saved
 
+    # T2S_WG_P1_MAIN=0: the res/skip weight gradient on the weight-gradient stream (the round-3 start)
+    p1_main = two and os.environ.get("T2S_WG_P1_MAIN", "1") != "0"
+    p1_count, p1_free = [0], [None, None]
     for k in reversed(range(m.n_flows)):
         c_off, n_rem, n_half = eng._flow_geom(k)
         wn = m.WN[k]
@@ -488,10 +492,29 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                       a_h, a_l, g_h, g_l, ts.act_bchunks, dp_h, dp_l, ts.dp_chunks, B, C, L, Lp, halo, ts.Mc, st)
             ev_dp = torch.cuda.Event()
             ev_dp.record(main_s)
-            # 2. dW_rs = [dx ; dS] . acts^T  (+ bias column)                                                 [side]
-            side_s.wait_event(ev_in)
+            # 2. dW_rs = [dx ; dS] . acts^T  (+ bias column)                                                 [side, or main]
             d = 2 ** i
-            if cl:
+            P1 = ts.P1
+            ev_tdrs = None
+            if cl and p1_main:
+                # On the data-gradient stream, between the two GEMMs that bracket it there: the chain then never waits for the
+                # weight-gradient stream before it updates DX (that wait was 135 us of the 463 us a layer took,
+                # profiles/r03_wg_train_timeline_before.md), and 74 us of half-chip work leave the longer stream.  Its slab
+                # reduction stays on the side stream; two slab sets, so the chain only waits for the reduction of two layers ago.
+                ta1, tb1, ta2, tb2 = _cl_tables(ts, (k, i), sv, last, xc, sc, ks, d, dev, i)
+                ks1 = ts.ks1_last if last else ts.ks1
+                pb = p1_count[0] & 1
+                p1_count[0] += 1
+                P1 = ts.P1b if pb else ts.P1
+                if p1_free[pb] is not None:
+                    main_s.wait_event(p1_free[pb])
+                _lib.call("t2s_wgrad_cl", _ptr(ta1), ta1.size(0), _ptr(tb1), tb1.size(0), _ptr(P1), B, rows2, ts.N1g, ts.ld1,
+                          ts.k0, ts.k1, ks1, ts.bias_cols, st)
+                ev_p1 = torch.cuda.Event()
+                ev_p1.record(main_s)
+                side_s.wait_event(ev_p1)
+            elif cl:
+                side_s.wait_event(ev_in)
                 ta1, tb1, ta2, tb2 = _cl_tables(ts, (k, i), sv, last, xc, sc, ks, d, dev, i)
                 ks1 = ts.ks1_last if last else ts.ks1
                 _lib.call("t2s_wgrad_cl", _ptr(ta1), ta1.size(0), _ptr(tb1), tb1.size(0), _ptr(ts.P1), B, rows2, ts.N1g, ts.ld1,
@@ -499,6 +522,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                 ev_tdrs = torch.cuda.Event()        # DX / DS have been read: the chain may update DX in place
                 ev_tdrs.record(side_s)
             else:
+                side_s.wait_event(ev_in)
                 if not last:
                     _lib.call("t2s_plane_transpose", _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, xc, xc, Lp, 0, _ptr(ts.TM_drs[0]),
                               _ptr(ts.TM_drs[1]), Mrs, 0, st2)
@@ -510,8 +534,11 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                           _ptr(ts.TM_act[1]), ts.N1pad, 0, st2)
                 _lib.call("t2s_wgrad_gemm_flat", _ptr(ts.TM_drs[0]), _ptr(ts.TM_drs[1]), _ptr(ts.TM_act[0]), _ptr(ts.TM_act[1]),
                           _ptr(zb), _ptr(ts.P1), B, rows2, ts.N1, Mrs, ts.N1pad, nt, ts.k0, ts.k1, ts.ks1, st2)
-            wn_grads(conv_rs, ts.P1, (ts.ks1_last if last else ts.ks1) if cl else ts.ks1, rows2, ts.ld1, 0, 0, C, rows2, C, 1,
+            wn_grads(conv_rs, P1, (ts.ks1_last if last else ts.ks1) if cl else ts.ks1, rows2, ts.ld1, 0, 0, C, rows2, C, 1,
                      stream=st2, nb=4 if ts.bias_cols and cl else 1)
+            if cl and p1_main:
+                p1_free[pb] = torch.cuda.Event()
+                p1_free[pb].record(side_s)
             # 3. dW_in, dW_cond = d_pre . [x taps | spect | 1]^T                                             [side]
             side_s.wait_event(ev_dp)
             if cl:
@@ -528,7 +555,8 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             wn_grads(conv_in, ts.P2, ts.ks2, 2 * C, ts.ld2, 0, C, ts.N2 - 1, 2 * C, C, ks, stream=st2)
             wn_grads(conv_c, ts.P2, ts.ks2, 2 * C, ts.ld2, ks * C, 0, ts.N2 - 1, 2 * C, n_cond, 1, stream=st2)
             # 4. dx (+)= W_in^T (*) d_pre ;  d_spect += W_cond^T d_pre                                       [main]
-            main_s.wait_event(ev_tdrs)      # (events of one stream complete in order: this covers every earlier read of DX too)
+            if ev_tdrs is not None:
+                main_s.wait_event(ev_tdrs)  # (events of one stream complete in order: this covers every earlier read of DX too)
             _lib.call("t2s_conv_accumulate", _ptr(A_inT[0]), _ptr(A_inT[1]), _ptr(zb), dp_h, dp_l, ts.dp_chunks,
                       _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, 2 * C, C, ks, d, 1 if last else 0, L, Lp, halo, ts.Mc, st)
             # (W_cond,i^T sits in K-chunks [2 xc i, 2 xc (i + 1)) of the flow's conditioning-gradient operand A_cT)
