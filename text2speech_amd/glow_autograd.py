@@ -414,6 +414,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
     # T2S_WG_P1_MAIN=0: the res/skip weight gradient on the weight-gradient stream (the round-3 start)
     p1_main = two and os.environ.get("T2S_WG_P1_MAIN", "1") != "0"
     p1_count, p1_free = [0], [None, None]
+    wcond_side = two and cl and not per_layer_cond and os.environ.get("T2S_WG_WCOND_SIDE", "1") == "1"
     for k in reversed(range(m.n_flows)):
         c_off, n_rem, n_half = eng._flow_geom(k)
         wn = m.WN[k]
@@ -568,8 +569,11 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                 dsp_init = 0
         # d_spect (+)= [W_cond,0^T | ... | W_cond,nl-1^T] [d_pre_0 ; ... ; d_pre_nl-1]: one GEMM per flow, K = nl * 2C       [main]
         if not per_layer_cond:
+            # (T2S_WG_WCOND_SIDE=1: on the weight-gradient stream - it feeds the upsampler's gradient only, not the chain; that
+            # stream has waited for every d_pre of the flow by now, and it owns the d_pre planes' reuse through side_done)
             _lib.call("t2s_conv_accumulate", _ptr(ts.A_cT[k][0]), _ptr(ts.A_cT[k][1]), _ptr(zb), _ptr(DP[0]), _ptr(DP[1]), 0,
-                      _ptr(ts.DSp[0]), _ptr(ts.DSp[1]), B, nl * 2 * C, n_cond, 1, 1, dsp_init, L, Lp, halo, ts.Ms, st)
+                      _ptr(ts.DSp[0]), _ptr(ts.DSp[1]), B, nl * 2 * C, n_cond, 1, 1, dsp_init, L, Lp, halo, ts.Ms,
+                      st2 if wcond_side else st)
             dsp_init = 0
         # ---- WN.start ----
         dW_eff = new(C, n_half)
@@ -602,6 +606,8 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
         ev_main.record(main_s)
         bucket.ship((ev_main, ev_side))
     # ---- upsampler ----
+    if wcond_side:
+        main_s.wait_stream(side_s)          # d_spect is complete on the weight-gradient stream
     up = m.upsample
     bucket = _Bucket(up.parameters())
     dW_up = bucket.take(*up.weight.shape)
