@@ -445,6 +445,10 @@ int t2s_adam_table(const t2s_adam_job* jobs, int n_jobs, long total_blocks, floa
 /* x[item - shift][c] (f32 rows, stride ld) -> time-major planes tm[item/32][n_off + c][item%32]; items_pad % 32 == 0 */
 int t2s_rows_to_tm(const float* x, long ld, int items, int items_pad, int shift, int C, void* dst_hi, void* dst_lo,
                    int Npad, int n_off, void* stream);
+/* the same for nb sets at once: set z reads x + z * x_bstride (floats) and writes its planes at dst + z * dst_bstride (bf16
+ * elements) - e.g. one set per batch element in front of a t2s_wgrad_gemm with B = nb */
+int t2s_rows_to_tm_batched(const float* x, long ld, long x_bstride, int items, int items_pad, int shift, int C, void* dst_hi,
+                           void* dst_lo, long dst_bstride, int Npad, int n_off, int nb, void* stream);
 /* LSTMCell backward, pointwise part: dh = (dh1+dh2+dh3)*dropout -> dgates[B][4H] (i,f,g,o), dc_carry updated in place */
 int t2s_lstm_cell_bwd(const float* dh1, long s1, const float* dh2, long s2, const float* dh3, long s3,
                       const unsigned char* drop_mask, float drop_scale, const float* gates, const float* c_new,

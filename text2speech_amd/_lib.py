@@ -68,6 +68,7 @@ SIGNATURES = {
     "t2s_taco_decode_steps": [c_vp, c_int, c_int, c_vp],
     "t2s_taco_stop_check": [c_vp, c_int, c_int, c_int, c_int, c_int, c_float, c_vp, c_vp],
     "t2s_rows_to_tm": [c_vp, c_long, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp],
+    "t2s_rows_to_tm_batched": [c_vp, c_long, c_long, c_int, c_int, c_int, c_int, c_vp, c_vp, c_long, c_int, c_int, c_int, c_vp],
     "t2s_lstm_cell_bwd": [c_vp, c_long, c_vp, c_long, c_vp, c_long, c_vp, c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int,
                           c_vp],
     "t2s_relu_drop_bwd": [c_vp, c_vp, c_float, ctypes.c_size_t, c_vp, c_vp],
@@ -150,10 +151,22 @@ def ptr(t):
     return c_vp(t.data_ptr())
 
 
+HOST_TIMES = {}     # T2S_HOST_TIMING=1: seconds the host spent inside each entry point (enqueue cost; diagnostic)
+_HOST_TIMING = bool(os.environ.get("T2S_HOST_TIMING"))
+
+
 def call(name, *args):
     """Call an int-returning entry point; raise on a non-zero code."""
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if _HOST_TIMING:
+        import time
+        t0 = time.perf_counter()
+        rc = getattr(lib, name)(*args)
+        c = HOST_TIMES.setdefault(name, [0, 0.0])
+        c[0] += 1
+        c[1] += time.perf_counter() - t0
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.t2s_error_string(rc).decode()
         hip = lib.t2s_last_hip_error().decode()

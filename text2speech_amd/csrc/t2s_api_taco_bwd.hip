@@ -69,6 +69,16 @@ int t2s_rows_to_tm(const float* x, long ld, int items, int items_pad, int shift,
     return T2S_OK;
 }
 
+int t2s_rows_to_tm_batched(const float* x, long ld, long x_bstride, int items, int items_pad, int shift, int C, void* dst_hi,
+                           void* dst_lo, long dst_bstride, int Npad, int n_off, int nb, void* stream) {
+    if (!x || !dst_hi || !dst_lo || items <= 0 || items_pad % 32 || items_pad < items || C <= 0 || n_off < 0 ||
+        n_off + C > Npad || nb <= 0 || nb > 65535)
+        return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_rows_to_tm_batched(x, ld, x_bstride, items, items_pad, shift, C, (u16*)dst_hi, (u16*)dst_lo,
+                                                dst_bstride, Npad, n_off, nb, (hipStream_t)stream));
+    return T2S_OK;
+}
+
 int t2s_lstm_cell_bwd(const float* dh1, long s1, const float* dh2, long s2, const float* dh3, long s3,
                       const unsigned char* drop_mask, float drop_scale, const float* gates, const float* c_new,
                       const float* c_prev, float* dc_carry, float* dgates, int B, int H, void* stream) {

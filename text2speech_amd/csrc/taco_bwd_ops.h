@@ -60,6 +60,9 @@ struct BnBwdArgs {
 
 hipError_t t2s_launch_rows_to_tm(const float* x, long ld, int items, int items_pad, int shift, int C, u16* dst_hi,
                                  u16* dst_lo, int Npad, int n_off, hipStream_t stream);
+hipError_t t2s_launch_rows_to_tm_batched(const float* x, long ld, long x_bstride, int items, int items_pad, int shift, int C,
+                                         u16* dst_hi, u16* dst_lo, long dst_bstride, int Npad, int n_off, int nb,
+                                         hipStream_t stream);
 hipError_t t2s_launch_lstm_cell_bwd(const LstmBwdArgs& a, hipStream_t stream);
 hipError_t t2s_launch_relu_drop_bwd(const float* dy, const float* y, float scale, size_t n, float* dz, hipStream_t stream);
 hipError_t t2s_launch_att_bwd(const AttBwdArgs& a, hipStream_t stream);

@@ -31,9 +31,13 @@ static __device__ __forceinline__ float sum3(const float* a, long sa, const floa
 // ------------------------------------------------------------------------------------------------
 // f32 rows x[item - shift][c0 + c] (row stride ld)  ->  time-major planes tm[item/32][n_off + c][item%32]
 __global__ __launch_bounds__(256) void rows_to_tm_kernel(const float* __restrict__ x, long ld, int items, int shift, int C,
-                                                         u16* dst_hi, u16* dst_lo, int Npad, int n_off) {
+                                                         u16* dst_hi, u16* dst_lo, int Npad, int n_off, long x_bstride,
+                                                         long dst_bstride) {
     __shared__ float tile[32][33];
     const int ic = blockIdx.x, cc = blockIdx.y, tid = threadIdx.x;
+    x += (size_t)blockIdx.z * x_bstride;            // batched form: one set of planes per blockIdx.z
+    dst_hi += (size_t)blockIdx.z * dst_bstride;
+    dst_lo += (size_t)blockIdx.z * dst_bstride;
     {
         const int r = tid >> 3, q = tid & 7;
         const int item = ic * 32 + r - shift;
@@ -64,7 +68,14 @@ __global__ __launch_bounds__(256) void rows_to_tm_kernel(const float* __restrict
 hipError_t t2s_launch_rows_to_tm(const float* x, long ld, int items, int items_pad, int shift, int C, u16* dst_hi,
                                  u16* dst_lo, int Npad, int n_off, hipStream_t stream) {
     hipLaunchKernelGGL(rows_to_tm_kernel, dim3(items_pad / 32, (C + 31) / 32), dim3(256), 0, stream, x, ld, items, shift, C,
-                       dst_hi, dst_lo, Npad, n_off);
+                       dst_hi, dst_lo, Npad, n_off, 0L, 0L);
+    return hipGetLastError();
+}
+hipError_t t2s_launch_rows_to_tm_batched(const float* x, long ld, long x_bstride, int items, int items_pad, int shift, int C,
+                                         u16* dst_hi, u16* dst_lo, long dst_bstride, int Npad, int n_off, int nb,
+                                         hipStream_t stream) {
+    hipLaunchKernelGGL(rows_to_tm_kernel, dim3(items_pad / 32, (C + 31) / 32, nb), dim3(256), 0, stream, x, ld, items, shift, C,
+                       dst_hi, dst_lo, Npad, n_off, x_bstride, dst_bstride);
     return hipGetLastError();
 }
 

@@ -331,12 +331,25 @@ class _Bwd:
         _lib.call("t2s_taco_bptt_steps", ctypes.byref(bp), T, 0, st)        # the whole reversed loop, enqueued from C++
         if dctx_all is not None:
             # d_memory[b] = sum_t w[t][b][:] (x) d_ctx[t][b][:]: one contraction over the decoder steps per batch element
-            for b in range(B):
-                Pm_, ks_, M4_, N_ = self.items_wgrad(T, [(_p(align, b * T_cap * T_in), T_in, T_in, 0, 0)],
-                                                     [(_p(dctx_all, b * E), B * E, E, 0, 0)], T_in, E)
-                _lib.call("t2s_wn_backward", _p(Pm_), ks_, M4_, N_, 0, 0, 0, N_ - 1, 1, _p(memory), None, T_in, E, 1,
-                          _p(d_memory, b * T_in * E), None, None, 0, st)
-            self.keep.append(dctx_all)
+            # (all batch elements at once: one set of time-major planes per element, the GEMM's per-element slabs ARE the result -
+            # five launches instead of 5 x B)
+            items_pad = _ru(T, 32)
+            nch_ = items_pad // 32
+            Mpad_, N_ = _lib.padded_rows(T_in), E + 1
+            Npad_ = _ru(N_, 256)
+            Am = (self.bf(B, nch_, Mpad_, 32, tag="dmem_Ah"), self.bf(B, nch_, Mpad_, 32, tag="dmem_Al"))
+            Xm = (self.bf(B, nch_, Npad_, 32, tag="dmem_Xh"), self.bf(B, nch_, Npad_, 32, tag="dmem_Xl"))
+            _lib.call("t2s_rows_to_tm_batched", _p(align), T_in, T_cap * T_in, T, items_pad, 0, T_in, _p(Am[0]), _p(Am[1]),
+                      nch_ * Mpad_ * 32, Mpad_, 0, B, st)
+            _lib.call("t2s_rows_to_tm_batched", _p(dctx_all), B * E, E, T, items_pad, 0, E, _p(Xm[0]), _p(Xm[1]),
+                      nch_ * Npad_ * 32, Npad_, 0, B, st)
+            _lib.call("t2s_tm_ones_row", _p(Xm[0]), _p(Xm[1]), B, items_pad, 0, T, Npad_, E, st)
+            Pm_ = self.new(B, T_in, N_, tag="dmem_P")
+            _lib.call("t2s_wgrad_gemm", _p(Am[0]), _p(Am[1]), _p(Xm[0]), _p(Xm[1]), _p(self.zero_bias), _p(Pm_), B, T_in, N_, Mpad_,
+                      Npad_, nch_, 0, nch_, 1, st)
+            _lib.call("t2s_wn_backward", _p(Pm_), 1, B * T_in, N_, 0, 0, 0, N_ - 1, 1, _p(memory), None, B * T_in, E, 1,
+                      _p(d_memory), None, None, 0, st)
+            self.keep += [dctx_all, Am, Xm, Pm_]
         self.keep += [dw_buf, df_buf, dq_part, dw_c2, dwc_c2]
         # ---- weight gradients over all (step, batch) items ----
         ar = dec.attention_rnn

@@ -35,9 +35,7 @@ def encoder_backward(bw, d_memory):
     M = 8 * H
     Mpad = _lib.padded_rows(M)
     A = (bw.bf(B, nt, Mpad, 32, tag="enc_Ah"), bw.bf(B, nt, Mpad, 32, tag="enc_Al"))
-    for b in range(B):
-        _lib.call("t2s_rows_to_tm", _p(dgx, b * T * M), M, T, items_pad, halo, M, _p(A[0], b * nt * Mpad * 32),
-                  _p(A[1], b * nt * Mpad * 32), Mpad, 0, st)
+    _lib.call("t2s_rows_to_tm_batched", _p(dgx), M, T * M, T, items_pad, halo, M, _p(A[0]), _p(A[1]), nt * Mpad * 32, Mpad, 0, B, st)
     Cin = lstm.input_size
     icc = _ru(Cin, 32) // 32
     N = Cin + 1

@@ -47,6 +47,8 @@ def main():
         step()
     torch.cuda.synchronize()
     print("[bench] warm-up done, loss %.4f" % l0, file=sys.stderr, flush=True)
+    from text2speech_amd import _lib
+    _lib.HOST_TIMES.clear()
     n = 3
     host = 0.0
     t0 = time.perf_counter()
@@ -61,5 +63,18 @@ def main():
                       "max_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}))
 
 
+def host_report(n=3):
+    """T2S_HOST_TIMING=1: where the host's enqueue time of a step goes (ms per step, calls per step), to stderr."""
+    from text2speech_amd import _lib
+    rows = sorted(_lib.HOST_TIMES.items(), key=lambda kv: -kv[1][1])
+    tot = sum(v[1] for _, v in rows)
+    print("[host] inside the library's entry points: %.2f ms per step in %d calls" % (tot / n * 1e3, sum(v[0] for _, v in rows) // n),
+          file=sys.stderr)
+    for k, v in rows[:12]:
+        print("[host]   %-32s %7.2f ms  %5d calls" % (k, v[1] / n * 1e3, v[0] // n), file=sys.stderr)
+
+
 if __name__ == "__main__":
     main()
+    if os.environ.get("T2S_HOST_TIMING"):
+        host_report()
