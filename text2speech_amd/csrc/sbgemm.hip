@@ -123,7 +123,9 @@ static __device__ __forceinline__ void sb_glds16(const void* gsrc, void* lds_dst
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int KW>
+// HALF: the workgroup takes 16 items instead of 32 (no second B fragment): for launches whose row count fills less than half the
+// chip - the per-CU fill is what bounds the kernel, and two workgroups with half the input vectors each pull 2/3 of the bytes per CU
+template <int KW, bool HALF = false>
 static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow_of_r16, bool row_ok, int item_base,
                                                float (*s_part)[2][4][64], char* ring, size_t grow_lo8, size_t grow_hi8) {
     constexpr int SB_R = SbCfg<KW>::R, SB_SLOT = SbCfg<KW>::SLOT;
@@ -133,7 +135,7 @@ static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow_
     const int nsteps = o.K / KW;
     const int s0 = (wave * nsteps) >> 3, s1 = ((wave + 1) * nsteps) >> 3;
     // every DMA reads valid memory: rows / items past the end are clamped by the caller / here and zeroed after the fragment read
-    const bool v0 = item_base + r16 < o.items, v1 = item_base + 16 + r16 < o.items;
+    const bool v0 = item_base + r16 < o.items, v1 = !HALF && item_base + 16 + r16 < o.items;
     char* const my = ring + wave * (SB_R * SB_SLOT);
     int slot_in = 0;                                        // slot the next issue fills (wave-uniform)
     // DMA lane roles.  KW = 16: row r16, piece q.  KW = 32: rows (lane >> 3) and (lane >> 3) + 8, piece (lane & 7) ^ (row & 7).
@@ -157,18 +159,20 @@ static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow_
         if constexpr (KW == 16) {
             sb_glds16(wbase + grow_of_r16 * wld + dp * 4, dst);
             sb_glds16(xp + dp * 4 + ia0 * sx, dst + 1024);
-            sb_glds16(xp + dp * 4 + ib0 * sx, dst + 2048);
+            if constexpr (!HALF) sb_glds16(xp + dp * 4 + ib0 * sx, dst + 2048);
         } else {
             sb_glds16(wbase + grow_lo8 * wld + dp * 4, dst);
             sb_glds16(wbase + grow_hi8 * wld + dp * 4, dst + 1024);
             sb_glds16(xp + dp * 4 + ia0 * sx, dst + 2048);
             sb_glds16(xp + dp * 4 + ia1 * sx, dst + 3072);
-            sb_glds16(xp + dp * 4 + ib0 * sx, dst + 4096);
-            sb_glds16(xp + dp * 4 + ib1 * sx, dst + 5120);
+            if constexpr (!HALF) {
+                sb_glds16(xp + dp * 4 + ib0 * sx, dst + 4096);
+                sb_glds16(xp + dp * 4 + ib1 * sx, dst + 5120);
+            }
         }
         slot_in = slot_in + 1 == SB_R ? 0 : slot_in + 1;
     };
-    constexpr int NDMA = KW == 16 ? 3 : 6;
+    constexpr int NDMA = (KW == 16 ? 3 : 6) - (HALF ? (KW == 16 ? 1 : 2) : 0);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const int nmine = s1 - s0;
     int issued = 0;                                         // steps are counted 0 .. nmine - 1
@@ -188,12 +192,13 @@ static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow_
         constexpr int OPB = KW == 16 ? 1024 : 2048;         // bytes per operand in a slot
         f32x4 fa = *(const f32x4*)(src + rd0);
         f32x4 fb0 = *(const f32x4*)(src + OPB + rd0);
-        f32x4 fb1 = *(const f32x4*)(src + 2 * OPB + rd0);
+        f32x4 fb1 = zero;
+        if constexpr (!HALF) fb1 = *(const f32x4*)(src + 2 * OPB + rd0);
         f32x4 ga = zero, gb0 = zero, gb1 = zero;
         if constexpr (KW == 32) {
             ga = *(const f32x4*)(src + rd1);
             gb0 = *(const f32x4*)(src + OPB + rd1);
-            gb1 = *(const f32x4*)(src + 2 * OPB + rd1);
+            if constexpr (!HALF) gb1 = *(const f32x4*)(src + 2 * OPB + rd1);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         slot_out = slot_out + 1 == SB_R ? 0 : slot_out + 1;
@@ -210,13 +215,13 @@ static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow_
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb0[j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb1[j], acc1, 0, 0, 0);
+            if constexpr (!HALF) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb1[j], acc1, 0, 0, 0);
         }
         if constexpr (KW == 32) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[j], gb0[j], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[j], gb1[j], acc1, 0, 0, 0);
+                if constexpr (!HALF) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[j], gb1[j], acc1, 0, 0, 0);
             }
         }
 #else
@@ -258,7 +263,7 @@ static __device__ __forceinline__ float sb_sum(float (*)[2][4][64], const char* 
 #endif
 
 // ---- plain epilogue: GemvArgs semantics (no split_row) -------------------------------------------------------
-template <int KW>
+template <int KW, bool HALF = false>
 __global__ __launch_bounds__(512) void sbgemm_plain_kernel(const GemvArgs a) {
     SB_DECL_PART
     extern __shared__ __attribute__((aligned(16))) char sb_ring[];
@@ -267,14 +272,18 @@ __global__ __launch_bounds__(512) void sbgemm_plain_kernel(const GemvArgs a) {
     o.x0 = a.x1; o.x1 = a.x2; o.x2 = a.x3; o.n0 = a.n1; o.n1 = a.n2; o.n2 = a.n3;
     o.sx0 = a.sx1; o.sx1 = a.sx2; o.sx2 = a.sx3;
     o.K = a.n1 + a.n2 + a.n3; o.items = a.items;
-    const int row0 = blockIdx.x * 16, item_base = blockIdx.y * 32;
+    const int row0 = blockIdx.x * 16, item_base = blockIdx.y * (HALF ? 16 : 32);
     const int lrow = row0 + (threadIdx.x & 15);
     auto clampr = [&](int r) { return (size_t)(r < a.rows ? r : a.rows - 1); };       // DMA sources stay inside the matrix
     const int dr = (threadIdx.x & 63) >> 3;
+#ifdef T2S_SBGEMM_VGPR
     sb_core<KW>(o, clampr(lrow), lrow < a.rows, item_base, s_part, sb_ring, clampr(row0 + dr), clampr(row0 + dr + 8));
+#else
+    sb_core<KW, HALF>(o, clampr(lrow), lrow < a.rows, item_base, s_part, sb_ring, clampr(row0 + dr), clampr(row0 + dr + 8));
+#endif
     const int r = threadIdx.x & 15, it = threadIdx.x >> 4;          // 512 threads = 16 rows x 32 items
     const int row = row0 + r, item = item_base + it;
-    if (row < a.rows && item < a.items) {
+    if (row < a.rows && item < a.items && (!HALF || it < 16)) {
         float y = sb_sum<KW>(s_part, sb_ring, r, it) + (a.bias1 ? a.bias1[row] : 0.f) + (a.bias2 ? a.bias2[row] : 0.f);
         if (a.act == ACT_RELU) y = fmaxf(y, 0.f);
         else if (a.act == ACT_TANH) y = tanhf(y);
@@ -295,13 +304,13 @@ bool t2s_sbgemm_plain_ok(const GemvArgs& a) {
     return true;
 }
 
-template <int KW, typename Args>
+template <int KW, typename Args, int VARIANT = 0>         // VARIANT: distinct kernels of one (KW, Args) each get their own flag
 static hipError_t sb_launch(void (*kern)(const Args), const Args& a, dim3 grid, hipStream_t stream) {
 #ifdef T2S_SBGEMM_VGPR
     constexpr int lds = 0;
 #else
     constexpr int lds = sb_ring_bytes<KW>();
-    static std::atomic<unsigned long long> attr_mask{0};         // one per (KW, Args) instantiation = per kernel
+    static std::atomic<unsigned long long> attr_mask{0};         // one per (KW, Args, VARIANT) instantiation = per kernel
     const hipError_t e = t2s_raise_lds_limit((const void*)kern, lds, attr_mask);
     if (e != hipSuccess) return e;
 #endif
@@ -318,9 +327,17 @@ static bool sb_wide_ok(int K, int k1, int n0, int n1, int n2) {
 hipError_t t2s_launch_sbgemm_plain(const GemvArgs& a, hipStream_t stream) {
     dim3 grid((a.rows + 15) / 16, (a.items + 31) / 32);
 #ifndef T2S_SBGEMM_VGPR
-    if (sb_wide_ok(a.n1 + a.n2 + a.n3, a.k1, a.n1, a.n2, a.n3)) return sb_launch<32>(sbgemm_plain_kernel<32>, a, grid, stream);
-#endif
+    // 16 items per workgroup where twice the workgroups still fit one round of the chip (T2S_SB_HALF=0: never): the attention
+    // cell's transposed GEMM of the BPTT loop (1792 rows = 112 workgroups at 32 items) pulls 512 instead of 768 KB per CU
+    static const bool half_ok = !(getenv("T2S_SB_HALF") && atoi(getenv("T2S_SB_HALF")) == 0);
+    const bool half = half_ok && a.items > 16 && (long)grid.x * ((a.items + 15) / 16) <= 256;
+    if (half) grid.y = (a.items + 15) / 16;
+    if (sb_wide_ok(a.n1 + a.n2 + a.n3, a.k1, a.n1, a.n2, a.n3))
+        return half ? sb_launch<32, GemvArgs, 1>(sbgemm_plain_kernel<32, true>, a, grid, stream) : sb_launch<32>(sbgemm_plain_kernel<32>, a, grid, stream);
+    return half ? sb_launch<16, GemvArgs, 1>(sbgemm_plain_kernel<16, true>, a, grid, stream) : sb_launch<16>(sbgemm_plain_kernel<16>, a, grid, stream);
+#else
     return sb_launch<16>(sbgemm_plain_kernel<16>, a, grid, stream);
+#endif
 }
 
 // ---- fused LSTMCell epilogue: LstmCellArgs semantics ---------------------------------------------------------------
