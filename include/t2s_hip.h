@@ -19,7 +19,7 @@
  *    on that device: (a) t2s_taco_bptt_steps keeps two helper streams + five events
  *    per device behind a per-device mutex (it overlaps dependent chains; on every
  *    exit, error exits included, the caller's stream waits for both helpers; with
- *    T2S_DECODE_SPLIT=1 t2s_taco_decode_steps borrows the first helper the same way);
+ *    t2s_taco_decode_steps borrows the first helper the same way for teacher-forced steps with saves);
  *    (b) the GEMM launchers remember per device that they raised the kernel's
  *    dynamic-LDS limit (an idempotent one-bit flag); (c) t2s_last_hip_error()
  *    is per thread.  Nothing else persists between calls.

@@ -150,11 +150,10 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
     // Teacher-forced decoding with the per-step saves at hand (training): the decoder cell of step s feeds only the decoder
     // cell of step s + 1 and the projection after the loop - never the attention chain (attention cell -> query -> energies ->
     // softmax + context), whose next prenet input is given.  So it runs on the library's helper stream from the saved copies
-    // of h_att[s] and ctx[s] (att_h_all, hc_all) and drops out of the serial chain.  OFF unless T2S_DECODE_SPLIT=1: measured
-    // 128.0 vs 128.2 ms per train step (profiles/r03_taco_timeline_fwd.md) - the event record on the critical stream opens a 7 us
-    // gap before the next attention cell, and the 8-workgroup query GEMM waits for a CU behind the decoder cell's 256 workgroups
-    // (both hold 96 KB of LDS: 7.3 -> 19 us), which together eat the 11.5 us the decoder cell no longer takes.
-    static const bool want_split = getenv("T2S_DECODE_SPLIT") && atoi(getenv("T2S_DECODE_SPLIT"));
+    // of h_att[s] and ctx[s] (att_h_all, hc_all), a chunk of steps behind the attention chain, and drops out of the serial chain.
+    // With one event per STEP this measured equal (128.0 vs 128.2 ms per train step, profiles/r03_taco_timeline_fwd_split.md: the
+    // record opens a 7 us gap on the critical stream); with one event per 16 steps: 95.7 -> 91.9 ms.  T2S_DECODE_SPLIT=0: off.
+    static const bool want_split = !(getenv("T2S_DECODE_SPLIT") && atoi(getenv("T2S_DECODE_SPLIT")) == 0);
     const bool split = d->teacher_forced && d->att_h_all && d->hc_all && want_split;
     T2sHelperStream hs;
     if (split) T2S_CHECK_HIP(t2s_helper_stream_acquire(hs));
@@ -164,11 +163,12 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
             if (on && hipEventRecord(hs.ev_join, hs.side) == hipSuccess) (void)hipStreamWaitEvent(stream, hs.ev_join, 0);
         }
     } join{hs, stream, split};
-    for (int s = step0; s < step0 + n_steps; ++s) {
+    auto body = [&](int s, bool do_att, bool do_dec) -> int {
         float* ah_in = (s & 1) ? d->att_h1 : d->att_h0;
         float* ah_out = (s & 1) ? d->att_h0 : d->att_h1;
         float* dh_in = (s & 1) ? d->dec_h1 : d->dec_h0;
         float* dh_out = (s & 1) ? d->dec_h0 : d->dec_h1;
+        if (do_att) {
         // 1. attention LSTMCell on [prenet_out | context]
         LstmCellArgs ca;
         memset(&ca, 0, sizeof(ca));
@@ -216,6 +216,8 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
             T2S_CHECK_HIP(t2s_launch_att_energy(aa, stream));
             T2S_CHECK_HIP(t2s_launch_att_softmax_ctx(aa, stream));
         }
+        }
+        if (!do_dec) return T2S_OK;
         // 5. decoder LSTMCell on [h_att | context]
         LstmCellArgs cd;
         memset(&cd, 0, sizeof(cd));
@@ -225,8 +227,6 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         if (split) {
             cd.x1 = d->att_h_all + (size_t)s * B * A;
             cd.x2 = d->hc_all + (size_t)s * B * (D + E) + D; cd.sx2 = D + E;
-            T2S_CHECK_HIP(hipEventRecord(hs.ev_step, stream));        // h_att[s], ctx[s] saved (and all earlier work of the caller)
-            T2S_CHECK_HIP(hipStreamWaitEvent(hs.side, hs.ev_step, 0));
             dstream = hs.side;
         }
         cd.h_in = dh_in; cd.h_out = dh_out; cd.c = d->dec_c; cd.B = B; cd.H = D;
@@ -272,6 +272,22 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
                 T2S_CHECK_HIP(t2s_launch_gemv(p2, stream));
             }
         }
+        return T2S_OK;
+    };
+    if (split) {
+        // the attention chain of `chunk` steps, ONE event, then the decoder cells of those steps on the helper stream while the
+        // caller's stream goes on with the next chunk (T2S_DECODE_CHUNK, default 16)
+        static const int chunk_env = getenv("T2S_DECODE_CHUNK") ? atoi(getenv("T2S_DECODE_CHUNK")) : 16;
+        const int chunk = chunk_env > 0 ? chunk_env : 1;
+        for (int c0 = step0; c0 < step0 + n_steps; c0 += chunk) {
+            const int c1 = c0 + chunk < step0 + n_steps ? c0 + chunk : step0 + n_steps;
+            for (int s = c0; s < c1; ++s) { const int rc = body(s, true, false); if (rc != T2S_OK) return rc; }
+            T2S_CHECK_HIP(hipEventRecord(hs.ev_step, stream));        // h_att, ctx of the chunk saved (and all earlier work of the caller)
+            T2S_CHECK_HIP(hipStreamWaitEvent(hs.side, hs.ev_step, 0));
+            for (int s = c0; s < c1; ++s) { const int rc = body(s, false, true); if (rc != T2S_OK) return rc; }
+        }
+    } else {
+        for (int s = step0; s < step0 + n_steps; ++s) { const int rc = body(s, true, true); if (rc != T2S_OK) return rc; }
     }
     return T2S_OK;
 }
