@@ -505,14 +505,16 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_kernel(const AttArgs a) {
 __global__ __launch_bounds__(512) void att_energy_mfma_kernel(const AttArgs a) {
     constexpr int AD = 128;
     __shared__ float s_cat[2][ATT_MQ + 64];
-    __shared__ float s_kb[64 * 48];            // conv kernel as B operand [k = c * KS + j][f], rows >= 2 KS zero
+    // 13 KB of LDS in all, so that a workgroup fits on a CU next to a small-batch GEMM workgroup (144 KB ring): in training the
+    // decoder cells run on a helper stream beside this chain
+    __shared__ float s_kb[2 * 64 * 16];        // conv kernel as B operand, one half per filter tile: [f / 16][k = c * KS + j][f % 16], rows >= 2 KS zero
     __shared__ float s_f[ATT_MQ * 33];
-    __shared__ float s_e[8][ATT_MQ];
+    float (*s_e)[ATT_MQ] = (float (*)[ATT_MQ])s_kb;      // [8][32] partial energies (after the features: s_kb is free)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int b = blockIdx.y, t0 = blockIdx.x * ATT_MQ;
     const int T = a.T, KS = a.loc_ks, pad = KS >> 1, K2 = 2 * KS;
-    for (int i = tid; i < 64 * 48; i += 512) s_kb[i] = 0.f;
+    for (int i = tid; i < 2 * 64 * 16; i += 512) s_kb[i] = 0.f;
     for (int i = tid; i < 2 * (ATT_MQ + KS - 1); i += 512) {
         const int c = i / (ATT_MQ + KS - 1), j = i - c * (ATT_MQ + KS - 1);
         const int t = t0 + j - pad;
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(512) void att_energy_mfma_kernel(const AttArgs a) {
         const int i = tid + j * 512;
         if (i < 32 * K2) {
             const int f = i / K2, k = i - f * K2;
-            s_kb[k * 48 + f] = rk[j];
+            s_kb[(f >> 4) * 1024 + k * 16 + (f & 15)] = rk[j];
         }
     }
     __syncthreads();
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(512) void att_energy_mfma_kernel(const AttArgs a) {
             const int kc = k < K2 ? k : 0;     // (B rows >= 2 KS are zero)
             const int c = kc >= KS ? 1 : 0, j = kc - c * KS;
             av[u] = s_cat[c][16 * tt + lr + j];
-            bv[u] = s_kb[k * 48 + 16 * ft + lr];
+            bv[u] = s_kb[ft * 1024 + k * 16 + lr];
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
