@@ -312,11 +312,15 @@ int t2s_wg_res_only(const void* A_hi, const void* A_lo, const float* bias, const
     a.xc = cdiv(C, 32); a.sc = 0; a.oc = cdiv(C, 32);
     a.taps = 1; a.dil = 1; a.nk_x = a.xc; a.nk = a.xc;
     a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
-    a.n_mtiles = cdiv(C, 128); a.n_ttiles = cdiv(L, 256);
+    // T2S_RES_TILE=256 (with T2S_RES_PAIR8=0: the 16-byte epilogue exists for 128-row tiles only): 256-row tiles, half the
+    // workgroups - the A/B behind DESIGN.md section 8 item 3
+    static const int tile_env = getenv("T2S_RES_TILE") ? atoi(getenv("T2S_RES_TILE")) : 0;
+    const int rows = (tile_env == 256 && !pair8) ? 256 : 128;
+    a.n_mtiles = cdiv(C, rows); a.n_ttiles = cdiv(L, 256);
     a.C = 0; a.n_res = C;
     if (pair8 && C % 32) return T2S_EINVAL;
     a.pair8 = pair8 ? 1 : 0;
-    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_RESSKIP, (hipStream_t)stream, 128));
+    T2S_CHECK_HIP(t2s_launch_conv_gemm(a, EPI_RESSKIP, (hipStream_t)stream, rows));
     return T2S_OK;
 }
 
