@@ -14,6 +14,7 @@ Structure of the backward (all through the C ABI of libt2s_hip.so):
   encoder  : BiLSTM BPTT, convolutions, embedding
 """
 import ctypes
+import os
 
 import torch
 
@@ -351,6 +352,17 @@ class _Bwd:
                       _p(d_memory), None, None, 0, st)
             self.keep += [dctx_all, Am, Xm, Pm_]
         self.keep += [dw_buf, df_buf, dq_part, dw_c2, dwc_c2]
+        # ---- d_memory is final once the memory layer's share is in: the encoder BiLSTM's BPTT starts now, on the side stream ----
+        items_m = B * T_in
+        W_mT = self.transpose(P["w_mem"])                                    # [E][ad]
+        d_mem2 = self.new(B, T_in, E)
+        self.gemv(W_mT, ad, ad, _p(d_pmem), ad, _p(d_mem2), E, E, items_m)
+        d_mem_tot = self.new(B, T_in, E)
+        _lib.call("t2s_add3", _p(d_memory), _p(d_mem2), None, d_mem_tot.numel(), _p(d_mem_tot), st)
+        self.d_memory = d_mem_tot
+        if os.environ.get("T2S_ENC_BWD_SIDE", "1") != "0":
+            from .autograd_encoder import encoder_lstm_backward
+            self.enc_pending = encoder_lstm_backward(self, d_mem_tot)
         # ---- weight gradients over all (step, batch) items ----
         ar = dec.attention_rnn
         Pa, ks, M4, N = self.items_wgrad(items, [(_p(dg_a), 4 * A, 4 * A, 0, 0)],
@@ -367,14 +379,8 @@ class _Bwd:
         Pq, ks, M4, N = self.items_wgrad(items, [(_p(dq_all), ad, ad, 0, 0)], [(_p(S["att_h_all"]), A, A, 0, 0)], ad, A)
         self.slab_to_grad(Pq, ks, M4, N, al.query_layer.linear_layer.weight, ad, A, 0)
         # memory layer: pmem = W_mem memory
-        items_m = B * T_in
         Pm, ks, M4, N = self.items_wgrad(items_m, [(_p(d_pmem), ad, ad, 0, 0)], [(_p(memory), E, E, 0, 0)], ad, E)
         self.slab_to_grad(Pm, ks, M4, N, al.memory_layer.linear_layer.weight, ad, E, 0)
-        W_mT = self.transpose(P["w_mem"])                                    # [E][ad]
-        d_mem2 = self.new(B, T_in, E)
-        self.gemv(W_mT, ad, ad, _p(d_pmem), ad, _p(d_mem2), E, E, items_m)
-        d_mem_tot = self.new(B, T_in, E)
-        _lib.call("t2s_add3", _p(d_memory), _p(d_mem2), None, d_mem_tot.numel(), _p(d_mem_tot), st)
         # attention parameters accumulated per batch element
         loc = al.location_layer
         for part, param, n in ((dD_p, loc.location_dense.linear_layer.weight, ad * F_),
