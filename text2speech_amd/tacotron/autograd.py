@@ -109,7 +109,9 @@ class _Bwd:
         return torch.zeros(*shape, dtype=torch.float32, device=self.dev)
 
     def close(self):
-        """Remember the arena size this pass needed (the next pass of this engine allocates it)."""
+        """Join the helper stream; remember the arena size this pass needed (the next pass of this engine allocates it)."""
+        if self.__dict__.get("side_used"):
+            torch.cuda.current_stream(self.dev).wait_stream(self.side_stream())
         self.eng.zero_arena_elems = max(getattr(self.eng, "zero_arena_elems", 0), self._za_need)
 
     def bf(self, *shape, tag=None):
@@ -174,10 +176,21 @@ class _Bwd:
         self.keep.append(w)
 
     # ------------------------------------------------------------------ conv + BatchNorm stack (postnet / encoder)
-    def conv_bn_stack_backward(self, saves, dout_f32=None, dout_planes=None):
+    def side_stream(self):
+        """The engine's helper stream for work nothing on the backward's dependent chain waits for (joined in close())."""
+        side = getattr(self.eng, "enc_side_stream", None)
+        if side is None:
+            side = self.eng.enc_side_stream = torch.cuda.Stream(device=self.dev)
+        return side
+
+    def conv_bn_stack_backward(self, saves, dout_f32=None, dout_planes=None, wgrad_side=False):
         """Backward of [conv -> BN(batch stats) -> act -> dropout] x n.  The gradient of the stack's output comes as f32
-        [B][C_last][T] or as planes.  Returns the gradient w.r.t. the stack's input as planes (hi, lo)."""
+        [B][C_last][T] or as planes.  Returns the gradient w.r.t. the stack's input as planes (hi, lo).
+        wgrad_side: the weight gradients (nothing downstream needs them) go to the helper stream, layer by layer behind an
+        event - for the postnet they then run beside the decoder's BPTT loop, which leaves most of the chip idle."""
         d_planes = dout_planes
+        main_t = torch.cuda.current_stream(self.dev)
+        side_t = self.side_stream() if wgrad_side else None
         for i in reversed(range(len(saves))):
             s = saves[i]
             conv, bn, layer = s["seq"][0].conv, s["seq"][1], s["layer"]
@@ -208,6 +221,12 @@ class _Bwd:
             Npad = _ru(N, 256)
             A = (self.bf(B, nt, Mpad, 32, tag=("cs_Ah", cs_)), self.bf(B, nt, Mpad, 32, tag=("cs_Al", cs_)))
             X = (self.bf(B, nt, Npad, 32, tag=("cs_Xh", cs_)), self.bf(B, nt, Npad, 32, tag=("cs_Xl", cs_)))
+            st_main = self.st
+            if side_t is not None:          # dconv is final: the weight-gradient sequence of this layer moves to the helper stream
+                ev = torch.cuda.Event()
+                ev.record(main_t)
+                side_t.wait_event(ev)
+                self.st = _lib.c_vp(side_t.cuda_stream)
             _lib.call("t2s_plane_transpose", _p(dconv[0]), _p(dconv[1]), B, occ, occ, Lp, 0, _p(A[0]), _p(A[1]), Mpad, 0, self.st)
             icc = Cin_pad // 32
             for tap in range(Kt):
@@ -220,6 +239,9 @@ class _Bwd:
                       Npad, nt, 0, nt, 1, self.st)
             self.slab_to_grad(P, B, M4, N, conv.weight, Cout, Cin, 0, conv.bias, Kt=Kt, tap_stride=Cin_pad)
             self.keep += [A, X, P]
+            if side_t is not None:
+                self.st = st_main
+                self.side_used = True
             # data gradient: convolution of dconv with the transposed, tap-mirrored weight
             w32 = _f32(conv.weight)
             Opad = _ru(Cout, 32)
@@ -251,7 +273,7 @@ class _Bwd:
         g_mel_post = self.zeros(B, n_mel, T) if g_mel_post is None else g_mel_post.to(torch.float32).contiguous()
         g_gate = self.zeros(B, T) if g_gate is None else g_gate.to(torch.float32).contiguous()
         # ---- postnet: mel_post = mel + postnet(mel) ----
-        d_in = self.conv_bn_stack_backward(sv["post_convs"], g_mel_post)
+        d_in = self.conv_bn_stack_backward(sv["post_convs"], g_mel_post, wgrad_side=os.environ.get("T2S_POSTNET_WGRAD_SIDE", "0") == "1")
         d_mel = self.new(B, n_mel, T)
         _lib.call("t2s_add3", _p(g_mel), _p(g_mel_post), None, d_mel.numel(), _p(d_mel), st)
         s0 = sv["post_convs"][0]

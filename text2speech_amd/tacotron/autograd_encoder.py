@@ -1,5 +1,7 @@
 """Encoder part of the Tacotron-2 backward (reference tacotron.py:192-209 under autograd): BiLSTM BPTT, the input
 projection's weight / data gradients through the GEMM paths, the conv + BatchNorm stack, and the embedding."""
+import os
+
 import torch
 
 from .. import _lib
@@ -85,7 +87,7 @@ def encoder_backward(bw, d_memory):
     _lib.call("t2s_conv_accumulate", _p(At[0]), _p(At[1]), _p(bw.zero_bias), _p(dgp[0]), _p(dgp[1]), 0, _p(dx[0]), _p(dx[1]), B, M,
               Cin, 1, 1, 1, T, Lp, halo, Mi, st)
     # ---- conv + BatchNorm stack, then the embedding ----
-    d_emb_in = bw.conv_bn_stack_backward(sv["enc_convs"], dout_planes=dx)
+    d_emb_in = bw.conv_bn_stack_backward(sv["enc_convs"], dout_planes=dx, wgrad_side=os.environ.get("T2S_ENC_WGRAD_SIDE", "0") == "1")
     E = m.embedding.embedding_dim
     V = m.embedding.num_embeddings
     d_emb = bw.new(V, E)
