@@ -1141,8 +1141,8 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
         }
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
-        // the running dwc total of the chunk's own positions sits in threads 0-31 (row_dwc): own-slot threads fetch it by shuffle
-        // within... (different waves) -> through LDS
+        // the running dwc total of the chunk's own positions sits in threads 0-31 (row_dwc); the threads that write the own slot
+        // are spread over all waves, so it travels through LDS (s_dw is free by now)
         if (tid < ATTB_CH) s_dw[tid] = row_dwc;
         __syncthreads();
         const int tp = t0 - pad + q;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: where one launch of the one-launch attention backward (att_bwd_fused_kernel) spends its time.  Needs a library built
-with -DT2S_ATTF_STAMPS (T2S_LIB_PATH points at it): workgroup (0, 0) records the 100 MHz clock at its phase boundaries; this runs
+with -DT2S_ATTF_STAMPS (recompile csrc/taco_bwd_ops.hip with that define, link it with the other objects of csrc/ into e.g.
+text2speech_amd/libt2s_hip_stamps.so - never over the shipped library - and point T2S_LIB_PATH at it): workgroup (0, 0) records the 100 MHz clock at its phase boundaries; this runs
 a few Tacotron train steps (B = 32, T_in = 256) and prints the deltas of the last launch in us."""
 import ctypes
 import os
