@@ -481,8 +481,13 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             conv_rs, conv_in, conv_c = wn.res_skip_layers[i], wn.in_layers[i], wn.cond_layers[i]
             # 1. d_pre = gate'(T,G) * (W_rs^T [dx ; dS])                                                     [main]
             A_rsT, A_inT, A_cT = ts.A_rsT[k][i], ts.A_inT[k][i], ts.A_cT[k]
-            ev_in = torch.cuda.Event()          # DX / DS of this layer are final (last written on the main stream)
-            ev_in.record(main_s)
+            # (one event per layer on the data-gradient stream when the res/skip weight gradient runs there: each record is a ~7 us
+            # bubble in front of the next kernel of the recording stream; T2S_WG_FEW_EVENTS=0: one per consumer as before)
+            few_ev = cl and p1_main and os.environ.get("T2S_WG_FEW_EVENTS", "1") != "0"
+            ev_in = None
+            if not few_ev:
+                ev_in = torch.cuda.Event()      # DX / DS of this layer are final (last written on the main stream)
+                ev_in.record(main_s)
             # this layer's slice of the flow-wide d_pre planes (bytes from the start of each plane)
             dp_off = 2 * i * 2 * xc * Lp * 32
             dp_h, dp_l = _lib.c_vp(DP[0].data_ptr() + dp_off), _lib.c_vp(DP[1].data_ptr() + dp_off)
@@ -491,8 +496,10 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             _lib.call("t2s_wg_bwd_gate_dgrad", _ptr(A_rsT[0]), _ptr(A_rsT[1]), _ptr(zb),
                       None if last else _ptr(ts.DX[0]), None if last else _ptr(ts.DX[1]), _ptr(DS[0]), _ptr(DS[1]),
                       a_h, a_l, g_h, g_l, ts.act_bchunks, dp_h, dp_l, ts.dp_chunks, B, C, L, Lp, halo, ts.Mc, st)
-            ev_dp = torch.cuda.Event()
-            ev_dp.record(main_s)
+            ev_dp = None
+            if not few_ev:
+                ev_dp = torch.cuda.Event()
+                ev_dp.record(main_s)
             # 2. dW_rs = [dx ; dS] . acts^T  (+ bias column)                                                 [side, or main]
             d = 2 ** i
             P1 = ts.P1
@@ -541,7 +548,8 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
                 p1_free[pb] = torch.cuda.Event()
                 p1_free[pb].record(side_s)
             # 3. dW_in, dW_cond = d_pre . [x taps | spect | 1]^T                                             [side]
-            side_s.wait_event(ev_dp)
+            if ev_dp is not None:
+                side_s.wait_event(ev_dp)        # (few_ev: the wait for ev_p1 above covers d_pre too - recorded later on the same stream)
             if cl:
                 _lib.call("t2s_wgrad_cl", _ptr(ta2), ta2.size(0), _ptr(tb2), tb2.size(0), _ptr(ts.P2), B, 2 * C, ts.N2, ts.ld2,
                           ts.k0, ts.k1, ts.ks2, 0, st2)
