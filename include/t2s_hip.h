@@ -292,7 +292,11 @@ typedef struct t2s_taco_decoder {
 } t2s_taco_decoder;
 
 /* Enqueue decoder steps [step0, step0+n_steps) (Decoder.decode, tacotron.py:355-393, plus in autoregressive mode
- * the projection and the prenet of the next step, tacotron.py:447-461) on `stream` without host synchronisation. */
+ * the projection and the prenet of the next step, tacotron.py:447-461) on `stream` without host synchronisation.
+ * Teacher-forced with att_h_all and hc_all given (training): the decoder LSTM cells - which feed nothing but the next decoder cell
+ * and the projection after the loop - are enqueued on a library-owned helper stream, T2S_DECODE_CHUNK (16) steps behind the
+ * attention chain, reading h_att / ctx from those saves; `stream` has been made to wait for the helper when the call returns
+ * (T2S_DECODE_SPLIT=0: everything on `stream`). */
 int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, void* stream);
 
 /* stop_step[b] = first step in [step0, step0+n) with sigmoid(gate) > threshold, if still -1 (tacotron.py:455) */
