@@ -87,7 +87,7 @@ def _run(B, T, KS, seed):
     return out
 
 
-@pytest.mark.parametrize("B,T,KS", [(3, 70, 31), (2, 33, 31), (3, 256, 31), (3, 96, 5), (1, 20, 31)])
+@pytest.mark.parametrize("B,T,KS", [(3, 70, 31), (2, 33, 31), (3, 256, 31), (3, 96, 5), (1, 20, 31), (2, 600, 31)])
 def test_one_launch_matches_three_launches(B, T, KS):
     out = _run(B, T, KS, seed=100 + T + KS)
     for k, ref in out["three"].items():
