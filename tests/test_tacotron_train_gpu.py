@@ -409,6 +409,64 @@ def test_pooled_buffers_carry_nothing_between_steps():
         assert torch.equal(grads_b[n], grads_f[n]), n
 
 
+def test_pooled_planes_cleared_when_padded_length_shrinks():
+    """ADVICE r3 (high x2): operand planes are pooled by SHAPE, and the padded row count Lp = ceil(T/256)*256 + 2*halo is the
+    same for 256 different T.  The reference's collate pads every batch to its own maximum (utils/data_utils.py:117), so a batch
+    padded to T = 37/33 follows one padded to 40/36 on the same buffers: rows 33..35 must read as the k=5 convolutions' ZERO
+    padding (forward: encoder / postnet layers and, through the batch statistics, every output; backward: the weight-gradient
+    contraction over the whole plane and the data gradient's last two frames).  Second step bit-identical to a fresh model; the
+    pool is also run with a tiny cap so that eviction happens between the two steps of a third model."""
+    from text2speech_amd.tacotron import Tacotron, Tacotron2Loss
+    from text2speech_amd.tacotron.tacotron import BufferPool
+    _lib.load()
+    B = 6
+    gen = torch.Generator().manual_seed(19)
+    shapes = [(40, 36), (37, 33)]
+    batches = [_ragged(B, ti, to, gen, din=lambda i: 0, dout=lambda i: 0) for ti, to in shapes]
+    masks = [_seeded_masks(B, ti, to, gen) for ti, to in shapes]
+    crit = Tacotron2Loss()
+
+    def step(m, k):
+        text, in_len, mel_t, gate_t, out_len = batches[k]
+        tm, pm, _ = masks[k]
+        m.load_state_dict(synth.tacotron_state(), strict=True)
+        m.zero_grad(set_to_none=True)
+        out = m((text.to(DEV), in_len.to(DEV), mel_t.to(DEV), int(in_len.max()), torch.zeros(B, device=DEV), out_len.to(DEV)),
+                prenet_masks=pm, train_masks=tm)
+        crit(out, (mel_t.to(DEV), gate_t.to(DEV))).backward()
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in out], {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    def fresh(cap=None):
+        m = Tacotron(HP, 80, num_speakers=2)
+        m.load_state_dict(synth.tacotron_state(), strict=True)
+        m = m.to(DEV).train()
+        if cap is not None:
+            m._eng().pool = BufferPool(cap_bytes=cap)
+        return m
+
+    out_f, grads_f = step(fresh(), 1)
+    m = fresh()
+    step(m, 0)
+    out_b, grads_b = step(m, 1)
+    for a, b in zip(out_b, out_f):
+        assert torch.equal(a, b)
+    assert sorted(grads_b) == sorted(grads_f)
+    for n in grads_f:
+        assert torch.equal(grads_b[n], grads_f[n]), n
+    # bounded pool: a 1 MB cap evicts nearly everything a step returns; results unchanged, pool stays under the cap
+    m2 = fresh(cap=1 << 20)
+    step(m2, 0)
+    out_c, grads_c = step(m2, 1)
+    pool = m2._eng().pool
+    m2.__dict__.pop("_last_bwd", None)
+    assert pool.evicted > 0 and pool.free_bytes <= pool.cap_bytes, (pool.evicted, pool.free_bytes)
+    for a, b in zip(out_c, out_f):
+        assert torch.equal(a, b)
+    for n in grads_f:
+        assert torch.equal(grads_c[n], grads_f[n]), n
+
+
 def test_dropout_masks_fresh_per_call_and_reproducible():
     """Every training forward / inference draws NEW dropout masks (reference: F.dropout on the global RNG,
     modules.py:21, tacotron.py:193,368,383) and torch.manual_seed reproduces them."""

@@ -37,8 +37,12 @@ def reduce_tensor(tensor, num_gpus):
     return rt
 
 
-def _avg_op():
-    return dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM
+def _avg_op(backend=None):
+    """AVG where the backend of the group that runs the collective has it (RCCL); SUM (then scaled by 1/world) elsewhere -
+    gloo rejects ReduceOp.AVG.  ``backend``: that group's backend (default: the default group's)."""
+    if backend is None:
+        backend = dist.get_backend()
+    return dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM
 
 
 class GradSync:
@@ -49,6 +53,8 @@ class GradSync:
     records an event behind it, so the compute streams are never blocked by a collective until ``finish()``, and every bucket has
     a (ready, done) event pair of its own - the per-bucket timing an 8-GPU run needs to be diagnosable:
     ``stats()`` returns, per bucket of the last step, bytes, ready -> complete ms and the gap to the previous completion.
+    The overlap holds for RCCL ("nccl") groups only: there ``h.wait()`` is a stream-level dependency.  On a gloo group with
+    device tensors (the CPU rehearsal path) ``h.wait()`` blocks the host until the bucket is averaged - correct, not overlapped.
     """
 
     def __init__(self, group=None, timing=True):
@@ -65,7 +71,7 @@ class GradSync:
     def reduce_async(self, flat, ready_events=()):
         """Start averaging one flat gradient bucket; returns immediately.  ``ready_events``: events recorded by the caller, one
         per stream that wrote gradients into the bucket, each after its last write (default: now, on the current stream)."""
-        op = _avg_op()
+        op = _avg_op(self.backend)
         cuda = flat.is_cuda
         if cuda and self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream(device=flat.device)

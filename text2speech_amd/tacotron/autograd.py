@@ -19,7 +19,7 @@ import os
 import torch
 
 from .. import _lib
-from .tacotron import _f32, pool_take
+from .tacotron import _f32, pool_take, BufferPool
 
 vp, i32, f32c, lng = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long
 
@@ -77,7 +77,7 @@ class _Bwd:
         self.grads = {}
         self.keep = []
         if eng.pool is None:
-            eng.pool = {}
+            eng.pool = BufferPool()
         self.leases = []            # buffers of this backward pass, back in the engine's pool when it is released
         self.zero_bias = pool_take(eng.pool, self.leases, "zero_bias", (8192,), torch.float32, self.dev, zero_once=True)
         self._seq = 0
@@ -114,14 +114,15 @@ class _Bwd:
             torch.cuda.current_stream(self.dev).wait_stream(self.side_stream())
         self.eng.zero_arena_elems = max(getattr(self.eng, "zero_arena_elems", 0), self._za_need)
 
-    def bf(self, *shape, tag=None):
+    def bf(self, *shape, tag=None, extent=()):
         """bf16 operand planes.  Their producers write the valid region and leave padding (halo rows, rows / columns / K-blocks
         past the operand's extent) untouched, and that padding must read as zero.  Which elements are padding depends on the
-        shape and the call site only - never on the data or on sequence lengths (ragged entries are zeroed BY VALUE inside the
-        valid region) - so a pooled buffer zeroed once at creation stays correct: tag = the call site (+ loop index where several
-        are alive at once).  No tag: a fresh zero-filled tensor."""
+        shape, the call site and the valid row counts `extent` (the batch's padded T, the item count: several of them share one
+        padded shape) - never on the data or on per-entry lengths (ragged entries are zeroed BY VALUE inside the valid region).
+        A pooled buffer (tag = the call site, + loop index where several are alive at once) is zeroed at creation and again
+        whenever it is handed out for a different extent.  No tag: a fresh zero-filled tensor."""
         if tag is not None:
-            return pool_take(self.eng.pool, self.leases, tag, shape, torch.bfloat16, self.dev, zero_once=True)
+            return pool_take(self.eng.pool, self.leases, tag, shape, torch.bfloat16, self.dev, zero_once=True, extent=tuple(extent))
         return torch.zeros(*shape, dtype=torch.bfloat16, device=self.dev)
 
     def seq(self):
@@ -150,8 +151,9 @@ class _Bwd:
         N = N_cols + 1
         Npad = _ru(N, 256)
         n_ = self.seq()             # the n-th call of a backward pass is the same call site in every step
-        A = (self.bf(nch, Mpad, 32, tag=("iw_Ah", n_)), self.bf(nch, Mpad, 32, tag=("iw_Al", n_)))
-        X = (self.bf(nch, Npad, 32, tag=("iw_Xh", n_)), self.bf(nch, Npad, 32, tag=("iw_Xl", n_)))
+        ex = (items,)
+        A = (self.bf(nch, Mpad, 32, tag=("iw_Ah", n_), extent=ex), self.bf(nch, Mpad, 32, tag=("iw_Al", n_), extent=ex))
+        X = (self.bf(nch, Npad, 32, tag=("iw_Xh", n_), extent=ex), self.bf(nch, Npad, 32, tag=("iw_Xl", n_), extent=ex))
         for (ptr, ld, C, off, shift) in a_srcs:
             _lib.call("t2s_rows_to_tm", ptr, ld, items, items_pad, shift, C, _p(A[0]), _p(A[1]), Mpad, off, self.st)
         for (ptr, ld, C, off, shift) in x_srcs:
@@ -198,7 +200,8 @@ class _Bwd:
             Cout, Cin, Kt = layer["Cout"], layer["Cin"], layer["taps"]
             occ = -(-Cout // 32)
             cs_ = self.seq()
-            dconv = (self.bf(B, occ, Lp, 32, tag=("cs_dch", cs_)), self.bf(B, occ, Lp, 32, tag=("cs_dcl", cs_)))
+            ex = (T,)
+            dconv = (self.bf(B, occ, Lp, 32, tag=("cs_dch", cs_), extent=ex), self.bf(B, occ, Lp, 32, tag=("cs_dcl", cs_), extent=ex))
             dgamma, dbeta = self.new(Cout), self.new(Cout)
             g32, b32 = _f32(bn.weight), _f32(bn.bias)
             a = _BnBwd(x=s["y"].data_ptr(), mean=s["mean"].data_ptr(), var=s["var"].data_ptr(), gamma=g32.data_ptr(),
@@ -219,8 +222,8 @@ class _Bwd:
             Ncols = Kt * Cin_pad
             N = Ncols + 1
             Npad = _ru(N, 256)
-            A = (self.bf(B, nt, Mpad, 32, tag=("cs_Ah", cs_)), self.bf(B, nt, Mpad, 32, tag=("cs_Al", cs_)))
-            X = (self.bf(B, nt, Npad, 32, tag=("cs_Xh", cs_)), self.bf(B, nt, Npad, 32, tag=("cs_Xl", cs_)))
+            A = (self.bf(B, nt, Mpad, 32, tag=("cs_Ah", cs_), extent=ex), self.bf(B, nt, Mpad, 32, tag=("cs_Al", cs_), extent=ex))
+            X = (self.bf(B, nt, Npad, 32, tag=("cs_Xh", cs_), extent=ex), self.bf(B, nt, Npad, 32, tag=("cs_Xl", cs_), extent=ex))
             st_main = self.st
             if side_t is not None:          # dconv is final: the weight-gradient sequence of this layer moves to the helper stream
                 ev = torch.cuda.Event()
@@ -248,7 +251,7 @@ class _Bwd:
             Mi = _lib.padded_rows(Cin)
             At = (self.bf(Kt * Opad // 32, Mi, 32, tag=("cs_Ath", cs_)), self.bf(Kt * Opad // 32, Mi, 32, tag=("cs_Atl", cs_)))
             _lib.call("t2s_pack_transposed", _p(w32), None, Cout, Cin, Kt, 1, Opad, Mi, 0, _p(At[0]), _p(At[1]), self.st)
-            d_in = (self.bf(B, icc, Lp, 32, tag=("cs_dih", cs_)), self.bf(B, icc, Lp, 32, tag=("cs_dil", cs_)))
+            d_in = (self.bf(B, icc, Lp, 32, tag=("cs_dih", cs_), extent=ex), self.bf(B, icc, Lp, 32, tag=("cs_dil", cs_), extent=ex))
             _lib.call("t2s_conv_accumulate", _p(At[0]), _p(At[1]), _p(self.zero_bias), _p(dconv[0]), _p(dconv[1]), 0, _p(d_in[0]),
                       _p(d_in[1]), B, Cout, _ru(Cin, 4), Kt, 1, 1, T, Lp, halo, Mi, self.st)
             self.keep += [w32, At, d_in]
@@ -360,8 +363,9 @@ class _Bwd:
             nch_ = items_pad // 32
             Mpad_, N_ = _lib.padded_rows(T_in), E + 1
             Npad_ = _ru(N_, 256)
-            Am = (self.bf(B, nch_, Mpad_, 32, tag="dmem_Ah"), self.bf(B, nch_, Mpad_, 32, tag="dmem_Al"))
-            Xm = (self.bf(B, nch_, Npad_, 32, tag="dmem_Xh"), self.bf(B, nch_, Npad_, 32, tag="dmem_Xl"))
+            ex = (T, T_in)
+            Am = (self.bf(B, nch_, Mpad_, 32, tag="dmem_Ah", extent=ex), self.bf(B, nch_, Mpad_, 32, tag="dmem_Al", extent=ex))
+            Xm = (self.bf(B, nch_, Npad_, 32, tag="dmem_Xh", extent=ex), self.bf(B, nch_, Npad_, 32, tag="dmem_Xl", extent=ex))
             _lib.call("t2s_rows_to_tm_batched", _p(align), T_in, T_cap * T_in, T, items_pad, 0, T_in, _p(Am[0]), _p(Am[1]),
                       nch_ * Mpad_ * 32, Mpad_, 0, B, st)
             _lib.call("t2s_rows_to_tm_batched", _p(dctx_all), B * E, E, T, items_pad, 0, E, _p(Xm[0]), _p(Xm[1]),

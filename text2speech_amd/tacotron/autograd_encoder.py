@@ -62,13 +62,13 @@ def encoder_backward(bw, d_memory):
     items_pad = nt * 32
     M = 8 * H
     Mpad = _lib.padded_rows(M)
-    A = (bw.bf(B, nt, Mpad, 32, tag="enc_Ah"), bw.bf(B, nt, Mpad, 32, tag="enc_Al"))
+    A = (bw.bf(B, nt, Mpad, 32, tag="enc_Ah", extent=(T,)), bw.bf(B, nt, Mpad, 32, tag="enc_Al", extent=(T,)))
     _lib.call("t2s_rows_to_tm_batched", _p(dgx), M, T * M, T, items_pad, halo, M, _p(A[0]), _p(A[1]), nt * Mpad * 32, Mpad, 0, B, st)
     Cin = lstm.input_size
     icc = _ru(Cin, 32) // 32
     N = Cin + 1
     Npad = _ru(N, 256)
-    X = (bw.bf(B, nt, Npad, 32, tag="enc_Xh"), bw.bf(B, nt, Npad, 32, tag="enc_Xl"))
+    X = (bw.bf(B, nt, Npad, 32, tag="enc_Xh", extent=(T,)), bw.bf(B, nt, Npad, 32, tag="enc_Xl", extent=(T,)))
     _lib.call("t2s_plane_transpose", _p(sv["enc_Xh"]), _p(sv["enc_Xl"]), B, icc, icc, Lp, 0, _p(X[0]), _p(X[1]), Npad, 0, st)
     _lib.call("t2s_tm_ones_row", _p(X[0]), _p(X[1]), B, Lp, halo, T, Npad, Cin, st)
     Pi = bw.new(B, M, N)
@@ -81,9 +81,9 @@ def encoder_backward(bw, d_memory):
     Mi = _lib.padded_rows(Cin)
     At = (bw.bf(M // 32, Mi, 32, tag="enc_Ath"), bw.bf(M // 32, Mi, 32, tag="enc_Atl"))
     _lib.call("t2s_pack_transposed", _p(w_cat), None, M, Cin, 1, 0, M, Mi, 0, _p(At[0]), _p(At[1]), st)
-    dgp = (bw.bf(B, M // 32, Lp, 32, tag="enc_dgph"), bw.bf(B, M // 32, Lp, 32, tag="enc_dgpl"))
+    dgp = (bw.bf(B, M // 32, Lp, 32, tag="enc_dgph", extent=(T,)), bw.bf(B, M // 32, Lp, 32, tag="enc_dgpl", extent=(T,)))
     _lib.call("t2s_rows_to_planes", _p(dgx), B, T, M, Lp, halo, _p(dgp[0]), _p(dgp[1]), st)
-    dx = (bw.bf(B, icc, Lp, 32, tag="enc_dxh"), bw.bf(B, icc, Lp, 32, tag="enc_dxl"))
+    dx = (bw.bf(B, icc, Lp, 32, tag="enc_dxh", extent=(T,)), bw.bf(B, icc, Lp, 32, tag="enc_dxl", extent=(T,)))
     _lib.call("t2s_conv_accumulate", _p(At[0]), _p(At[1]), _p(bw.zero_bias), _p(dgp[0]), _p(dgp[1]), 0, _p(dx[0]), _p(dx[1]), B, M,
               Cin, 1, 1, 1, T, Lp, halo, Mi, st)
     # ---- conv + BatchNorm stack, then the embedding ----

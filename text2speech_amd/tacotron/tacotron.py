@@ -141,34 +141,106 @@ def _f32(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+class BufferPool:
+    """Per-engine pool of step-sized device buffers, keyed by (call site, shape, dtype, device).
+
+    Bounded: the bytes sitting in free lists never exceed ``cap_bytes`` (default 16 GiB, ``T2S_POOL_CAP_GB``); when a returned
+    buffer takes the pool over the cap, the free lists of the least recently used keys are dropped (their memory goes back to
+    torch's caching allocator).  Batches padded to many different lengths (the reference's collate pads to the per-batch
+    maximum, utils/data_utils.py:117) therefore cost re-allocations, not unbounded growth.  Leased buffers are in no list."""
+
+    def __init__(self, cap_bytes=None):
+        import os
+        if cap_bytes is None:
+            cap_bytes = int(float(os.environ.get("T2S_POOL_CAP_GB", "16")) * (1 << 30))
+        self.cap_bytes = int(cap_bytes)
+        self.free = {}          # key -> [tensors]
+        self.stamp = {}         # key -> tick of the last take / give_back
+        self.free_bytes = 0
+        self.tick = 0
+        self.evicted = 0        # buffers dropped so far (diagnostics / tests)
+
+    def take(self, key):
+        self.tick += 1
+        self.stamp[key] = self.tick
+        lst = self.free.get(key)
+        if lst:
+            t = lst.pop()
+            self.free_bytes -= t.numel() * t.element_size()
+            return t
+        return None
+
+    def give_back(self, key, t):
+        self.tick += 1
+        self.stamp[key] = self.tick
+        self.free.setdefault(key, []).append(t)
+        self.free_bytes += t.numel() * t.element_size()
+        if self.free_bytes > self.cap_bytes:
+            self._evict(keep=key)
+
+    def _evict(self, keep=None):
+        for key in sorted(self.free, key=lambda k: self.stamp.get(k, 0)):
+            if self.free_bytes <= self.cap_bytes:
+                break
+            if key == keep and len(self.free) > 1:
+                continue
+            lst = self.free.pop(key)
+            self.stamp.pop(key, None)
+            for t in lst:
+                self.free_bytes -= t.numel() * t.element_size()
+                self.evicted += 1
+        if self.free_bytes > self.cap_bytes and keep in self.free:     # one key alone over the cap: keep its newest buffers
+            lst = self.free[keep]
+            while lst and self.free_bytes > self.cap_bytes:
+                t = lst.pop(0)
+                self.free_bytes -= t.numel() * t.element_size()
+                self.evicted += 1
+
+    def clear(self):
+        self.free.clear()
+        self.stamp.clear()
+        self.free_bytes = 0
+
+
 class _Lease:
-    """A buffer taken from the engine's per-shape pool; goes back when its holder (the autograd context of one step, or that
+    """A buffer taken from the engine's pool; goes back when its holder (the autograd context of one step, or that
     step's backward scratch) is released.  While leased it is in no free list, so two live steps never share a buffer; reuse is
     stream-ordered like the caching allocator's."""
 
-    def __init__(self, free, tensor):
-        self.free, self.tensor = free, tensor
+    def __init__(self, pool, key, tensor):
+        self.pool, self.key, self.tensor = pool, key, tensor
 
     def __del__(self):
         try:
-            self.free.append(self.tensor)
+            self.pool.give_back(self.key, self.tensor)
         except Exception:       # noqa: BLE001  (interpreter shutdown)
             pass
 
 
-def pool_take(pool, holder, tag, shape, dtype, device, zero_once=False):
-    """Buffer of `shape` for call site `tag`: reused from the pool when one is free (NOT cleared - either every element is
-    rewritten by the kernels that own it, or, with zero_once, the elements they never write were zeroed when the buffer was
-    created and depend on the shape only), else allocated.  `holder` (a list) keeps the lease."""
+def pool_take(pool, holder, tag, shape, dtype, device, zero_once=False, extent=None):
+    """Buffer of `shape` for call site `tag`: reused from the pool when one is free, else allocated.  `holder` (a list) keeps
+    the lease.  Three kinds of buffer:
+      * plain (zero_once=False): every element is rewritten by the kernels that own it - never cleared;
+      * zero_once with extent=None: the elements the kernels never write depend on the shape and the call site only (weight packs,
+        the zero bias) - zeroed when created;
+      * zero_once with an `extent` (the valid row counts the producers write, e.g. (T,) of a [.., Lp, 32] plane whose
+        Lp = ceil(T/256)*256 + 2*halo is shared by 256 different T): zeroed when created AND cleared again whenever the buffer
+        comes back out of the pool for a different extent - a batch padded to T = 780 must not read the previous batch's rows
+        780..799 as its convolutions' zero padding."""
     key = (tag, tuple(int(x) for x in shape), dtype, str(device))
-    free = pool.setdefault(key, [])
-    t = free.pop() if free else (torch.zeros if zero_once else torch.empty)(*shape, dtype=dtype, device=device)
-    holder.append(_Lease(free, t))
+    t = pool.take(key)
+    if t is None:
+        t = (torch.zeros if zero_once else torch.empty)(*shape, dtype=dtype, device=device)
+    elif zero_once and extent is not None and getattr(t, "_t2s_extent", None) != tuple(extent):
+        _lib.call("t2s_zero_fill", _lib.ptr(t), t.numel() * t.element_size(), _lib.current_stream())
+    if zero_once and extent is not None:
+        t._t2s_extent = tuple(extent)
+    holder.append(_Lease(pool, key, t))
     return t
 
 
 class _TacoEngine:
-    pool = None     # per-engine buffer pool (created on first use): {(tag, shape, dtype, device): [free tensors]}
+    pool = None     # per-engine BufferPool (created on first use)
 
     def __init__(self, model):
         self.m = model
@@ -277,17 +349,20 @@ class _TacoEngine:
         return P
 
     # ------------------------------------------------------------------ building blocks
-    def _planes(self, shape, dev, leases=None, tag=None):
-        """A (hi, lo) pair of bf16 operand planes whose padding (halo rows, channels past the operand's extent) must read as
-        zero.  The kernels that fill them write the whole valid region whatever the data, so inside a training step (leases = the
-        step's lease list) they come from the engine's pool, zeroed once when created; otherwise fresh zero-filled tensors."""
+    def _planes(self, shape, dev, leases=None, tag=None, extent=None):
+        """A (hi, lo) pair of bf16 operand planes whose padding (halo rows, rows past the valid length, channels past the operand's
+        extent) must read as zero.  The kernels that fill them write rows halo .. halo + T only, so inside a training step
+        (leases = the step's lease list) they come from the engine's pool, zeroed when created and again whenever the valid row
+        count `extent` = (T,) differs from the one the buffer last held (the padded row count Lp is shared by 256 different T);
+        otherwise fresh zero-filled tensors."""
         if leases is None or tag is None:
             hi = torch.zeros(*shape, dtype=torch.bfloat16, device=dev)
             return hi, torch.zeros_like(hi)
         if self.pool is None:
-            self.pool = {}
-        return (pool_take(self.pool, leases, tag + "_h", shape, torch.bfloat16, dev, zero_once=True),
-                pool_take(self.pool, leases, tag + "_l", shape, torch.bfloat16, dev, zero_once=True))
+            self.pool = BufferPool()
+        assert extent is not None, "pooled planes need their valid extent"
+        return (pool_take(self.pool, leases, tag + "_h", shape, torch.bfloat16, dev, zero_once=True, extent=extent),
+                pool_take(self.pool, leases, tag + "_l", shape, torch.bfloat16, dev, zero_once=True, extent=extent))
 
     def _conv(self, layer, Xh, Xl, B, L, Lp, halo, act, out_planes=True, out_f32=None, f32_cl=0):
         dev = Xh.device
@@ -316,14 +391,14 @@ class _TacoEngine:
             Lp = _lib.plane_rows(T, halo)
             ids64 = None
             emb32 = embedded.detach().to(torch.float32).contiguous()
-            Xh, Xl = self._planes((B, -(-E // 32), Lp, 32), dev, leases, "enc_x")
+            Xh, Xl = self._planes((B, -(-E // 32), Lp, 32), dev, leases, "enc_x", (T,))
             _lib.call("t2s_f32_to_planes", _lib.ptr(emb32), B, E, T, Lp, halo, _lib.ptr(Xh), _lib.ptr(Xl), st)
         else:
             dev = ids.device
             B, T = ids.shape
             Lp = _lib.plane_rows(T, halo)
             ids64 = ids.to(torch.int64).contiguous()
-            Xh, Xl = self._planes((B, -(-E // 32), Lp, 32), dev, leases, "enc_x")
+            Xh, Xl = self._planes((B, -(-E // 32), Lp, 32), dev, leases, "enc_x", (T,))
             _lib.call("t2s_embed_planes", _lib.ptr(ids64), _lib.ptr(P["emb"]), B, T, E, m.embedding.num_embeddings, Lp, halo,
                       _lib.ptr(Xh), _lib.ptr(Xl), st)
         if m.training:
@@ -349,7 +424,7 @@ class _TacoEngine:
         if save is not None:
             # (the recurrence writes, and its backward reads, the steps below each entry's length only: no clearing)
             if self.pool is None:
-                self.pool = {}
+                self.pool = BufferPool()
             gsave = pool_take(self.pool, leases, "enc_gsave", (B, T, 2, 4 * H), torch.float32, dev)
             csave = pool_take(self.pool, leases, "enc_csave", (B, T, 2, H), torch.float32, dev)
             save.update(enc_gates=gsave, enc_c=csave)
@@ -425,7 +500,7 @@ class _TacoEngine:
         dev = mel.device
         mel = mel.contiguous()
         leases = None if save is None else save.setdefault("_leases", [])
-        Xh, Xl = self._planes((B, -(-C // 32), Lp, 32), dev, leases, "post_x")
+        Xh, Xl = self._planes((B, -(-C // 32), Lp, 32), dev, leases, "post_x", (T,))
         _lib.call("t2s_f32_to_planes", _lib.ptr(mel), B, C, T, Lp, halo, _lib.ptr(Xh), _lib.ptr(Xl), _lib.current_stream())
         n = len(m.postnet.convolutions)
         out = torch.empty(B, C, T, dtype=torch.float32, device=dev)
@@ -473,7 +548,7 @@ class _TacoEngine:
         # the padding around it depends on that triple only (it is part of the tag).  The leases live in the layer dict, which
         # the step's saves reference too, so a buffer is not recycled while a backward still reads it.
         if self.pool is None:
-            self.pool = {}
+            self.pool = BufferPool()
         leases, tag = [], "pack_plain_%d_%d_%d" % (O, Cin, Kt)
         A_hi = pool_take(self.pool, leases, tag + "_h", (Kt * Cpad // 32, Mpad, 32), torch.bfloat16, dev, zero_once=True)
         A_lo = pool_take(self.pool, leases, tag + "_l", (Kt * Cpad // 32, Mpad, 32), torch.bfloat16, dev, zero_once=True)
@@ -496,7 +571,7 @@ class _TacoEngine:
         var = torch.empty(C, dtype=torch.float32, device=dev)
         Oh = Ol = None
         if want_planes:
-            Oh, Ol = self._planes((B, -(-C // 32), Lp, 32), dev, leases, tag)
+            Oh, Ol = self._planes((B, -(-C // 32), Lp, 32), dev, leases, tag, (T,))
         g, be = _f32(bn.weight), _f32(bn.bias)
         _lib.call("t2s_bn_train", _lib.ptr(y), _lib.ptr(g), _lib.ptr(be), float(bn.eps), act, _lib.ptr(mask), 2.0, B, C, T, Lp,
                   halo, _lib.ptr(mean), _lib.ptr(var), _lib.ptr(Oh), _lib.ptr(Ol), _lib.ptr(out_f32), _lib.current_stream())
@@ -630,7 +705,7 @@ class _TacoEngine:
             # query / cumulative weights of ALL batch entries and ALL encoder positions), so nothing is cleared: the buffers
             # come from the engine's pool and go back when this step's autograd context is released.
             if self.pool is None:
-                self.pool = {}
+                self.pool = BufferPool()
             leases = save.setdefault("_leases", [])
             zf = lambda name, *sh: pool_take(self.pool, leases, name, sh, torch.float32, dev)
             extra.update(att_gates_all=zf("att_gates_all", T_out, B, 4 * A_), att_c_all=zf("att_c_all", T_out, B, A_),
