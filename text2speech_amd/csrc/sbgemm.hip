@@ -382,7 +382,7 @@ __global__ __launch_bounds__(512) void sbgemm_lstm_kernel(const LstmCellArgs a) 
 }
 
 bool t2s_sbgemm_lstm_ok(const LstmCellArgs& a) {
-    if (a.B <= 8 || (a.H & 15) || (a.n1 & 15) || (a.n2 & 15) || a.q_part) return false;
+    if (a.B <= 8 || (a.H & 15) || (a.n1 & 15) || (a.n2 & 15) || a.q_part || a.pre_a || !a.h_in || a.ld_ih > 0) return false;
     if ((a.sx1 & 3) || (a.x2 && (a.sx2 & 3))) return false;
     if (((uintptr_t)a.W_ih & 15) || ((uintptr_t)a.W_hh & 15) || ((uintptr_t)a.x1 & 15) || ((uintptr_t)a.x2 & 15) ||
         ((uintptr_t)a.h_in & 15))

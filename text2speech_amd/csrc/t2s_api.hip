@@ -26,7 +26,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 extern "C" {
 
-int t2s_abi_version(void) { return 3; }
+int t2s_abi_version(void) { return 4; }
 
 const char* t2s_error_string(int code) {
     switch (code) {

@@ -163,11 +163,17 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
             if (on && hipEventRecord(hs.ev_join, hs.side) == hipSuccess) (void)hipStreamWaitEvent(stream, hs.ev_join, 0);
         }
     } join{hs, stream, split};
+    // Streamed gate partials (ABI v4, t2s_taco_decoder::gate_part): autoregressive small-batch decode only.  T2S_DECODE_STREAM=0: off.
+    static const bool want_stream = !(getenv("T2S_DECODE_STREAM") && atoi(getenv("T2S_DECODE_STREAM")) == 0);
+    const size_t GP = (size_t)B * 4 * A;                   // one [B][4H] block of gate_part
     auto body = [&](int s, bool do_att, bool do_dec) -> int {
         float* ah_in = (s & 1) ? d->att_h1 : d->att_h0;
         float* ah_out = (s & 1) ? d->att_h0 : d->att_h1;
         float* dh_in = (s & 1) ? d->dec_h1 : d->dec_h0;
         float* dh_out = (s & 1) ? d->dec_h0 : d->dec_h1;
+        GateStreamArgs gs;
+        memset(&gs, 0, sizeof(gs));
+        bool stream_gates = false, fold_pre2 = false;
         if (do_att) {
         // 1. attention LSTMCell on [prenet_out | context]
         LstmCellArgs ca;
@@ -188,6 +194,23 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         const bool q_parts = fused_att && B <= 8 && d->q_part != nullptr;      // (9+ items: the cells run on sbgemm.hip, no partials)
         const int units = ca.gates_out ? 2 : 4;             // hidden units per workgroup of lstm_cell_kernel (training / eval)
         if (q_parts) { ca.w_q = d->w_query; ca.q_part = d->q_part; ca.q_dim = d->att_dim; }
+        // streamed gates: W_hh_att . h_att(s-1) was left in gate_part[2] by the previous step's attention launch (zero at step 0)
+        if (want_stream && d->gate_part && !d->teacher_forced && fused_att && q_parts && !ca.gates_out && A == 1024 && D == 1024) {
+            gs.W0 = d->dec_w_hh; gs.ld0 = D; gs.x0 = dh_in; gs.out0 = d->gate_part;
+            gs.W1 = d->dec_w_ih; gs.ld1 = A + E; gs.out1 = d->gate_part + GP;
+            gs.W2 = d->att_w_hh; gs.ld2 = A; gs.out2 = d->gate_part + 2 * GP; gs.x12 = ah_out;
+            gs.rows = 4 * A; gs.H = A; gs.B = B;
+            stream_gates = true;
+        }
+        if (stream_gates) { ca.h_in = nullptr; ca.pre_a = d->gate_part + 2 * GP; }
+        // ... and with it the prenet's second layer folded into this launch (every workgroup recomputes the 256 outputs from
+        // pre1 and W_pre2 out of L2) instead of a GEMV launch of its own at the end of the previous step.  T2S_DECODE_FOLD_PRE2=0: off
+        static const bool want_fold = !(getenv("T2S_DECODE_FOLD_PRE2") && atoi(getenv("T2S_DECODE_FOLD_PRE2")) == 0);
+        fold_pre2 = stream_gates && want_fold && P == 256 && s < d->mask_steps;
+        if (fold_pre2) {
+            ca.x1 = nullptr; ca.w_p2 = d->w_pre2; ca.p1 = d->pre1;
+            ca.p2_mask = d->prenet_masks + (size_t)s * B * 2 * P + P; ca.s_p2_mask = 2 * P; ca.p2_scale = 2.0f;
+        }
         T2S_CHECK_HIP(t2s_launch_lstm_cell(ca, stream));
         // 2.-4. attention: query, location-sensitive energies, softmax, context, cumulative weights
         AttArgs aa;
@@ -204,7 +227,8 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         if (q_parts) { aa.q_part = d->q_part; aa.n_part = A / units; }
         if (fused_att) {
             // small batch: one fused launch per step (one workgroup per batch element)
-            T2S_CHECK_HIP(t2s_launch_att_fused(aa, stream));
+            if (stream_gates && !t2s_att_fused_stream_ok(aa, gs)) return T2S_EINVAL;
+            T2S_CHECK_HIP(t2s_launch_att_fused(aa, stream, stream_gates ? &gs : nullptr));
         } else {
             GemvArgs qa;
             memset(&qa, 0, sizeof(qa));
@@ -230,6 +254,12 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
             dstream = hs.side;
         }
         cd.h_in = dh_in; cd.h_out = dh_out; cd.c = d->dec_c; cd.B = B; cd.H = D;
+        if (stream_gates) {
+            // only the context columns of W_ih are left to stream (8.4 MB of 42): W_hh . h_dec(s-1) and W_ih[:, :A] . h_att(s)
+            // came out of the attention launch as gate_part[0], gate_part[1]
+            cd.W_ih = d->dec_w_ih + A; cd.ld_ih = A + E; cd.x1 = d->ctx; cd.n1 = E; cd.sx1 = E; cd.x2 = nullptr; cd.n2 = 0; cd.sx2 = 0;
+            cd.h_in = nullptr; cd.pre_a = d->gate_part; cd.pre_b = d->gate_part + GP;
+        }
         if (d->dec_drop) { cd.drop_mask = d->dec_drop + (size_t)s * B * D; cd.drop_scale = d->dec_drop_scale; }
         if (d->teacher_forced) { cd.h_copy = d->hc_all + (size_t)s * B * (D + E); cd.s_copy = D + E; }
         if (d->dec_gates_all) { cd.gates_out = d->dec_gates_all + (size_t)s * B * 4 * D; cd.c_out = d->dec_c_all + (size_t)s * B * D; }
@@ -263,7 +293,7 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
                     T2S_CHECK_HIP(t2s_launch_gemv(p1, stream));
                 }
             }
-            if (more) {
+            if (more && !fold_pre2) {
                 GemvArgs p2;
                 memset(&p2, 0, sizeof(p2));
                 p2.W1 = d->w_pre2; p2.ld1 = P; p2.k1 = P; p2.x1 = d->pre1; p2.n1 = P; p2.sx1 = P;

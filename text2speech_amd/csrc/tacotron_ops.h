@@ -49,6 +49,31 @@ struct LstmCellArgs {
     float* c_out;        // optional [B][H]: new cell state copy
     // optional: per-workgroup partial attention queries q_part[wg][b][a] = sum_{u in wg} w_q[a][u] * h_out[b][u]
     const float* w_q; float* q_part; int q_dim;
+    // streamed-gates form (B <= 8 autoregressive decode, GateStreamArgs below): the products of W_hh (and of some W_ih columns)
+    // with vectors that were known one launch earlier arrive as pre-activation partials [B][4H] and are simply added;
+    // h_in == NULL then drops the W_hh . h term from this kernel, ld_ih > 0 is the row stride of W_ih when only a column
+    // range of it is multiplied here (W_ih then points at the first of those columns)
+    const float* pre_a; const float* pre_b; int ld_ih;
+    // folded prenet layer 1 (autoregressive B <= 8, with the streamed-gates form): x1 is not read; instead every workgroup
+    // recomputes x1[b][r] = relu(w_p2[r][:] . p1[b][:]) * (p2_mask[b * s_p2_mask + r] ? p2_scale : 0), r < n1 = 256
+    // (modules.py:19-22, the prenet's second Linear + ReLU + always-on dropout: 256 KB of weights out of L2 per workgroup
+    // instead of a launch of its own on the serial chain)
+    const float* w_p2; const float* p1; const unsigned char* p2_mask; long s_p2_mask; float p2_scale;
+};
+
+// Role-specialised second half of the fused attention launch (B <= 8): while ONE workgroup per batch element runs the
+// attention of step t (10.7 us with 255 CUs and HBM idle), the other workgroups stream the three [4H][H] weight blocks whose
+// input vectors already exist - W_hh_dec . h_dec(t-1), W_ih_dec[:, :A] . h_att(t) (both for this step's decoder cell) and
+// W_hh_att . h_att(t) (next step's attention cell) - and leave the products as partials; the two cell launches then stream
+// 8.4 / 12.6 MB instead of 42 / 29.4 MB.  The consumers are the NEXT launches: the kernel boundary stays the only barrier.
+struct GateStreamArgs {
+    const float* W0; int ld0; const float* x0; float* out0;   // out0[b][r] = W0[r][:H] . x0[b][:H], r < rows
+    const float* W1; int ld1; float* out1;                    // out1[b][r] = W1[r][:H] . x12[b][:H]
+    const float* W2; int ld2; float* out2;                    // out2[b][r] = W2[r][:H] . x12[b][:H]
+    const float* x12;
+    int rows, H, B;                                           // rows = 4H of each block, H = 1024
+    int dbg;                                                  // -DT2S_ATTSTREAM_ABLATE builds only: 1 = attention role returns at once,
+                                                              // 2 = gate-stream role returns at once (timing only, results garbage)
 };
 
 struct AttArgs {
@@ -86,7 +111,8 @@ hipError_t t2s_launch_sbgemm_lstm(const LstmCellArgs& a, hipStream_t stream);
 hipError_t t2s_launch_lstm_cell(const LstmCellArgs& a, hipStream_t stream);
 hipError_t t2s_launch_att_energy(const AttArgs& a, hipStream_t stream);
 hipError_t t2s_launch_att_softmax_ctx(const AttArgs& a, hipStream_t stream);
-hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream);
+hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream, const GateStreamArgs* gs = nullptr);
+bool t2s_att_fused_stream_ok(const AttArgs& a, const GateStreamArgs& g);
 hipError_t t2s_launch_lstm_seq(const float* gx, const float* whhT_f, const float* whhT_r, const int* lengths, float* out,
                                int B, int T, int H, int T_out, float* gates_save, float* c_save, hipStream_t stream);
 hipError_t t2s_launch_transpose(const float* in, float* out, int R, int C, hipStream_t stream);

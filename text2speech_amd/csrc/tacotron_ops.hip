@@ -203,14 +203,31 @@ __global__ __launch_bounds__(UNITS * 256) void lstm_cell_kernel(const LstmCellAr
     const int wave = threadIdx.x >> 6;
     const int ul = wave >> 2, kq = wave & 3;
     const int u = blockIdx.x * UNITS + ul;           // H % UNITS == 0 is checked by the caller
-    const int K1 = a.n1 + a.n2, K = K1 + a.H;
+    const int K1 = a.n1 + a.n2, K = K1 + (a.h_in ? a.H : 0);
+    const int ldi = a.ld_ih > 0 ? a.ld_ih : K1;
     // Everything the tail of the kernel needs from memory is requested now, next to the weight rows, so the pointwise update
     // and the partial query do not add dependent round trips behind the reduction: the gate biases, the cell state of the
     // first item chunk, and this workgroup's UNITS columns of W_query.
     __shared__ float s_bsum[UNITS][4];
     __shared__ float s_wq[UNITS][128];
     float c_pre = 0.f;
-    if (kq == 0 && lane < a.B) c_pre = a.c[(size_t)lane * a.H + u];
+    // streamed-gates form: partial pre-activations of the first item chunk.  Loaded raw (clamped addresses, no arithmetic here:
+    // an add at this point makes hipcc wait for the loads in front of the weight-row loads - a whole memory round trip at the
+    // head of the kernel); summed where they are used.
+    float g_pa[4] = {0.f, 0.f, 0.f, 0.f}, g_pb[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        const bool mine = kq == 0 && lane < a.B;
+        const int itc = mine ? lane : 0;
+        c_pre = a.c[(size_t)itc * a.H + u];
+        const float* pa = a.pre_a ? a.pre_a : a.c;          // (always a readable address; unused values are dropped below)
+        const float* pb = a.pre_b ? a.pre_b : pa;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const size_t i = a.pre_a ? (size_t)itc * 4 * a.H + (size_t)g * a.H + u : (size_t)u;
+            g_pa[g] = pa[i];
+            g_pb[g] = pb[i];
+        }
+    }
     f32x4 w[4][NVW];
     const float* xp[NVW];
     long xs[NVW];
@@ -225,13 +242,13 @@ __global__ __launch_bounds__(UNITS * 256) void lstm_cell_kernel(const LstmCellAr
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const size_t row = (size_t)g * a.H + u;
-            const float* wp = kc < K1 ? a.W_ih + row * K1 + kc : a.W_hh + row * a.H + (kc - K1);
+            const float* wp = kc < K1 ? a.W_ih + row * ldi + kc : a.W_hh + row * a.H + (kc - K1);
             w[g][j] = T2S_WLOAD((const f32x4*)wp);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             if (!valid[j]) w[g][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (!valid[j]) { xp[j] = a.x1; xs[j] = 0; }
+        if (!valid[j]) { xp[j] = a.c; xs[j] = 0; }          // (a readable dummy: x1 is NULL in the folded-prenet form)
         else if (k < a.n1) { xp[j] = a.x1 + k; xs[j] = a.sx1; }
         else if (k < K1) { xp[j] = a.x2 + (k - a.n1); xs[j] = a.sx2; }
         else { xp[j] = a.h_in + (k - K1); xs[j] = a.H; }
@@ -268,9 +285,14 @@ __global__ __launch_bounds__(UNITS * 256) void lstm_cell_kernel(const LstmCellAr
             const int it = b0 + lane;
             float gsum[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g) {
                 gsum[g] = (s_part[ul][0][g][lane] + s_part[ul][1][g][lane]) + (s_part[ul][2][g][lane] + s_part[ul][3][g][lane]) +
                           s_bsum[ul][g];
+                if (a.pre_a) {
+                    const size_t i = (size_t)it * 4 * a.H + (size_t)g * a.H + u;
+                    gsum[g] += b0 == 0 ? g_pa[g] + (a.pre_b ? g_pb[g] : 0.f) : a.pre_a[i] + (a.pre_b ? a.pre_b[i] : 0.f);
+                }
+            }
             const size_t idx = (size_t)it * a.H + u;
             const float c = b0 == 0 ? c_pre : a.c[idx];
             const float c2 = sigmoid_acc(gsum[1]) * c + sigmoid_acc(gsum[0]) * tanhf(gsum[2]);
@@ -302,12 +324,134 @@ __global__ __launch_bounds__(UNITS * 256) void lstm_cell_kernel(const LstmCellAr
     PROBE_END()
 }
 
+// ------------------------------------------------------------------------------------------------
+// Attention LSTMCell of the streamed-gates decode (B <= 8, autoregressive) with the prenet's second layer folded in:
+//   x1 = relu(W_pre2 . pre1) * mask * 2      (modules.py:19-22: Linear + ReLU + the always-on dropout), recomputed by EVERY workgroup
+//   gates = W_ih [x1 | ctx] + b_ih + b_hh + pre_a            (pre_a = W_hh . h from the previous attention launch's gate-stream role)
+// so the prenet GEMV leaves the serial chain (4.4 us per step as a launch of its own).  K = 256 + 512 is exactly three
+// 256-float slots, so the workgroup is 12 waves = (4 hidden units) x (3 K slots) - 768 threads, a 170-VGPR budget - and wave w
+// also carries rows 22 w .. 22 w + 21 of W_pre2 (22 x 16 bytes per lane; 256 KB per workgroup out of L2).  Every global load of
+// the kernel that does not depend on pre2 is requested before the first wait.
+__global__ __launch_bounds__(768) void lstm_cell_p2_kernel(const LstmCellArgs a) {
+    PROBE_BEGIN(210)
+    __shared__ float s_part[4][3][4][8];             // [unit][kq][gate][item]
+    __shared__ float s_h[4][8];
+    __shared__ float s_bsum[4][4];
+    __shared__ float s_wq[4][128];
+    __shared__ __attribute__((aligned(16))) float s_p2[8 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ul = wave / 3, kq = wave - 3 * ul;
+    const int u = blockIdx.x * 4 + ul;
+    const int ldi = a.ld_ih > 0 ? a.ld_ih : 768;
+    // LSTM rows (HBM, non-temporal: read once per step by this wave)
+    f32x4 w[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) w[g] = T2S_WLOAD((const f32x4*)(a.W_ih + ((size_t)g * a.H + u) * ldi + kq * 256 + 4 * lane));
+    // this wave's rows of W_pre2 (L2)
+    constexpr int RP = 22;
+    f32x4 wp2[RP];
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+        const int r = wave * RP + i;
+        wp2[i] = *(const f32x4*)(a.w_p2 + (size_t)(r < 256 ? r : 255) * 256 + 4 * lane);
+    }
+    // tail operands: cell state, streamed partials, biases, this workgroup's columns of W_query (raw loads, no arithmetic here)
+    const bool mine = kq == 0 && lane < a.B;
+    const int itc = mine ? lane : 0;
+    const float c_pre = a.c[(size_t)itc * a.H + u];
+    float g_pa[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) g_pa[g] = a.pre_a[(size_t)itc * 4 * a.H + (size_t)g * a.H + u];
+    float bi = 0.f, bh = 0.f;
+    if (kq == 0 && lane < 4) { bi = a.b_ih[lane * a.H + u]; bh = a.b_hh[lane * a.H + u]; }
+    float wq[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_q = a.q_part && tid < a.q_dim && a.q_dim <= 128;
+    if (do_q) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wq[i] = a.w_q[(size_t)tid * a.H + blockIdx.x * 4 + i];
+    }
+    // ---- prenet layer 1: 22 dot products per wave, reduced over the 64 lanes by ONE multi-row butterfly (at every stage a lane
+    // keeps one row of a pair and sends the other: 32 shuffles for up to 32 rows instead of 6 per row) ----
+    // the row this lane ends up with: bit 5 of the lane is bit 0 of the row, bit 4 bit 1, ... bit 1 bit 4
+    const int rw = ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) |
+                   (((lane >> 1) & 1) << 4);
+    const int r = wave * RP + rw;
+    const bool r_ok = !(lane & 1) && rw < RP && r < 256;
+    for (int b = 0; b < a.B; ++b) {
+        const f32x4 p1 = *(const f32x4*)(a.p1 + (size_t)b * 256 + 4 * lane);
+        const unsigned char mkb = a.p2_mask[(size_t)b * a.s_p2_mask + (r_ok ? r : 0)];     // (requested in front of the reduction)
+        float v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            v[i] = i < RP ? wp2[i < RP ? i : 0][0] * p1[0] + wp2[i < RP ? i : 0][1] * p1[1] + wp2[i < RP ? i : 0][2] * p1[2] +
+                                wp2[i < RP ? i : 0][3] * p1[3]
+                          : 0.f;
+        // (the mask byte is pinned here, where the wait for p1 covers it: left alone, hipcc sinks the load behind the reduction -
+        // one more memory round trip in front of the LDS store)
+        int mk_i = mkb;
+        asm volatile("" : "+v"(mk_i));
+#pragma unroll
+        for (int off = 32, n = 32; off >= 2; off >>= 1, n >>= 1) {
+            const bool hi = (lane & off) != 0;
+#pragma unroll
+            for (int i = 0; i < n / 2; ++i) {
+                const float send = hi ? v[2 * i] : v[2 * i + 1], keep = hi ? v[2 * i + 1] : v[2 * i];
+                v[i] = keep + __shfl_xor(send, off, 64);
+            }
+        }
+        const float tot = v[0] + __shfl_xor(v[0], 1, 64);
+        if (r_ok) s_p2[b * 256 + r] = mk_i ? fmaxf(tot, 0.f) * a.p2_scale : 0.f;
+    }
+    if (kq == 0 && lane < 4) s_bsum[ul][lane] = bi + bh;
+    if (do_q) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_wq[i][tid] = wq[i];
+    }
+    __syncthreads();
+    // ---- gate pre-activations: slot 0 = pre2 (LDS), slots 1, 2 = the context ----
+    for (int b = 0; b < a.B; ++b) {
+        const f32x4 x = kq == 0 ? *(const f32x4*)(s_p2 + b * 256 + 4 * lane)
+                                : *(const f32x4*)(a.x2 + (size_t)b * a.sx2 + (kq - 1) * 256 + 4 * lane);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float acc = w[g][0] * x[0] + w[g][1] * x[1] + w[g][2] * x[2] + w[g][3] * x[3];
+            acc = wave_sum(acc);
+            if (lane == 0) s_part[ul][kq][g][b] = acc;
+        }
+    }
+    __syncthreads();
+    if (mine) {
+        const int it = lane;
+        float gsum[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gsum[g] = (s_part[ul][0][g][it] + s_part[ul][1][g][it]) + s_part[ul][2][g][it] + s_bsum[ul][g] + g_pa[g];
+        const size_t idx = (size_t)it * a.H + u;
+        const float c2 = sigmoid_acc(gsum[1]) * c_pre + sigmoid_acc(gsum[0]) * tanhf(gsum[2]);
+        float h2 = sigmoid_acc(gsum[3]) * tanhf(c2);
+        a.c[idx] = c2;
+        if (a.drop_mask) h2 = a.drop_mask[idx] ? h2 * a.drop_scale : 0.f;
+        a.h_out[idx] = h2;
+        if (a.h_copy) a.h_copy[(size_t)it * a.s_copy + u] = h2;
+        s_h[ul][it] = h2;
+    }
+    __syncthreads();
+    if (do_q) {
+        for (int b = 0; b < a.B; ++b) {
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q += s_wq[i][tid] * s_h[i][b];
+            a.q_part[((size_t)blockIdx.x * a.B + b) * a.q_dim + tid] = q;
+        }
+    }
+    PROBE_END()
+}
+
 hipError_t t2s_launch_lstm_cell(const LstmCellArgs& a, hipStream_t stream) {
     if (t2s_sbgemm_lstm_ok(a)) return t2s_launch_sbgemm_lstm(a, stream);        // 9+ items: f32 matrix cores
-    const int K = a.n1 + a.n2 + a.H;
+    const int K = a.n1 + a.n2 + (a.h_in ? a.H : 0);
     const int nv4 = (K + 255) / 256;
     const int nvw = (nv4 + 3) / 4;
-    if (a.H % 4) return hipErrorInvalidValue;
+    if (a.H % 4 || (!a.h_in && !a.pre_a)) return hipErrorInvalidValue;
     // eval / inference: 4 units per 1024-thread workgroup (128-VGPR cap, fits without the save code);
     // training saves: 2 units per 512-thread workgroup (256-VGPR budget)
 #define LL(N)                                                                                                     \
@@ -315,6 +459,13 @@ hipError_t t2s_launch_lstm_cell(const LstmCellArgs& a, hipStream_t stream) {
         if (a.gates_out) hipLaunchKernelGGL((lstm_cell_kernel<N, 2, true>), dim3(a.H / 2), dim3(512), 0, stream, a); \
         else hipLaunchKernelGGL((lstm_cell_kernel<N, 4, false>), dim3(a.H / 4), dim3(1024), 0, stream, a);          \
     } while (0)
+    if (a.w_p2) {           // folded prenet layer 1 (lstm_cell_p2_kernel): K = 256 (pre2) + 512 (context), W_hh . h streamed earlier
+        if (a.gates_out || a.c_out || a.n1 != 256 || a.n2 != 512 || a.h_in || !a.pre_a || a.pre_b || a.B > 8 || !a.p1 ||
+            !a.p2_mask || !a.x2 || (a.sx2 & 3))
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(lstm_cell_p2_kernel, dim3(a.H / 4), dim3(768), 0, stream, a);
+        return hipGetLastError();
+    }
     if (nvw <= 1) LL(1);
     else if (nvw <= 2) LL(2);
     else if (nvw <= 3) LL(3);
@@ -866,7 +1017,76 @@ static __device__ __forceinline__ float row16_ror(float v, int n) {
 // At B = 1, T = 64 the VALU form spent 5.1 us in the convolution and 8.0 us in the energies (124 and 96 ds_read_b32 per
 // output and wave: LDS-bound in ONE CU); here both are a few dozen MFMAs per wave.
 // LDS operand layouts are padded so that the b32 fragment reads are bank-conflict free: K as [k][48], D as [f][144].
-__global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a) {
+// Gate-stream role of the fused attention launch (GateStreamArgs, tacotron_ops.h): workgroups B .. gridDim.x - 1.
+// Unit = one [H = 1024] weight row of one of the three blocks (3 * rows units of 4 KB).  Wave w of the role (NW waves in all)
+// takes units w, w + NW, w + 2 NW and - the first (n_units - 3 NW) waves only - w + 3 NW: ONE pass, every weight load of a wave
+// (12 or 16 x 16 bytes per lane) requested before the first use, so no workgroup pays a second memory round trip (with 255
+// workgroups and 12288 units a strided loop left 48 waves a second pass: 15.6 us per launch instead of ~11).  Non-temporal
+// weight loads: each row is read once per step by one wave.  The two input vectors (h_dec(t-1), h_att(t)) are staged in LDS
+// once per workgroup.  Requires 3 NW <= n_units <= 4 NW (checked on the host).
+static __device__ __forceinline__ void gate_stream_role(const GateStreamArgs& g, int role_block, int role_blocks, float* s_x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int NW = role_blocks * 16, gw = role_block * 16 + wave;
+    const int n_units = 3 * g.rows;
+    const bool four = gw + 3 * NW < n_units;                    // wave-uniform
+    f32x4 w[4][4];
+    float* ob[4];
+    int rr[4];
+    bool first[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int un = (j < 3 || four) ? gw + j * NW : gw;      // (j = 3 without a fourth unit: a row this wave reads anyway)
+        const int blk = un / g.rows, r = un - blk * g.rows;
+        const float* W = blk == 0 ? g.W0 : (blk == 1 ? g.W1 : g.W2);
+        const int ld = blk == 0 ? g.ld0 : (blk == 1 ? g.ld1 : g.ld2);
+        first[j] = blk == 0;
+        ob[j] = blk == 0 ? g.out0 : (blk == 1 ? g.out1 : g.out2);
+        rr[j] = r;
+        const float* wp = W + (size_t)r * ld + 4 * lane;
+        if (j < 3 || four) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) w[j][v] = T2S_WLOAD((const f32x4*)(wp + 256 * v));
+        }
+    }
+    // input vectors -> LDS: [b][2][H] (h_dec, h_att), 2 * B * H floats <= 64 KB
+    for (int i = threadIdx.x; i < g.B * 2 * (g.H / 4); i += 1024) {
+        const int b = i / (2 * (g.H / 4)), rem = i - b * 2 * (g.H / 4), which = rem / (g.H / 4), k4 = rem - which * (g.H / 4);
+        *(f32x4*)(s_x + (size_t)i * 4) = *(const f32x4*)((which ? g.x12 : g.x0) + (size_t)b * g.H + 4 * k4);
+    }
+    __syncthreads();
+    for (int b = 0; b < g.B; ++b) {
+        const float* xd = s_x + (size_t)b * 2 * g.H, *xa = xd + g.H;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j == 3 && !four) break;
+            const float* xs = first[j] ? xd : xa;                  // (wave-uniform: a unit belongs to one block)
+            float acc = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const f32x4 x = *(const f32x4*)(xs + 4 * lane + 256 * v);
+                acc += w[j][v][0] * x[0] + w[j][v][1] * x[1] + w[j][v][2] * x[2] + w[j][v][3] * x[3];
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) ob[j][(size_t)b * g.rows + rr[j]] = acc;
+        }
+    }
+}
+
+template <bool STREAM>
+__global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a, const GateStreamArgs gs) {
+    if constexpr (STREAM) {
+        if ((int)blockIdx.x >= a.B) {           // whole workgroups take this branch: no barrier of the attention role is skipped
+#ifdef T2S_ATTSTREAM_ABLATE
+            if (gs.dbg == 2) return;
+#endif
+            extern __shared__ __attribute__((aligned(16))) float s_role[];
+            gate_stream_role(gs, (int)blockIdx.x - a.B, (int)gridDim.x - a.B, s_role);
+            return;
+        }
+#ifdef T2S_ATTSTREAM_ABLATE
+        if (gs.dbg == 1) return;
+#endif
+    }
     PROBE_BEGIN(301)
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // s_f [max(Tp*33, 4096)] | s_e [Tp] | s_ep [8][Tp] | s_kb [KP][48]
     __shared__ float s_q[128];
@@ -1142,18 +1362,56 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a) {
     PROBE_END()
 }
 
-hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream) {
+static bool att_fused_mfma_form(const AttArgs& a) {
+    static const bool no_mfma = getenv("T2S_ATT_VALU") != nullptr;       // A/B switch: the VALU form
+    return a.loc_f == 32 && a.att_dim == 128 && !no_mfma;
+}
+
+// the gate-stream role rides on the matrix-core form of the fused attention launch only; three [4H][H] blocks, H = 1024
+bool t2s_att_fused_stream_ok(const AttArgs& a, const GateStreamArgs& g) {
+    if (!att_fused_mfma_form(a) || a.B > 8 || a.T > ATT_FUSED_MAXT) return false;
+    if (g.H != 1024 || g.rows != 4 * g.H || g.B != a.B) return false;
+    const void* ptrs[] = {g.W0, g.W1, g.W2, g.x0, g.x12, g.out0, g.out1, g.out2};
+    for (const void* p : ptrs)
+        if (!p || ((uintptr_t)p & 15)) return false;
+    if (g.ld0 < g.H || g.ld1 < g.H || g.ld2 < g.H || ((g.ld0 | g.ld1 | g.ld2) & 3)) return false;
+    return true;
+}
+
+hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream, const GateStreamArgs* gs) {
     if (a.T > ATT_FUSED_MAXT || a.enc_dim > 512 || a.att_dim > 128 || a.loc_f > 32 || a.loc_ks > 63 || a.att_rnn > 1024)
         return hipErrorInvalidValue;
-    static const bool no_mfma = getenv("T2S_ATT_VALU") != nullptr;       // A/B switch: the VALU form
-    if (a.loc_f == 32 && a.att_dim == 128 && !no_mfma) {
+    if (gs && !t2s_att_fused_stream_ok(a, *gs)) return hipErrorInvalidValue;
+    if (att_fused_mfma_form(a)) {
         const int Tp = (a.T + 15) & ~15, KP = (2 * a.loc_ks + 3) & ~3;
         const size_t nF = (size_t)Tp * 33 > 4096 ? (size_t)Tp * 33 : 4096;
         const size_t lds = (nF + Tp + 8 * Tp + (size_t)KP * 48) * sizeof(float);
+        if (gs) {
+            // one workgroup per CU (1024 threads, > 64 KB of LDS at any T): the attention workgroups take B CUs, the gate-stream
+            // role the rest of the chip in ONE round
+            static std::atomic<unsigned long long> attr_mask3{0};
+            const hipError_t e3 = t2s_raise_lds_limit((const void*)att_fused_mfma_kernel<true>, 120 * 1024, attr_mask3);
+            if (e3 != hipSuccess) return e3;
+            static const int n_cu = [] {
+                int dev = 0, n = 256;
+                if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+                return n > 16 ? n : 256;
+            }();
+            const size_t lds1 = lds > 84 * 1024 ? lds : 84 * 1024;      // more than half a CU's LDS: never two workgroups on one CU
+            const int n_waves = (n_cu - a.B) * 16, n_units = 3 * gs->rows;  // one pass: 3 or 4 units per wave (gate_stream_role)
+            if (n_cu <= a.B || 3 * n_waves > n_units || 4 * n_waves < n_units) return hipErrorInvalidValue;
+            GateStreamArgs g2 = *gs;
+#ifdef T2S_ATTSTREAM_ABLATE
+            static const int dbg = getenv("T2S_DBG_ATTSTREAM") ? atoi(getenv("T2S_DBG_ATTSTREAM")) : 0;
+            g2.dbg = dbg;
+#endif
+            hipLaunchKernelGGL(att_fused_mfma_kernel<true>, dim3(n_cu), dim3(1024), lds1, stream, a, g2);
+            return hipGetLastError();
+        }
         static std::atomic<unsigned long long> attr_mask2{0};
-        const hipError_t e2 = t2s_raise_lds_limit((const void*)att_fused_mfma_kernel, 120 * 1024, attr_mask2);
+        const hipError_t e2 = t2s_raise_lds_limit((const void*)att_fused_mfma_kernel<false>, 120 * 1024, attr_mask2);
         if (e2 != hipSuccess) return e2;
-        hipLaunchKernelGGL(att_fused_mfma_kernel, dim3(a.B), dim3(1024), lds, stream, a);
+        hipLaunchKernelGGL(att_fused_mfma_kernel<false>, dim3(a.B), dim3(1024), lds, stream, a, GateStreamArgs{});
         return hipGetLastError();
     }
     const size_t lds = ((size_t)a.T * 33 + a.T) * sizeof(float);
