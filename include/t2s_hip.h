@@ -295,6 +295,11 @@ typedef struct t2s_taco_decoder {
      * attention cell of step t+1 then add them instead of streaming those 50 MB themselves.  State like h / c: carried between
      * calls that continue one utterance.  NULL (or T2S_DECODE_STREAM=0): every cell streams its own weights (ABI v3 behaviour). */
     float *gate_part;
+    /* ABI v4.  [prenet][prenet] TRANSPOSE of w_pre2, or NULL.  With gate_part: the prenet's second layer (modules.py:19-22) is
+     * folded into the attention cell's launch - every workgroup recomputes its 256 outputs from pre1, as a sparse product (pre1 is
+     * ~3/4 exact zeros after ReLU and dropout: one coalesced row of the transpose per nonzero) - instead of a GEMV launch of its own
+     * on the serial chain.  NULL (or T2S_DECODE_FOLD_PRE2=0): the separate launch. */
+    const float *w_pre2T;
 } t2s_taco_decoder;
 
 /* Enqueue decoder steps [step0, step0+n_steps) (Decoder.decode, tacotron.py:355-393, plus in autoregressive mode

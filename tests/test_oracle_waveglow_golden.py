@@ -92,3 +92,49 @@ def test_grads_config_defaults_vs_reference(golden_dir):
             flat = sd[name].grad.flatten()
             step = max(1, flat.numel() // 4096)
             assert _rel(flat[::step], g[key]) < 2e-4, name
+
+
+def full_infer_case(golden_dir):
+    """Inputs of tests/golden/waveglow_full_infer_1000.npz (tools/gen_golden_waveglow.py --infer-full) regenerated from its seed:
+    mel from a seeded generator, the Gaussian draws from the global CPU RNG in the reference's draw order (glow.py:260-267, 284-289),
+    checked against the fixture's checksums before they are used."""
+    g = np.load(os.path.join(golden_dir, "waveglow_full_infer_1000.npz"))
+    cfg = synth.WAVEGLOW_DEFAULT
+    seed, frames = int(g["seed"]), int(g["frames"])
+    mel = torch.randn(1, cfg["n_mel_channels"], frames, generator=torch.Generator().manual_seed(seed))
+    L = frames * 256 // cfg["n_group"]
+    torch.manual_seed(seed + 1)
+    n_rem = cfg["n_group"] - cfg["n_early_size"] * sum(1 for k in range(cfg["n_flows"]) if k % cfg["n_early_every"] == 0 and k > 0)
+    draws = [torch.FloatTensor(1, n_rem, L).normal_()]
+    for k in reversed(range(cfg["n_flows"])):
+        if k % cfg["n_early_every"] == 0 and k > 0:
+            draws.append(torch.FloatTensor(1, cfg["n_early_size"], L).normal_())
+    for i, t in enumerate(draws):       # last-bit differences between CPU vector paths are fine; a different stream is not
+        assert abs(float(t.double().sum()) - g["noise_sum"][i]) < 1e-3 and abs(float((t.double() ** 2).sum()) - g["noise_sq"][i]) < 1e-5 * g["noise_sq"][i], \
+            "the CPU RNG on this box does not reproduce the reference's Gaussian draws"
+    return g, cfg, mel, draws[0], draws[1:]
+
+
+def check_full_infer(audio, g, tol):
+    audio = torch.as_tensor(audio).detach().cpu().reshape(-1)
+    n = audio.numel()
+    assert n == 256 * int(g["frames"])
+    stride = int(g["stride"])
+    errs = {"strided": _rel(audio[::stride], g["audio_strided"]), "head": _rel(audio[:2048], g["audio_head"]),
+            "tail": _rel(audio[-2048:], g["audio_tail"])}
+    sq = np.array([float((audio[i:i + 4096].double() ** 2).sum()) for i in range(0, n, 4096)])
+    errs["block_energy"] = float(np.max(np.abs(sq - g["audio_sq_by_4096"]) / g["audio_sq_by_4096"]))
+    errs["max_sample"] = float((audio[::stride].double() - torch.from_numpy(g["audio_strided"]).double()).abs().max() / float(g["audio_absmax"]))
+    assert errs["strided"] < tol and errs["head"] < tol and errs["tail"] < tol and errs["max_sample"] < tol, errs
+    assert errs["block_energy"] < 2 * tol, errs
+    return errs
+
+
+@pytest.mark.slow
+def test_infer_benchmarked_length_vs_reference(golden_dir):
+    """The oracle's `infer` at the length bench.py and tools/bench_e2e.py time (B = 1, 512 channels, 1000 frames, sigma 0.666)
+    against the reference's own audio (strided samples, head, tail, per-4096-sample energies)."""
+    g, cfg, mel, nf, ne = full_infer_case(golden_dir)
+    with torch.no_grad():
+        audio = O.waveglow_infer(synth.waveglow_state(cfg), cfg, mel, nf, ne, sigma=float(g["sigma"]))
+    print(check_full_infer(audio, g, 1e-5))

@@ -301,6 +301,21 @@ def test_infer_small_vs_golden(lib, golden_dir, name, sigma):
     assert _rel(audio, g["audio"]) < 1e-3 and _maxrel(audio, g["audio"]) < 1e-3
 
 
+def test_infer_benchmarked_length_vs_reference(lib, golden_dir):
+    """`infer` at the length bench.py / tools/bench_e2e.py time - B = 1, config.json defaults (512 channels),
+    1000 mel frames -> 256 000 samples, sigma 0.666 - against the REFERENCE's own audio (tests/golden/waveglow_full_infer_1000.npz:
+    4096 strided samples, the first and last 2048 samples, the energy of every 4096-sample block).  This is the reverse direction
+    on the 256-row ping-pong tiles (500 workgroups), which the 24- and 96-frame checks (128-row lockstep tiles) never reach.  The
+    Gaussian draws are regenerated from the fixture's seed in the reference's draw order and checked against its checksums."""
+    from test_oracle_waveglow_golden import check_full_infer, full_infer_case
+    g, cfg, mel, nf, ne = full_infer_case(golden_dir)
+    m = _build(cfg)
+    assert _lib.load().t2s_wg_gate_tile_rows(1, cfg["WN_config"]["n_channels"], 1000 * 256 // cfg["n_group"]) == 256
+    audio = m.infer(mel.to(DEV), sigma=float(g["sigma"]), noise=(nf, ne))
+    errs = check_full_infer(audio[0], g, 1e-3)
+    print("infer 1000 frames vs reference:", errs)
+
+
 def test_roundtrip_full_size(lib):
     """Size-independent property at the full config: forward(infer(noise)) == noise."""
     cfg = synth.WAVEGLOW_DEFAULT

@@ -206,9 +206,9 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         // ... and with it the prenet's second layer folded into this launch (every workgroup recomputes the 256 outputs from
         // pre1 and W_pre2 out of L2) instead of a GEMV launch of its own at the end of the previous step.  T2S_DECODE_FOLD_PRE2=0: off
         static const bool want_fold = !(getenv("T2S_DECODE_FOLD_PRE2") && atoi(getenv("T2S_DECODE_FOLD_PRE2")) == 0);
-        fold_pre2 = stream_gates && want_fold && P == 256 && s < d->mask_steps;
+        fold_pre2 = stream_gates && want_fold && d->w_pre2T && P == 256 && E == 512 && s < d->mask_steps;
         if (fold_pre2) {
-            ca.x1 = nullptr; ca.w_p2 = d->w_pre2; ca.p1 = d->pre1;
+            ca.x1 = nullptr; ca.w_p2 = d->w_pre2T; ca.p1 = d->pre1;
             ca.p2_mask = d->prenet_masks + (size_t)s * B * 2 * P + P; ca.s_p2_mask = 2 * P; ca.p2_scale = 2.0f;
         }
         T2S_CHECK_HIP(t2s_launch_lstm_cell(ca, stream));

@@ -55,9 +55,9 @@ struct LstmCellArgs {
     // range of it is multiplied here (W_ih then points at the first of those columns)
     const float* pre_a; const float* pre_b; int ld_ih;
     // folded prenet layer 1 (autoregressive B <= 8, with the streamed-gates form): x1 is not read; instead every workgroup
-    // recomputes x1[b][r] = relu(w_p2[r][:] . p1[b][:]) * (p2_mask[b * s_p2_mask + r] ? p2_scale : 0), r < n1 = 256
-    // (modules.py:19-22, the prenet's second Linear + ReLU + always-on dropout: 256 KB of weights out of L2 per workgroup
-    // instead of a launch of its own on the serial chain)
+    // recomputes x1[b][r] = relu(sum_k w_p2[k][r] * p1[b][k]) * (p2_mask[b * s_p2_mask + r] ? p2_scale : 0), r < n1 = 256
+    // (modules.py:19-22, the prenet's second Linear + ReLU + always-on dropout; w_p2 = the TRANSPOSED weight, walked sparsely:
+    // lstm_cell_p2_kernel)
     const float* w_p2; const float* p1; const unsigned char* p2_mask; long s_p2_mask; float p2_scale;
 };
 

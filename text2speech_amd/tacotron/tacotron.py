@@ -132,7 +132,7 @@ class _DecoderStruct(ctypes.Structure):
     _F = ["att_drop_scale", "dec_drop_scale"]
     _P2 = ["att_h0", "att_h1", "att_c", "dec_h0", "dec_h1", "dec_c", "att_w", "att_wcum", "ctx", "q", "energies",
            "pre1", "pre2", "q_part", "mel_gate_out", "align_out", "hc_all", "att_gates_all", "att_c_all",
-           "dec_gates_all", "dec_c_all", "att_h_all", "q_all", "wcum_all", "gate_part"]
+           "dec_gates_all", "dec_c_all", "att_h_all", "q_all", "wcum_all", "gate_part", "w_pre2T"]
     _fields_ = ([(n, ctypes.c_int) for n in _I] + [(n, ctypes.c_void_p) for n in _P1] +
                 [(n, ctypes.c_float) for n in _F] + [(n, ctypes.c_void_p) for n in _P2])
 
@@ -345,6 +345,8 @@ class _TacoEngine:
         F_, AD_ = P["w_loc_dense"].size(1), P["w_loc_dense"].size(0)
         P["w_loc_denseT"] = torch.empty(F_, AD_, dtype=torch.float32, device=dev)
         _lib.call("t2s_transpose", _lib.ptr(P["w_loc_dense"]), _lib.ptr(P["w_loc_denseT"]), AD_, F_, st)
+        P["w_pre2T"] = torch.empty(Pd, Pd, dtype=torch.float32, device=dev)     # ABI v4: the folded, sparse prenet layer 1
+        _lib.call("t2s_transpose", _lib.ptr(P["w_pre2"]), _lib.ptr(P["w_pre2T"]), Pd, Pd, st)
         self.prep, self.prep_key = P, key
         return P
 
@@ -484,6 +486,7 @@ class _TacoEngine:
             setattr(d, name, P[name].data_ptr())
         for name, t in S.items():
             setattr(d, name, t.data_ptr())
+        d.w_pre2T = P["w_pre2T"].data_ptr() if "gate_part" in S else None
         d.mem_lengths = None if len32 is None else len32.data_ptr()
         d.att_drop_scale = d.dec_drop_scale = 1.0
         for name, t in extra.items():

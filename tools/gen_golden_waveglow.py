@@ -157,11 +157,49 @@ def run_infer(name, cfg, batch, frames, seed, sigma):
     print(name, "audio std", float(audio.std()), tuple(audio.shape))
 
 
+def run_infer_full(name, cfg, frames, seed, sigma, sample=4096):
+    """BASELINE configs[4], vocoder half, at the BENCHMARKED length (B = 1, config.json defaults, `frames` mel frames ->
+    256 * frames samples): the reference's own `infer`.  The fixture holds what pins the audio without shipping it: strided
+    samples, the first / last 2048 samples, the energy of every 4096-sample block, and checksums of the Gaussian draws (the test
+    regenerates them from the seed, in the reference's draw order, and checks these before using them)."""
+    sd = synth.waveglow_state(cfg)
+    gen = torch.Generator().manual_seed(seed)
+    mel = torch.randn(1, cfg["n_mel_channels"], frames, generator=gen)
+    m = build_ref(cfg, sd)
+    torch.cuda.FloatTensor = torch.FloatTensor      # device shim only
+    L = frames * 256 // cfg["n_group"]
+    torch.manual_seed(seed + 1)
+    draws = [torch.FloatTensor(1, m.n_remaining_channels, L).normal_()]
+    for k in reversed(range(cfg["n_flows"])):
+        if k % cfg["n_early_every"] == 0 and k > 0:
+            draws.append(torch.FloatTensor(1, cfg["n_early_size"], L).normal_())
+    torch.manual_seed(seed + 1)
+    with torch.no_grad():
+        audio = m.infer(mel, sigma=sigma)[0]
+    n = audio.numel()
+    wsum = lambda t: float((t.flatten().double() * (torch.arange(t.numel(), dtype=torch.float64) % 9973 + 1)).sum())
+    out = {"seed": np.int64(seed), "sigma": np.float64(sigma), "frames": np.int64(frames),
+           "noise_sum": np.array([float(t.double().sum()) for t in draws]),
+           "noise_sq": np.array([float((t.double() ** 2).sum()) for t in draws]),
+           "noise_wsum": np.array([wsum(t) for t in draws]),
+           "audio_strided": audio[::max(1, n // sample)].contiguous().numpy(), "stride": np.int64(max(1, n // sample)),
+           "audio_head": audio[:2048].numpy(), "audio_tail": audio[-2048:].numpy(),
+           "audio_sq_by_4096": np.array([float((audio[i:i + 4096].double() ** 2).sum()) for i in range(0, n, 4096)]),
+           "audio_absmax": np.float64(float(audio.abs().max()))}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "audio std", float(audio.std()), "absmax", float(audio.abs().max()), n)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--infer-full", action="store_true", help="ONLY the 512-channel, 1000-frame infer fixture (~1 min)")
     ap.add_argument("--full", action="store_true", help="also run the 512-channel 8x16000 config (~1 min)")
     ap.add_argument("--train-full", action="store_true", help="ONLY the 8x16000 training-step fixture (8 reference backward passes)")
     args = ap.parse_args()
+    if args.infer_full:
+        torch.set_num_threads(8)
+        run_infer_full("waveglow_full_infer_1000", synth.WAVEGLOW_DEFAULT, 1000, seed=51, sigma=0.666)
+        sys.exit(0)
     if args.train_full:
         torch.set_num_threads(8)
         run_train_full("waveglow_train_full_grads", synth.WAVEGLOW_DEFAULT, 8, 16000, seed=31)
