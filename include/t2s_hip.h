@@ -310,6 +310,17 @@ typedef struct t2s_taco_decoder {
  * (T2S_DECODE_SPLIT=0: everything on `stream`). */
 int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, void* stream);
 
+/* ABI v4.  One call of the location-sensitive attention alone (Attention.forward, tacotron.py:145-166, with the state update of
+ * Decoder.decode around it, tacotron.py:371-379): query = w_query . h_att, energies from the location features of (w, w_cum) and
+ * the processed memory, masked softmax over T, context.  IN PLACE: w [B][T] holds the previous weights on entry and the new ones on
+ * return, w_cum [B][T] is incremented by them, ctx [B][enc] receives the context.  q_scratch [B][att_dim], e_scratch [B][T].
+ * lengths [B] int32 or NULL.  Same kernels as t2s_taco_decode_steps (one fused launch up to T2S_ATT_FUSED_MAXB items, else
+ * query GEMV + energies + softmax/context). */
+int t2s_taco_attention(const float* h_att, const float* memory, const float* pmem, const int* lengths, float* w, float* w_cum,
+                       float* ctx, float* q_scratch, float* e_scratch, const float* w_query, const float* w_loc_conv,
+                       const float* w_loc_dense, const float* w_loc_denseT, const float* w_v, int B, int T, int att_rnn,
+                       int att_dim, int enc_dim, int loc_filters, int loc_kernel, void* stream);
+
 /* stop_step[b] = first step in [step0, step0+n) with sigmoid(gate) > threshold, if still -1 (tacotron.py:455) */
 int t2s_taco_stop_check(const float* mel_gate_out, int B, int n_mel, int T_cap, int step0, int n, float threshold,
                         int* stop_step, void* stream);

@@ -120,3 +120,56 @@ def test_waveglow_submodules_vs_oracle():
     assert abs(float(log_det) - float(B * L * torch.logdet(W.squeeze(-1)))) < 1e-3 * abs(float(B * L * torch.logdet(W.squeeze(-1)))) + 1e-3
     back = conv(out, reverse=True)
     assert _rel(back, z) < 1e-4 and hasattr(conv, "W_inverse")
+
+
+@pytest.mark.parametrize("B,training", [(1, False), (3, False), (3, True), (12, False)])
+def test_decoder_decode_and_attention_forward_vs_oracle(taco, B, training):
+    """VERDICT r3 item 7 (SURVEY 8c golden list item 4): Decoder.initialize_decoder_states + three consecutive Decoder.decode calls on
+    module-held state (reference tacotron.py:276-307, 355-393) against the oracle's DecoderState / decode_step, every output and
+    every state tensor after every step; Attention.forward (tacotron.py:145-166) as a pure function against the same step's
+    context and weights.  B = 12 takes the matrix-core cells and the three-launch attention, B <= 8 the fused launch."""
+    from oracle import tacotron_oracle as O
+    sd = synth.tacotron_state()
+    gen = torch.Generator().manual_seed(40 + B)
+    T_in = 37
+    lengths = torch.tensor([T_in - 3 * i for i in range(B)])
+    memory = torch.randn(B, T_in, 512, generator=gen) * 0.5
+    for b in range(B):
+        memory[b, lengths[b]:] = 0
+    pad = ~(torch.arange(T_in)[None, :] < lengths[:, None])
+    dec = taco.decoder
+    dec.train(training)
+    try:
+        dec.initialize_decoder_states(memory.to(DEV), pad.to(DEV) if B > 1 else None)
+        st = O.DecoderState(sd, HP, memory, lengths if B > 1 else None)
+        assert _rel(dec.processed_memory, st.pmem) < 1e-5
+        assert tuple(dec.get_go_frame(memory.to(DEV)).shape) == (B, 80)
+        for step in range(3):
+            x = torch.relu(torch.randn(B, 256, generator=gen))
+            da = (torch.rand(B, 1024, generator=gen) < 0.9).to(torch.uint8) if training else None
+            dd = (torch.rand(B, 1024, generator=gen) < 0.9).to(torch.uint8) if training else None
+            w_prev, wc_prev = dec.attention_weights.clone(), dec.attention_weights_cum.clone()
+            mel, gate, w = dec.decode(x.to(DEV), attention_dropout_mask=da, decoder_dropout_mask=dd)
+            with torch.no_grad():
+                o_mel, o_gate, o_w = O.decode_step(sd, HP, st, x, None if da is None else da.float(), None if dd is None else dd.float())
+            assert tuple(mel.shape) == (B, 80) and tuple(gate.shape) == (B, 1) and tuple(w.shape) == (B, T_in)
+            for name, a, b in (("mel", mel, o_mel), ("gate", gate, o_gate.reshape(B, 1)), ("weights", w, o_w),
+                               ("attention_hidden", dec.attention_hidden, st.ah), ("attention_cell", dec.attention_cell, st.ac),
+                               ("decoder_hidden", dec.decoder_hidden, st.dh), ("decoder_cell", dec.decoder_cell, st.dc),
+                               ("attention_weights_cum", dec.attention_weights_cum, st.wc),
+                               ("attention_context", dec.attention_context, st.ctx)):
+                assert _rel(a, b) < 1e-4, (step, name, _rel(a, b))
+            # Attention.forward on this step's inputs: same context and weights, and no state touched
+            cat = torch.stack((w_prev, wc_prev), 1)
+            ctx2, w2 = dec.attention_layer(dec.attention_hidden, dec.memory, dec.processed_memory, cat, dec.mask)
+            assert _rel(w2, o_w) < 1e-4 and _rel(ctx2, st.ctx) < 1e-4
+            assert _rel(dec.attention_weights_cum, st.wc) < 1e-4
+    finally:
+        dec.train(False)
+
+
+def test_decode_before_initialize_fails_loudly():
+    from text2speech_amd.tacotron import Tacotron
+    m = Tacotron(HP, 80, num_speakers=2).to(DEV).eval()
+    with pytest.raises(_lib.T2SError):
+        m.decoder.decode(torch.zeros(1, 256, device=DEV))

@@ -64,6 +64,7 @@ SIGNATURES = {
     "t2s_embedding_grad": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp],
     "t2s_bn_running_update": [c_vp, c_vp, c_vp, c_vp, c_vp, c_float, ctypes.c_longlong, c_int, c_vp],
     "t2s_zero_fill": [c_vp, ctypes.c_size_t, c_vp],
+    "t2s_taco_attention": [c_vp] * 14 + [c_int] * 7 + [c_vp],
     "t2s_bernoulli_mask": [c_vp, ctypes.c_size_t, ctypes.c_ulonglong, ctypes.c_ulonglong, c_float, c_vp],
     "t2s_taco_decode_steps": [c_vp, c_int, c_int, c_vp],
     "t2s_taco_stop_check": [c_vp, c_int, c_int, c_int, c_int, c_int, c_float, c_vp, c_vp],

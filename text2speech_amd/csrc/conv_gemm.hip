@@ -305,11 +305,11 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
 #pragma unroll
-            for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal[m], fbh[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < NWT; ++n) acc[m][n] = T2S_MFMA32(fal[m], fbh[n], acc[m][n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[m], fbl[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < NWT; ++n) acc[m][n] = T2S_MFMA32(fah[m], fbl[n], acc[m][n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah[m], fbh[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < NWT; ++n) acc[m][n] = T2S_MFMA32(fah[m], fbh[n], acc[m][n], 0, 0, 0);
         }
     }
   } else if constexpr (!SH) {
@@ -364,11 +364,11 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
             }
             if (!(T2S_ABLATE(a) & 2)) {
 #pragma unroll
-                for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NWT; ++n) acc[m][n] = T2S_MFMA32(al, bh[n], acc[m][n], 0, 0, 0);
 #pragma unroll
-                for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NWT; ++n) acc[m][n] = T2S_MFMA32(ah, bl[n], acc[m][n], 0, 0, 0);
 #pragma unroll
-                for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NWT; ++n) acc[m][n] = T2S_MFMA32(ah, bh[n], acc[m][n], 0, 0, 0);
             } else {
                 asm volatile("" :: "v"(al), "v"(ah));
             }
@@ -441,11 +441,11 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
                 al_n = *(const bf16x8*)(sa + a_frag + A_PLANE + (m + 1) * 1024);
             }
 #pragma unroll
-            for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < NWT; ++n) acc[m][n] = T2S_MFMA32(al, bh[n], acc[m][n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < NWT; ++n) acc[m][n] = T2S_MFMA32(ah, bl[n], acc[m][n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < NWT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < NWT; ++n) acc[m][n] = T2S_MFMA32(ah, bh[n], acc[m][n], 0, 0, 0);
             ah = ah_n;
             al = al_n;
         }
@@ -565,9 +565,9 @@ __global__ __launch_bounds__(128 * WN) void conv_gemm_kernel(const ConvGemmArgs 
                                        lv[1][n][0], lv[1][n][1], lv[1][n][2], lv[1][n][3]};
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, bh8);
                     const bf16x8 bl = __builtin_bit_cast(bf16x8, bl8);
-                    facc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, bh, facc[n], 0, 0, 0);
-                    facc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bl, facc[n], 0, 0, 0);
-                    facc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bh, facc[n], 0, 0, 0);
+                    facc[n] = T2S_MFMA32(wl, bh, facc[n], 0, 0, 0);
+                    facc[n] = T2S_MFMA32(wh, bl, facc[n], 0, 0, 0);
+                    facc[n] = T2S_MFMA32(wh, bh, facc[n], 0, 0, 0);
                 }
             }
         }

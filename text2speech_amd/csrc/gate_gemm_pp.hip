@@ -284,9 +284,9 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
 
 #define PP_MFMA(ACC, AH, AL, BH, BL)                                                 \
     if (!(ABL & 2)) {                                                                \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL, BH, ACC, 0, 0, 0);         \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, BL, ACC, 0, 0, 0);         \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, BH, ACC, 0, 0, 0);         \
+        ACC = T2S_MFMA32(AL, BH, ACC, 0, 0, 0);         \
+        ACC = T2S_MFMA32(AH, BL, ACC, 0, 0, 0);         \
+        ACC = T2S_MFMA32(AH, BH, ACC, 0, 0, 0);         \
     } else {                                                                         \
         asm volatile("" ::"v"(AH), "v"(AL), "v"(BH), "v"(BL));                       \
     }
@@ -532,9 +532,9 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
                                    lv[1][n][0], lv[1][n][1], lv[1][n][2], lv[1][n][3]};
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, bh8);
                 const bf16x8 bl = __builtin_bit_cast(bf16x8, bl8);
-                facc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, bh, facc[n], 0, 0, 0);
-                facc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bl, facc[n], 0, 0, 0);
-                facc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bh, facc[n], 0, 0, 0);
+                facc[n] = T2S_MFMA32(wl, bh, facc[n], 0, 0, 0);
+                facc[n] = T2S_MFMA32(wh, bl, facc[n], 0, 0, 0);
+                facc[n] = T2S_MFMA32(wh, bh, facc[n], 0, 0, 0);
             }
         }
     }

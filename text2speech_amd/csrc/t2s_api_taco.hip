@@ -128,6 +128,37 @@ int t2s_taco_stop_check(const float* mel_gate_out, int B, int n_mel, int T_cap, 
     return T2S_OK;
 }
 
+int t2s_taco_attention(const float* h_att, const float* memory, const float* pmem, const int* lengths, float* w, float* w_cum,
+                       float* ctx, float* q_scratch, float* e_scratch, const float* w_query, const float* w_loc_conv,
+                       const float* w_loc_dense, const float* w_loc_denseT, const float* w_v, int B, int T, int att_rnn,
+                       int att_dim, int enc_dim, int loc_filters, int loc_kernel, void* stream_) {
+    if (!h_att || !memory || !pmem || !w || !w_cum || !ctx || !q_scratch || !e_scratch || !w_query || !w_loc_conv || !w_loc_dense ||
+        !w_v || B <= 0 || T <= 0 || (att_rnn & 3) || (enc_dim & 3) || att_dim <= 0 || att_dim > 128 || loc_filters <= 0 ||
+        loc_filters > 32 || loc_kernel <= 0 || loc_kernel > 63 || !(loc_kernel & 1))
+        return T2S_EINVAL;
+    hipStream_t stream = (hipStream_t)stream_;
+    AttArgs aa;
+    memset(&aa, 0, sizeof(aa));
+    aa.q = q_scratch; aa.w_loc_conv = w_loc_conv; aa.w_loc_dense = w_loc_dense; aa.w_v = w_v; aa.pmem = pmem; aa.memory = memory;
+    aa.lengths = lengths; aa.w_prev = w; aa.w_cum = w_cum; aa.energies = e_scratch; aa.ctx = ctx;
+    aa.B = B; aa.T = T; aa.att_dim = att_dim; aa.enc_dim = enc_dim; aa.loc_f = loc_filters; aa.loc_ks = loc_kernel;
+    aa.w_query = w_query; aa.h_att = h_att; aa.w_loc_denseT = w_loc_denseT; aa.att_rnn = att_rnn;
+    static const int fused_max_b = getenv("T2S_ATT_FUSED_MAXB") ? atoi(getenv("T2S_ATT_FUSED_MAXB")) : 8;
+    if (B <= fused_max_b && T <= 512 && w_loc_denseT && enc_dim <= 512 && att_rnn <= 1024) {
+        T2S_CHECK_HIP(t2s_launch_att_fused(aa, stream));
+        return T2S_OK;
+    }
+    GemvArgs qa;
+    memset(&qa, 0, sizeof(qa));
+    qa.W1 = w_query; qa.ld1 = att_rnn; qa.k1 = att_rnn; qa.x1 = h_att; qa.n1 = att_rnn; qa.sx1 = att_rnn;
+    qa.y = q_scratch; qa.sy_item = att_dim; qa.sy_row = 1; qa.rows = att_dim; qa.items = B; qa.mask_scale = 1.f;
+    if (!gemv_args_ok(qa)) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_gemv(qa, stream));
+    T2S_CHECK_HIP(t2s_launch_att_energy(aa, stream));
+    T2S_CHECK_HIP(t2s_launch_att_softmax_ctx(aa, stream));
+    return T2S_OK;
+}
+
 int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, void* stream_) {
     if (!d || step0 < 0 || n_steps <= 0) return T2S_EINVAL;
     hipStream_t stream = (hipStream_t)stream_;

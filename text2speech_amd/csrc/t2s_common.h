@@ -14,8 +14,6 @@
 #include <stdint.h>
 
 typedef unsigned short u16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
 
@@ -23,6 +21,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
 #define T2S_TILE_M 256          // output-channel rows per workgroup
 #define T2S_TILE_N 256          // time steps per workgroup
 
+#ifndef T2S_SPLIT_F16
+// ---- the shipped operand format: split-bf16 ----
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;      // one MFMA operand fragment (8 x 16-bit)
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#define T2S_MFMA32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
 static __device__ __forceinline__ u16 bf16_bits(float x) {
     __bf16 h = (__bf16)x;                      // v_cvt_pk_bf16_f32: RNE, NaN-preserving
     return __builtin_bit_cast(u16, h);
@@ -30,6 +33,25 @@ static __device__ __forceinline__ u16 bf16_bits(float x) {
 static __device__ __forceinline__ float bf16_to_f32(u16 b) {
     return __builtin_bit_cast(float, (uint32_t)b << 16);
 }
+#else
+// ---- DIAGNOSTIC build (-DT2S_SPLIT_F16, `python -m text2speech_amd.build --variant f16x3 -DT2S_SPLIT_F16`): the same three
+// products per MAC with fp16 operand planes instead of bf16 (v_mfma_f32_16x16x32_f16: same issue rate, profiles/r03_mfma_f8_probe.txt).
+// hi = fp16(x) keeps 11 significand bits instead of 8, so hi + lo carries ~22 bits where both are normal numbers - but fp16 has
+// no exponent range to spare: |x| > 65504 overflows to inf and |x| < 6e-5 loses the low plane to subnormals.  The no-grad WaveGlow
+// forward / infer only (activations and weight-normed weights sit inside that range; GRADIENT planes do not, and the training path
+// also builds bf16 constants on the Python side): tests/test_waveglow_gpu.py::test_stress_weights_* runs it next to the shipped
+// library.  The type and function NAMES below stay those of the shipped format so that no kernel source differs between the builds.
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 bf16x4;
+#define T2S_MFMA32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+static __device__ __forceinline__ u16 bf16_bits(float x) {
+    _Float16 h = (_Float16)x;                  // v_cvt_f16_f32: RNE
+    return __builtin_bit_cast(u16, h);
+}
+static __device__ __forceinline__ float bf16_to_f32(u16 b) {
+    return (float)__builtin_bit_cast(_Float16, b);
+}
+#endif
 // x -> (hi, lo) with hi = bf16(x), lo = bf16(x - hi); x - hi is exact in f32.
 static __device__ __forceinline__ void split_bf16(float x, u16& hi, u16& lo) {
     hi = bf16_bits(x);

@@ -66,6 +66,7 @@ __device__ __forceinline__ bf16x8 tr_frag_asm(unsigned addr) {
 
 // sum of the 8 bf16 values of a fragment, added to acc (4 v_dot2c_f32_bf16 against (1, 1): exact products, f32 accumulate)
 __device__ __forceinline__ float frag_sum(bf16x8 v, float acc) {
+#ifndef T2S_SPLIT_F16
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
     const bf16x2_t one = {(__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
@@ -73,6 +74,15 @@ __device__ __forceinline__ float frag_sum(bf16x8 v, float acc) {
         const bf16x2_t p = {v[2 * i], v[2 * i + 1]};
         acc = __builtin_amdgcn_fdot2_f32_bf16(p, one, acc, false);
     }
+#else       // (diagnostic fp16 build: the training path is not meant to run there; kept compilable)
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+    const f16x2_t one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f16x2_t p = {v[2 * i], v[2 * i + 1]};
+        acc = __builtin_amdgcn_fdot2(p, one, acc, false);
+    }
+#endif
     return acc;
 }
 
@@ -171,11 +181,11 @@ __global__ __launch_bounds__(512) void wgrad_cl_kernel(const WgradClArgs a) {
                 fal_n = tr_frag(sb + off + WG_PLANE);
             }
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fal, fbh[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < 4; ++n) acc[m][n] = T2S_MFMA32(fal, fbh[n], acc[m][n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah, fbl[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < 4; ++n) acc[m][n] = T2S_MFMA32(fah, fbl[n], acc[m][n], 0, 0, 0);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fah, fbh[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < 4; ++n) acc[m][n] = T2S_MFMA32(fah, fbh[n], acc[m][n], 0, 0, 0);
             fah = fah_n;
             fal = fal_n;
         }
@@ -349,9 +359,9 @@ __global__ __launch_bounds__(512) void wgrad_cl_pp_kernel(const WgradClArgs a) {
 
     // swapped operands: D[i][j] = sum_k Bfrag[i][k] * Afrag[j][k]  ->  lane holds columns n = 4 (lane >> 4) + e of row m = lane & 15
 #define WG_MFMA(ACC, AH, AL, BH, BL)                                             \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BH, AL, ACC, 0, 0, 0);         \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BL, AH, ACC, 0, 0, 0);         \
-    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BH, AH, ACC, 0, 0, 0);
+    ACC = T2S_MFMA32(BH, AL, ACC, 0, 0, 0);         \
+    ACC = T2S_MFMA32(BL, AH, ACC, 0, 0, 0);         \
+    ACC = T2S_MFMA32(BH, AH, ACC, 0, 0, 0);
 
     auto kstep = [&](int ks, auto main_tag) {
         constexpr bool MAIN = decltype(main_tag)::value;

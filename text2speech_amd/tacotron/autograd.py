@@ -439,11 +439,11 @@ class _Bwd:
 
 class _TacotronFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, text, text_lengths, mels, output_lengths, prenet_masks, train_masks, *params):
+    def forward(ctx, model, text, text_lengths, mels, output_lengths, prenet_masks, train_masks, max_len, *params):
         eng = model._eng()
         sv = {}
         with torch.no_grad():
-            out = eng.forward(text, text_lengths, mels, output_lengths, prenet_masks, train_masks=train_masks, save=sv)
+            out = eng.forward(text, text_lengths, mels, output_lengths, prenet_masks, train_masks=train_masks, save=sv, max_len=max_len)
         ctx.model, ctx.sv, ctx.params = model, sv, params
         ctx.mark_non_differentiable(out[3])
         return tuple(out)
@@ -462,9 +462,9 @@ class _TacotronFn(torch.autograd.Function):
             g = grads.get(id(p))
             outs.append(None if g is None else g.reshape(p.shape).to(p.dtype))
         ctx.model.__dict__["_last_bwd"] = bw          # keeps scratch alive until the next step's backward
-        return (None, None, None, None, None, None, None, *outs)
+        return (None, None, None, None, None, None, None, None, *outs)
 
 
-def tacotron_forward_with_grad(model, text, text_lengths, mels, output_lengths, prenet_masks, train_masks):
+def tacotron_forward_with_grad(model, text, text_lengths, mels, output_lengths, prenet_masks, train_masks, max_len=None):
     params = list(model.parameters())
-    return list(_TacotronFn.apply(model, text, text_lengths, mels, output_lengths, prenet_masks, train_masks, *params))
+    return list(_TacotronFn.apply(model, text, text_lengths, mels, output_lengths, prenet_masks, train_masks, max_len, *params))

@@ -25,6 +25,7 @@ class OwnedModule(nn.Module):
     def __getstate__(self):
         d = self.__dict__.copy()
         d.pop("_owner", None)
+        d.pop("_step", None)        # Decoder: the device-side step state (raw pointers) is not part of the model
         return d
 
 

@@ -34,7 +34,14 @@ class LocationLayer(nn.Module):
         self.location_dense = LinearNorm(attention_n_filters, attention_dim, bias=False, w_init_gain="tanh")
 
 
-class Attention(nn.Module):
+def _lengths_from_mask(mask, T):
+    """int32 lengths from the reference's padding mask (True on padding, a suffix of every row: ~get_mask_from_lengths)."""
+    if mask is None:
+        return None
+    return (T - mask.to(torch.int32).sum(1)).to(torch.int32).contiguous()
+
+
+class Attention(OwnedModule):
     def __init__(self, attention_rnn_dim, embedding_dim, attention_dim, attention_location_n_filters,
                  attention_location_kernel_size):
         super().__init__()
@@ -44,6 +51,33 @@ class Attention(nn.Module):
         self.location_layer = LocationLayer(attention_location_n_filters, attention_location_kernel_size,
                                             attention_dim)
         self.score_mask_value = -float("inf")
+
+    def forward(self, attention_hidden_state, memory, processed_memory, attention_weights_cat, mask):
+        """Reference tacotron.py:145-166: (attention_context [B, E], attention_weights [B, T]) from the attention LSTM's output,
+        the encoder outputs, their memory_layer projection, the previous and cumulative weights stacked as [B, 2, T], and the
+        padding mask (True on padding; None: no masking).  One call of the kernels the decode loop uses (t2s_taco_attention);
+        forward only - training goes through Tacotron.forward."""
+        from .modules import owner_engine
+        with torch.no_grad():
+            eng = owner_engine(self)
+            dev = memory.device
+            P = eng.prepare(dev)
+            B, T, E = memory.shape
+            ad = self.query_layer.linear_layer.out_features
+            w = attention_weights_cat[:, 0].detach().to(torch.float32).contiguous().clone()
+            wc = attention_weights_cat[:, 1].detach().to(torch.float32).contiguous().clone()
+            h = _f32(attention_hidden_state)
+            mem, pmem = _f32(memory), _f32(processed_memory)
+            ctx = torch.empty(B, E, dtype=torch.float32, device=dev)
+            q = torch.empty(B, ad, dtype=torch.float32, device=dev)
+            e = torch.empty(B, T, dtype=torch.float32, device=dev)
+            len32 = _lengths_from_mask(mask, T)
+            conv = self.location_layer.location_conv.conv
+            _lib.call("t2s_taco_attention", _lib.ptr(h), _lib.ptr(mem), _lib.ptr(pmem), _lib.ptr(len32), _lib.ptr(w), _lib.ptr(wc),
+                      _lib.ptr(ctx), _lib.ptr(q), _lib.ptr(e), _lib.ptr(P["w_query"]), _lib.ptr(P["w_loc_conv"]),
+                      _lib.ptr(P["w_loc_dense"]), _lib.ptr(P["w_loc_denseT"]), _lib.ptr(P["w_v"]), B, T, h.size(1), ad, E,
+                      conv.out_channels, conv.kernel_size[0], _lib.current_stream())
+            return ctx, w
 
 
 class Encoder(OwnedModule):
@@ -119,6 +153,81 @@ class Decoder(OwnedModule):
         from .modules import owner_engine
         with torch.no_grad():
             return owner_engine(self).decode_free(memory, prenet_masks, None, 64, train_masks)
+
+    # ---- single decoder steps on module-held state (reference tacotron.py:262-307, 355-393) ----
+    def get_go_frame(self, memory):
+        """Reference tacotron.py:262-274: the all-zero first decoder input [B, n_mel * n_frames_per_step]."""
+        return memory.new_zeros(memory.size(0), self.n_mel_channels * self.n_frames_per_step)
+
+    def initialize_decoder_states(self, memory, mask):
+        """Reference tacotron.py:276-307: zero LSTM states / attention weights / context, store memory and processed memory.
+        mask: True on padding (~get_mask_from_lengths(memory_lengths)), or None.  The state lives in one device block the step
+        kernels update in place; the reference's attribute names are views of it."""
+        from .modules import owner_engine
+        with torch.no_grad():
+            eng = owner_engine(self)
+            dev = memory.device
+            eng.prepare(dev)
+            mem = memory.detach().to(torch.float32).contiguous()
+            B, T_in, E = mem.shape
+            len32 = _lengths_from_mask(mask, T_in)
+            Pd, D = self.prenet_dim, self.decoder_rnn_dim
+            # two step slots: the step kernels ping-pong h by step parity and index their per-step buffers by the step number
+            pre = torch.zeros(2, B, Pd, dtype=torch.float32, device=dev)
+            hc = torch.empty(2, B, D + E, dtype=torch.float32, device=dev)
+            extra = dict(pre_all=pre, hc_all=hc)
+            d, S = eng._decoder_struct(mem, len32, 2, True, extra)
+            self.__dict__["_step"] = dict(d=d, S=S, n=0, len32=len32, B=B, T_in=T_in, E=E)
+            self.memory, self.processed_memory, self.mask = memory, S["pmem"], mask
+            self._publish_state()
+
+    def _publish_state(self):
+        st = self.__dict__["_step"]
+        S, n = st["S"], st["n"]
+        cur = (lambda a, b: S[b] if n & 1 else S[a])       # after n steps the newest h sits in slot n & 1
+        self.attention_hidden, self.attention_cell = cur("att_h0", "att_h1"), S["att_c"]
+        self.decoder_hidden, self.decoder_cell = cur("dec_h0", "dec_h1"), S["dec_c"]
+        self.attention_weights, self.attention_weights_cum, self.attention_context = S["att_w"], S["att_wcum"], S["ctx"]
+
+    def decode(self, decoder_input, attention_dropout_mask=None, decoder_dropout_mask=None):
+        """Reference tacotron.py:355-393: ONE decoder step on the stored state.  decoder_input [B, prenet_dim] is the prenet's
+        output, as in the reference.  Returns (decoder_output [B, n_mel], gate_prediction [B, 1], attention_weights [B, T_in]).
+        In .train() mode the two LSTM outputs get dropout (tacotron.py:368,383): {0,1} masks [B, H] can be injected, else they are
+        drawn on the device.  Forward only."""
+        from .modules import owner_engine
+        st = self.__dict__.get("_step")
+        if st is None:
+            raise _lib.T2SError("Decoder.decode before Decoder.initialize_decoder_states")
+        with torch.no_grad():
+            eng = owner_engine(self)
+            d, S, n, B = st["d"], st["S"], st["n"], st["B"]
+            dev = S["ctx"].device
+            P = eng.prepare(dev)
+            slot = n & 1
+            S["pre_all"][slot].copy_(decoder_input.detach().to(torch.float32).reshape(B, self.prenet_dim))
+            keep = []
+            if self.training:
+                seed = eng.fresh_seed()
+                am = eng._drop(attention_dropout_mask, (B, self.attention_rnn_dim), 1 - self.p_attention_dropout, dev, seed + 301)
+                dm = eng._drop(decoder_dropout_mask, (B, self.decoder_rnn_dim), 1 - self.p_decoder_dropout, dev, seed + 302)
+                # the kernels index the masks by step number: hand them a base such that base + slot * B * H is this step's mask
+                d.att_drop = am.data_ptr() - slot * B * self.attention_rnn_dim
+                d.dec_drop = dm.data_ptr() - slot * B * self.decoder_rnn_dim
+                d.att_drop_scale = 1.0 / (1.0 - self.p_attention_dropout)
+                d.dec_drop_scale = 1.0 / (1.0 - self.p_decoder_dropout)
+                keep = [am, dm]
+            else:
+                d.att_drop = d.dec_drop = None
+                d.att_drop_scale = d.dec_drop_scale = 1.0
+            _lib.call("t2s_taco_decode_steps", ctypes.byref(d), slot, 1, _lib.current_stream())
+            n_mel = self.n_mel_channels * self.n_frames_per_step
+            proj = torch.empty(B, n_mel + 1, dtype=torch.float32, device=dev)
+            D, E = self.decoder_rnn_dim, st["E"]
+            eng._gemv(P["w_proj"], S["hc_all"][slot], n_mel + 1, B, D + E, proj, bias=P["b_proj"])
+            st["n"] = n + 1
+            st["keep"] = keep
+            self._publish_state()
+            return proj[:, :n_mel].contiguous(), proj[:, n_mel:].contiguous(), S["align_out"][:, slot].clone()
 
 
 class _DecoderStruct(ctypes.Structure):
@@ -378,7 +487,7 @@ class _TacoEngine:
                   layer["Cout"], layer.get("taps", 1), 1, act, L, Lp, halo, layer["Mpad"], _lib.current_stream())
         return Oh, Ol
 
-    def encode(self, ids, lengths, train_masks=None, seed=0, save=None, embedded=None):
+    def encode(self, ids, lengths, train_masks=None, seed=0, save=None, embedded=None, max_len=None):
         """Embedding + Encoder.forward / .inference (reference tacotron.py:40,192-220).  In training mode the
         convolutions use batch statistics and dropout(0.5) (masks from ``train_masks['enc']`` or drawn here).
         ``embedded`` [B, E, T] f32: start from embedded inputs instead of ids (Encoder.forward's own argument)."""
@@ -418,7 +527,10 @@ class _TacoEngine:
         self._conv(P["lstm_in"], Xh, Xl, B, T, Lp, halo, 0, out_planes=False, out_f32=gx, f32_cl=1)
         if lengths is not None:
             len32 = lengths.to(device=dev, dtype=torch.int32).contiguous()
-            T_out = int(lengths.max().item())
+            # the longest entry: given by the caller (the batch tuple's max_len, reference tacotron.py:81-83 / parse_batch) or read
+            # back from the device - a host synchronisation that keeps the host from enqueueing this step while the previous one
+            # still runs
+            T_out = int(max_len) if max_len is not None else int(lengths.max().item())
         else:
             len32, T_out = None, T
         memory = torch.empty(B, T_out, 2 * H, dtype=torch.float32, device=dev)
@@ -660,14 +772,19 @@ class _TacoEngine:
         align = S["align_out"][:, :n_done].contiguous()
         return mel, gate, align
 
-    def forward(self, text, text_lengths, mels, output_lengths, prenet_masks=None, seed=None, train_masks=None, save=None):
+    def forward(self, text, text_lengths, mels, output_lengths, prenet_masks=None, seed=None, train_masks=None, save=None,
+                max_len=None):
         if seed is None:
             seed = self.fresh_seed()
         m = self.m
         dec = m.decoder
         dev = text.device
         self.prepare(dev)
-        memory, len32 = self.encode(text, text_lengths, train_masks, seed, save=save)
+        if max_len is not None:
+            max_len = int(max_len)
+            if not 0 < max_len <= text.size(1):
+                raise _lib.T2SError("max_len %d outside (0, %d]" % (max_len, text.size(1)))
+        memory, len32 = self.encode(text, text_lengths, train_masks, seed, save=save, max_len=max_len)
         mel, gate, align = self.decode_teacher(memory, len32, mels, prenet_masks, seed, train_masks, save)
         B, n_mel, T_out = mels.shape
         mel_post = mel + self.postnet(mel, train_masks, seed, save=save)
@@ -794,7 +911,7 @@ class Tacotron(nn.Module):
     def _adopt(self):
         """The sub-modules reach the engine through a weak reference to their owner (kept out of the module tree)."""
         import weakref
-        for sub in (self.encoder, self.decoder, self.decoder.prenet, self.postnet):
+        for sub in (self.encoder, self.decoder, self.decoder.prenet, self.decoder.attention_layer, self.postnet):
             sub.__dict__["_owner"] = weakref.ref(self)
 
     def _eng(self):
@@ -827,11 +944,19 @@ class Tacotron(nn.Module):
             from .autograd import tacotron_forward_with_grad
             # parse_output (tacotron.py:49) has been applied by the engine: one HIP launch inside the forward, see there
             return list(tacotron_forward_with_grad(self, text_inputs, text_lengths.data, mels, output_lengths.data, prenet_masks,
-                                                   train_masks))
+                                                   train_masks, self._host_max_len(max_len)))
         with torch.no_grad():
             out = self._eng().forward(text_inputs, text_lengths.data, mels, output_lengths.data, prenet_masks,
-                                      train_masks=train_masks)
+                                      train_masks=train_masks, max_len=self._host_max_len(max_len))
         return self._as_module_dtype(out)
+
+    @staticmethod
+    def _host_max_len(max_len):
+        """The batch tuple's `max_len` (reference parse_batch: torch.max(input_lengths).item(), a host number) when it is one; a
+        device tensor or None makes the encoder read the maximum back itself."""
+        if isinstance(max_len, (int, float)) and not isinstance(max_len, bool):
+            return int(max_len)
+        return None
 
     def inference(self, inputs, speaker_id=None, prenet_masks=None, train_masks=None):
         """Autoregressive decode (reference tacotron.py:51-65).  Works in ``.train()`` mode as the reference's does (batch-statistics
