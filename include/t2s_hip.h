@@ -49,6 +49,11 @@ extern "C" {
 #define T2S_ACT_TANH 2
 
 int t2s_abi_version(void);
+/* ABI v4.  Operand format of the split planes this build computes with: 0 = bf16 hi/lo (the shipped library), 1 = fp16 hi/lo
+ * (diagnostic build -DT2S_SPLIT_F16: same three MFMA products per MAC, ~22 instead of ~16 significand bits, but no exponent range
+ * to spare - the no-grad WaveGlow forward / infer only; the host side refuses the training path and turns a non-finite result,
+ * i.e. an operand plane that overflowed 65504, into an error instead of returning it). */
+int t2s_operand_format(void);
 const char* t2s_error_string(int code);
 /* last HIP error text seen by a failing entry point on this thread ("" if none) */
 const char* t2s_last_hip_error(void);

@@ -15,6 +15,7 @@ c_int, c_float, c_vp, c_long = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ct
 # name -> argtypes (every function returns int unless listed in _RESTYPE)
 SIGNATURES = {
     "t2s_abi_version": [],
+    "t2s_operand_format": [],
     "t2s_error_string": [c_int],
     "t2s_last_hip_error": [],
     "t2s_plane_rows": [c_int, c_int],
@@ -173,6 +174,11 @@ def call(name, *args):
         hip = lib.t2s_last_hip_error().decode()
         raise T2SError("%s failed: %s%s" % (name, msg, (" (" + hip + ")") if hip and rc == -2 else ""))
     return rc
+
+
+def operand_format():
+    """0: split-bf16 planes (the shipped library); 1: split-fp16 planes (diagnostic build, T2S_LIB_PATH=build/f16x3/...)."""
+    return load().t2s_operand_format()
 
 
 def plane_rows(L, halo):

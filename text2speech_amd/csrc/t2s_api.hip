@@ -28,6 +28,14 @@ extern "C" {
 
 int t2s_abi_version(void) { return 4; }
 
+int t2s_operand_format(void) {
+#ifdef T2S_SPLIT_F16
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 const char* t2s_error_string(int code) {
     switch (code) {
         case T2S_OK: return "ok";

@@ -705,10 +705,25 @@ class WaveGlow(torch.nn.Module):
         """forward_input = (mel [B, n_mel, frames], audio [B, T]) -> (z, [log_s], [log_det_W])
         (reference glow.py:207-249)."""
         spect, audio = forward_input
+        f16 = _lib.operand_format() == 1
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if f16:
+                raise _lib.T2SError("the fp16-operand diagnostic build runs the no-grad forward / infer only: gradient planes "
+                                    "underflow fp16 (use the shipped library for training)")
             from .glow_autograd import waveglow_forward_with_grad
             return waveglow_forward_with_grad(self, spect, audio)
-        return self._eng().forward(spect, audio)
+        out = self._eng().forward(spect, audio)
+        if f16:
+            self._refuse_overflow(out[0])
+        return out
+
+    @staticmethod
+    def _refuse_overflow(t):
+        """fp16-operand build only: a plane element beyond fp16's range (65504) became inf inside the flow and shows as a non-finite
+        output - an error, not a result (the shipped bf16 planes have f32's exponent range and need no such check)."""
+        if not bool(torch.isfinite(t).all()):
+            raise _lib.T2SError("fp16 operand planes overflowed (|x| > 65504 somewhere in the flow): result refused; "
+                                "use the shipped split-bf16 library for this checkpoint / input")
 
     def infer(self, spect, sigma=1.0, noise=None):
         """mel [B, n_mel, frames] -> audio [B, 256*frames] (reference glow.py:251-292).
@@ -716,6 +731,8 @@ class WaveGlow(torch.nn.Module):
         Gaussian draws explicit for parity tests; by default they are drawn on the device."""
         with torch.no_grad():
             out = self._eng().infer(spect, float(sigma), noise)
+        if _lib.operand_format() == 1:
+            self._refuse_overflow(out)
         return out.to(spect.dtype) if spect.dtype in (torch.float16, torch.bfloat16) else out
 
     @staticmethod

@@ -31,6 +31,17 @@ def main():
     m = WaveGlow(**cfg)
     m.load_state_dict(sd)
     m = m.cuda().eval()
+    if len(sys.argv) > 2 and sys.argv[2] == "overflow":
+        # audio far outside fp16's range: the fp16-operand build must REFUSE (exit 7), the shipped bf16 planes just compute (exit 0)
+        from text2speech_amd import _lib
+        try:
+            with torch.no_grad():
+                z, _, _ = m((mel.cuda(), (audio * 1e7).cuda()))
+            torch.cuda.synchronize()
+        except _lib.T2SError as e:
+            print("refused:", e)
+            sys.exit(7)
+        sys.exit(0 if bool(torch.isfinite(z).all()) else 8)
     with torch.no_grad():
         z, _, _ = m((mel.cuda(), audio.cuda()))
         a = m.infer(mel_inf.cuda(), sigma=0.666, noise=noise)
