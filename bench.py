@@ -37,7 +37,7 @@ BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s HBM3E
 WG_FWD_FLOP_PER_SAMPLE = 65.36e6  # 8.3666 TFLOP per 8 x 16000 forward
 TACO_FWD_FLOP_PER_FRAME = 52.1e6  # 1.334 TFLOP per 32 x 800 teacher-forced forward
-GEMM_PMC = "r03_pmc_traffic.json"  # profiles/: HBM-side bytes per launch of the gate GEMM (separate --pmc passes)
+GEMM_PMC = "r04_pmc_traffic.json"  # profiles/: HBM-side bytes per launch of the gate GEMM (separate --pmc passes)
 
 
 def log(msg):
@@ -183,8 +183,12 @@ def tacotron_metrics(dev):
                        "achieved": lstm_bytes / (dt / n) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": lstm_bytes / (dt / n) / 1e9 / HBM_PEAK_GBS,
                        "algorithmic_bytes_per_step": lstm_bytes,
+                       "decode_step_only": {"achieved": lstm_bytes / slope / 1e9, "frac": lstm_bytes / slope / 1e9 / HBM_PEAK_GBS,
+                                            "note": "the same bytes over the decode step alone (slope between 200 and 1000 frames)"},
                        "note": "71.3 MB of f32 LSTMCell weights per decoder step (what the reference streams) over the whole "
-                               "step time, encoder + postnet included"}
+                               "step time, encoder + postnet included.  Since round 4 the step is four launches: attention cell "
+                               "(+ the sparse prenet layer), attention + gate-stream role (50 MB of the weights on the CUs the "
+                               "attention leaves idle), decoder cell, projection"}
     B, T_in, T_out = 32, 256, 800
     gen = torch.Generator().manual_seed(21)
     text = torch.randint(2, 80, (B, T_in), generator=gen).to(dev)
@@ -399,7 +403,7 @@ def main():
             # HBM-side bytes per launch of this kernel come from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
             # --pmc WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note in MI355X_MICROARCH.md)
             traffic, tsrc = None, None
-            for name in (GEMM_PMC, "r02_pmc_traffic.json", "r01_pmc_traffic_v5.json"):
+            for name in (GEMM_PMC, "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic_v5.json"):
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", name)))
                     # the gate GEMM: the ping-pong kernel (round 2), or the two lockstep instantiations of round 1

@@ -355,7 +355,13 @@ __global__ __launch_bounds__(512) void sbgemm_lstm_kernel(const LstmCellArgs a) 
     const int u0 = blockIdx.x * 4, item_base = blockIdx.y * 32;
     auto wrow = [&](int tr) { return (size_t)(tr & 3) * a.H + u0 + (tr >> 2); };       // tile row = unit * 4 + gate
     const int dr = (threadIdx.x & 63) >> 3;
+    // partial attention query of this workgroup's four units (LstmCellArgs::q_part, q_dim = 128): its four columns of W_query are
+    // requested now, in front of the K loop
+    __shared__ float s_hq[4][32];
+    f32x4 wq = {0.f, 0.f, 0.f, 0.f};
+    if (a.q_part) wq = *(const f32x4*)(a.w_q + (size_t)(threadIdx.x & 127) * a.H + u0);
     sb_core<KW>(o, wrow(threadIdx.x & 15), true, item_base, s_part, sb_ring, wrow(dr), wrow(dr + 8));
+    if (threadIdx.x < 128) s_hq[threadIdx.x & 3][threadIdx.x >> 2] = 0.f;
     if (threadIdx.x < 128) {
         const int ul = threadIdx.x & 3, it = threadIdx.x >> 2;
         const int item = item_base + it, u = u0 + ul;
@@ -377,12 +383,27 @@ __global__ __launch_bounds__(512) void sbgemm_lstm_kernel(const LstmCellArgs a) 
             if (a.drop_mask) h2 = a.drop_mask[idx] ? h2 * a.drop_scale : 0.f;
             a.h_out[idx] = h2;
             if (a.h_copy) a.h_copy[(size_t)item * a.s_copy + u] = h2;
+            s_hq[ul][it] = h2;
+        }
+    }
+    if (a.q_part) {
+        // q_part[workgroup][item][a] = sum over this workgroup's units of W_query[a][u] * h[item][u] (tacotron.py:137 query_layer; summed
+        // over the H / 4 workgroups by the energies kernel): the query GEMM leaves the serial chain of the teacher-forced decoder
+        __syncthreads();
+        const int aq = threadIdx.x & 127, ig = threadIdx.x >> 7;           // 4 groups of 8 items
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int it = ig * 8 + j, item = item_base + it;
+            if (item < a.B)
+                a.q_part[((size_t)blockIdx.x * a.B + item) * 128 + aq] =
+                    (wq[0] * s_hq[0][it] + wq[1] * s_hq[1][it]) + (wq[2] * s_hq[2][it] + wq[3] * s_hq[3][it]);
         }
     }
 }
 
 bool t2s_sbgemm_lstm_ok(const LstmCellArgs& a) {
-    if (a.B <= 8 || (a.H & 15) || (a.n1 & 15) || (a.n2 & 15) || a.q_part || a.pre_a || !a.h_in || a.ld_ih > 0) return false;
+    if (a.B <= 8 || (a.H & 15) || (a.n1 & 15) || (a.n2 & 15) || a.pre_a || !a.h_in || a.ld_ih > 0) return false;
+    if (a.q_part && (a.q_dim != 128 || !a.w_q || ((uintptr_t)a.w_q & 15))) return false;
     if ((a.sx1 & 3) || (a.x2 && (a.sx2 & 3))) return false;
     if (((uintptr_t)a.W_ih & 15) || ((uintptr_t)a.W_hh & 15) || ((uintptr_t)a.x1 & 15) || ((uintptr_t)a.x2 & 15) ||
         ((uintptr_t)a.h_in & 15))

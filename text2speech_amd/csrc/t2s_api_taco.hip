@@ -225,6 +225,17 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         const bool q_parts = fused_att && B <= 8 && d->q_part != nullptr;      // (9+ items: the cells run on sbgemm.hip, no partials)
         const int units = ca.gates_out ? 2 : 4;             // hidden units per workgroup of lstm_cell_kernel (training / eval)
         if (q_parts) { ca.w_q = d->w_query; ca.q_part = d->q_part; ca.q_dim = d->att_dim; }
+        // large batch (matrix-core cells): the same idea - every cell workgroup (4 hidden units) leaves a partial query and the
+        // energies kernel sums the A / 4 = 256 of them - takes the query GEMM off the serial chain.  T2S_QPART_BIG=0: the GEMM.
+        static const bool want_qbig = !(getenv("T2S_QPART_BIG") && atoi(getenv("T2S_QPART_BIG")) == 0);
+        static const bool att_valu = getenv("T2S_ATT_VALU") != nullptr;
+        bool q_big = false;
+        if (!fused_att && !q_parts && want_qbig && !att_valu && d->q_part && A == 1024 && d->att_dim == 128 && d->loc_filters == 32 &&
+            d->loc_kernel <= 31 && d->w_loc_denseT) {
+            ca.w_q = d->w_query; ca.q_part = d->q_part; ca.q_dim = d->att_dim;
+            q_big = t2s_sbgemm_lstm_ok(ca);
+            if (!q_big) { ca.w_q = nullptr; ca.q_part = nullptr; ca.q_dim = 0; }
+        }
         // streamed gates: W_hh_att . h_att(s-1) was left in gate_part[2] by the previous step's attention launch (zero at step 0)
         if (want_stream && d->gate_part && !d->teacher_forced && fused_att && q_parts && !ca.gates_out && A == 1024 && D == 1024) {
             gs.W0 = d->dec_w_hh; gs.ld0 = D; gs.x0 = dh_in; gs.out0 = d->gate_part;
@@ -267,7 +278,8 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
             qa.y = d->q_all ? d->q_all + (size_t)s * B * d->att_dim : d->q; qa.sy_item = d->att_dim; qa.sy_row = 1;
             qa.rows = d->att_dim; qa.items = B;
             aa.q = qa.y;
-            T2S_CHECK_HIP(t2s_launch_gemv(qa, stream));
+            if (q_big) { aa.q_part = d->q_part; aa.n_part = A / 4; aa.q_out = qa.y; aa.q_save = nullptr; }
+            else T2S_CHECK_HIP(t2s_launch_gemv(qa, stream));
             T2S_CHECK_HIP(t2s_launch_att_energy(aa, stream));
             T2S_CHECK_HIP(t2s_launch_att_softmax_ctx(aa, stream));
         }

@@ -98,6 +98,7 @@ struct AttArgs {
     int att_rnn;
     const float* q_part;       // [n_part][B][att_dim] partial queries from lstm_cell_kernel (instead of w_query . h_att)
     int n_part;
+    float* q_out;              // large-batch form with q_part: the summed query [B][att_dim] is written here (by the first chunk's workgroup)
     float* q_save;             // optional [B][att_dim]: query of this step (training)
     float* wcum_save;          // optional [B][T]: cumulative weights after this step (training)
 };

@@ -686,7 +686,25 @@ __global__ __launch_bounds__(512) void att_energy_mfma_kernel(const AttArgs a) {
     float bd[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) bd[u] = a.w_loc_denseT[(4 * u + lq) * AD + ach];      // B[k = f][col a] = D[a][f]
-    const float qv = a.q[(size_t)b * AD + ach], vv = a.w_v[ach];
+    // The query: given (a.q), or the sum of the per-workgroup partials the attention cell's launch left (a.q_part, n_part = 256:
+    // thread = (four consecutive channels, one of 16 slices of 16 partials), 16 float4 loads in flight at once next to the loads
+    // above - one round trip for the 128 KB -, then a 16-way sum through LDS in a fixed order).
+    __shared__ __attribute__((aligned(16))) float s_qp[16][AD];
+    const bool parts = a.q_part != nullptr;
+    if (parts) {
+        const int aq = tid & 31, part = tid >> 5;
+        const float* qp = a.q_part + ((size_t)part * 16 * a.B + b) * AD + 4 * aq;
+        const size_t qs = (size_t)a.B * AD;
+        f32x4 pv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) pv[u] = *(const f32x4*)(qp + (size_t)u * qs);
+        f32x4 acc = pv[0];
+#pragma unroll
+        for (int u = 1; u < 16; ++u) acc += pv[u];
+        *(f32x4*)&s_qp[part][4 * aq] = acc;
+    }
+    float qv = parts ? 0.f : a.q[(size_t)b * AD + ach];
+    const float vv = a.w_v[ach];
     float pm[2][4];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
@@ -702,6 +720,16 @@ __global__ __launch_bounds__(512) void att_energy_mfma_kernel(const AttArgs a) {
         if (i < 32 * K2) {
             const int f = i / K2, k = i - f * K2;
             s_kb[(f >> 4) * 1024 + k * 16 + (f & 15)] = rk[j];
+        }
+    }
+    if (parts) {
+        float q = 0.f;
+#pragma unroll
+        for (int p16 = 0; p16 < 16; ++p16) q += s_qp[p16][ach];
+        qv = q;
+        if (blockIdx.x == 0 && lq == 0) {
+            if (a.q_out) a.q_out[(size_t)b * AD + ach] = q;
+            if (a.q_save) a.q_save[(size_t)b * AD + ach] = q;
         }
     }
     __syncthreads();
@@ -754,10 +782,12 @@ hipError_t t2s_launch_att_energy(const AttArgs& a, hipStream_t stream) {
     // T2S_ATT_VALU set: the VALU kernel (A/B switch, shared with the fused small-batch form)
     static const bool no_mfma = getenv("T2S_ATT_VALU") != nullptr;
     if (!no_mfma && a.att_dim == 128 && a.loc_f == 32 && a.loc_ks <= 31 && a.w_loc_denseT) {
+        if (a.q_part && a.n_part != 256) return hipErrorInvalidValue;
         dim3 grid((a.T + ATT_MQ - 1) / ATT_MQ, a.B);
         hipLaunchKernelGGL(att_energy_mfma_kernel, grid, dim3(512), 0, stream, a);
         return hipGetLastError();
     }
+    if (a.q_part) return hipErrorInvalidValue;          // (only the matrix-core kernel sums partial queries)
     dim3 grid((a.T + ATT_TQ - 1) / ATT_TQ, a.B);
     hipLaunchKernelGGL(att_energy_kernel, grid, dim3(256), (size_t)a.loc_f * 2 * a.loc_ks * sizeof(float), stream, a);
     return hipGetLastError();
