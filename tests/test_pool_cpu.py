@@ -1,15 +1,16 @@
 """Host logic of the training-step buffer pool (text2speech_amd/tacotron/tacotron.py: pool_take / _Lease): buffers are keyed by
 call site + shape, come back when their holder is released, are never shared between two live holders, and `zero_once` buffers
-are zero-filled only when created.  Runs on CPU tensors."""
+are zero-filled only when created (or, with an `extent`, again when the valid extent changes: tests/test_tacotron_train_gpu.py).
+The bound on the pool's size is in tests/test_host_logic_cpu.py.  Runs on CPU tensors."""
 import gc
 
 import torch
 
-from text2speech_amd.tacotron.tacotron import pool_take
+from text2speech_amd.tacotron.tacotron import BufferPool, pool_take
 
 
 def test_lease_returns_buffer_when_holder_is_released():
-    pool, h1 = {}, []
+    pool, h1 = BufferPool(), []
     a = pool_take(pool, h1, "site", (4, 8), torch.float32, "cpu")
     assert a.shape == (4, 8)
     h2 = []
@@ -24,17 +25,20 @@ def test_lease_returns_buffer_when_holder_is_released():
 
 
 def test_keys_separate_tags_shapes_and_dtypes():
-    pool, h = {}, []
+    pool, h = BufferPool(), []
     a = pool_take(pool, h, "x", (8,), torch.float32, "cpu")
     b = pool_take(pool, h, "y", (8,), torch.float32, "cpu")
     c = pool_take(pool, h, "x", (16,), torch.float32, "cpu")
     d = pool_take(pool, h, "x", (8,), torch.bfloat16, "cpu")
     assert len({t.data_ptr() for t in (a, b, c, d)}) == 4
-    assert len(pool) == 4
+    del a, b, c, d
+    h.clear()
+    gc.collect()
+    assert len(pool.free) == 4
 
 
 def test_zero_once_is_cleared_at_creation_only():
-    pool, h = {}, []
+    pool, h = BufferPool(), []
     a = pool_take(pool, h, "planes", (3, 32), torch.float32, "cpu", zero_once=True)
     assert float(a.abs().max()) == 0.0
     a.fill_(5.0)                    # the owner writes its valid region ...
