@@ -252,6 +252,18 @@ def test_forward_full_vs_golden(lib, golden_dir):
         assert _rel(ls[:, :, ::step], g[f"log_s_{k}"]) < 1e-3
 
 
+_STRESS_ORACLE = {}
+
+
+def _stress_oracle_forward(sd, cfg, mel, audio):
+    """The f32 oracle's forward at the stress weights (2 x 4096): computed once, shared by the two stress tests."""
+    from oracle import waveglow_oracle as O
+    if "fwd" not in _STRESS_ORACLE:
+        with torch.no_grad():
+            _STRESS_ORACLE["fwd"] = O.waveglow_forward(sd, cfg, mel, audio)
+    return _STRESS_ORACLE["fwd"]
+
+
 def test_stress_weights_forward_and_infer_vs_oracle(lib):
     """Split-bf16 margin at a trained-checkpoint-like dynamic range and beyond: WN.end std 0.03 and every weight-norm gain of the
     WN layers x 1.25 (max |log_s| 3-4 against 1.3 with the seeded weights; |z| up to a few hundred).  The flow multiplies by
@@ -271,7 +283,7 @@ def test_stress_weights_forward_and_infer_vs_oracle(lib):
     mel, audio = synth.waveglow_inputs(2, 4096, seed=31)
     with torch.no_grad():
         z, log_s, log_det = m((mel.to(DEV), audio.to(DEV)))
-        zo, lso, ldo = O.waveglow_forward(sd, cfg, mel, audio)
+    zo, lso, ldo = _stress_oracle_forward(sd, cfg, mel, audio)
     torch.cuda.synchronize()
     assert max(float(l.abs().max()) for l in lso) > 2.5          # the stress is real
     rz, mz = _rel(z, zo), _maxrel(z, zo)
@@ -308,8 +320,8 @@ def test_stress_weights_infer_120_frames_both_splits(lib, tmp_path):
     sys.path.insert(0, ROOT)
     from tools.stress_infer_child import stress_case
     cfg, sd, mel, audio, mel_inf, noise = stress_case()
+    zo, lso, _ = _stress_oracle_forward(sd, cfg, mel, audio)          # (same case as the test above: seed 31, 2 x 4096)
     with torch.no_grad():
-        zo, lso, _ = O.waveglow_forward(sd, cfg, mel, audio)
         ao = O.waveglow_infer(sd, cfg, mel_inf, noise[0], noise[1], sigma=0.666)
     assert max(float(l.abs().max()) for l in lso) > 2.5 and float(ao.abs().max()) > 50.0          # the stress is real
     rows = {}
