@@ -197,6 +197,29 @@ def test_forward_ragged_vs_golden(model, golden_dir):
     assert float(out[0][3, :, 25:].abs().max()) == 0.0 and float(out[2][3, 25:].min()) == 1e3
 
 
+def test_eval_forward_batch12_split_decoder_cells_vs_oracle(model):
+    """No-grad teacher-forced forward at 9+ items: the decoder cells run on the library's helper stream a chunk of steps behind the
+    attention chain (t2s_taco_decode_steps with att_h_all + hc_all, as in training) - against the oracle, ragged lengths."""
+    from oracle import tacotron_oracle as O
+    gen = torch.Generator().manual_seed(61)
+    B, T_in, T_out = 12, 30, 41
+    in_len = torch.tensor([T_in - i for i in range(B)])
+    out_len = torch.tensor([T_out - 2 * i for i in range(B)])
+    text = torch.randint(2, 80, (B, T_in), generator=gen)
+    mel = torch.randn(B, 80, T_out, generator=gen)
+    for b in range(B):
+        text[b, in_len[b]:] = 0
+        mel[b, :, out_len[b]:] = 0
+    pm = (torch.rand(T_out + 1, B, 2, 256, generator=gen) < 0.5).to(torch.uint8)
+    out = model((text.to(DEV), in_len.to(DEV), mel.to(DEV), int(in_len.max()), torch.zeros(B, device=DEV), out_len.to(DEV)),
+                prenet_masks=pm)
+    with torch.no_grad():
+        want = O.tacotron_forward(synth.tacotron_state(), HP, text, in_len, mel, out_len, {"prenet": pm.float()})
+    for name, a, b in zip(("mel", "mel_post", "gate", "align"), out, want):
+        assert tuple(a.shape) == tuple(b.shape), name
+        assert _rel(a, b) < 1e-3, (name, _rel(a, b))
+
+
 def test_stop_condition_and_device_masks(model):
     """gate threshold stop (tacotron.py:455): with random weights sigmoid(gate) crosses 0.5 early; the
     result must be a prefix of the forced-length run with the same masks."""

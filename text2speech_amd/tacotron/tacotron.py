@@ -834,6 +834,11 @@ class _TacoEngine:
                          dec_gates_all=zf("dec_gates_all", T_out, B, 4 * D), dec_c_all=zf("dec_c_all", T_out, B, D),
                          att_h_all=zf("att_h_all", T_out, B, A_), q_all=zf("q_all", T_out, B, ad_),
                          wcum_all=zf("wcum_all", T_out, B, T_in_))
+        elif B > 8:
+            # no-grad teacher-forced forward at 9+ items: with a copy of every step's h_att at hand the library takes the decoder cells
+            # off the serial chain (helper stream, a chunk of steps behind the attention chain: t2s_taco_decode_steps) exactly as in
+            # training - the only save that path needs besides hc_all
+            extra["att_h_all"] = torch.empty(T_out, B, dec.attention_rnn_dim, dtype=torch.float32, device=dev)
         d, S = self._decoder_struct(memory, len32, T_out, True, extra)
         if m.training:
             d.att_drop_scale = 1.0 / (1.0 - dec.p_attention_dropout)
