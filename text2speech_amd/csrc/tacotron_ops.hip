@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a, c
     float* s_kb = s_ep + 8 * Tp;
     const int lr = lane & 15, lq = lane >> 4;
     // ---- every independent global load first, in one batch (fixed trip counts, clamped addresses) ----
-    float pm[2][4];
+    float pm[4][4];
     {
         const int nK = F * K2;
         float rk[4], rd[4], rc[2];
@@ -1159,9 +1159,11 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a, c
             if (!in) rc[j] = 0.f;
         }
         const float vv = tid < AD ? a.w_v[tid] : 0.f;
-        // processed memory of this wave's first two stage-2 tiles (tile id = wave, wave + 16: t-tile id >> 3, a-tile id & 7)
+        // processed memory of this wave's first four stage-2 tiles (tile id = wave + 16 i: t-tile id >> 3, a-tile id & 7): every tile
+        // up to T = 128 (two were prefetched before: at 128 encoder positions the third and fourth tile loaded inside the loop, two
+        // exposed memory round trips on the launch's critical workgroup)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int id = wave + 16 * i, tt = id >> 3, at = id & 7;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1278,9 +1280,9 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a, c
         for (int id = wave; id < n_tiles; id += 16, ++it) {
             const int tt = id >> 3, at = id & 7;
             float pmv[4];
-            if (it < 2) {
+            if (it < 4) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pmv[r] = it == 0 ? pm[0][r] : pm[1][r];
+                for (int r = 0; r < 4; ++r) pmv[r] = it == 0 ? pm[0][r] : it == 1 ? pm[1][r] : it == 2 ? pm[2][r] : pm[3][r];
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1373,6 +1375,13 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a, c
         if (4 * cq < a.enc_dim) {
             const float* mem = a.memory + (size_t)b * T * a.enc_dim + 4 * cq;
             int t = tb;
+            for (; t + 16 <= te; t += 16) {                     // sixteen float4 loads in flight per thread (T = 128: one round trip)
+                f32x4 mv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) mv[u] = *(const f32x4*)(mem + (size_t)(t + u) * a.enc_dim);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += mv[u] * s_e[t + u];
+            }
             for (; t + 8 <= te; t += 8) {                       // eight float4 loads in flight per thread, no duplicates
                 f32x4 mv[8];
 #pragma unroll
