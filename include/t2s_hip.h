@@ -380,14 +380,14 @@ int t2s_wg_skip_sum(const void* A_hi, const void* A_lo, const float* bias, const
 int t2s_wg_bwd_gate_dgrad(const void* A_hi, const void* A_lo, const float* zero_bias, const void* DX_hi,
                           const void* DX_lo, const void* DS_hi, const void* DS_lo, const void* acts_hi, const void* acts_lo,
                           const void* G_hi, const void* G_lo, int tg_bchunks, void* DP_hi, void* DP_lo, int dp_bchunks, int B, int C,
-                          int L, int Lp, int halo, int Mpad, void* stream);
+                          int L, int Lp, int halo, int Mpad, int pair8, void* stream);
 
 /* O (+)= conv(X) with packed (transposed) weights: data gradients of in_layers[i] (dilated, taps mirrored) and
  * cond_layers[i].  init=1 stores, init=0 accumulates into the O planes.  x_bchunks: chunks between batch entries of the X
  * planes (0 = Cin/32; X may be a slice of a wider plane set, see t2s_wg_bwd_gate_dgrad). */
 int t2s_conv_accumulate(const void* A_hi, const void* A_lo, const float* zero_bias, const void* X_hi, const void* X_lo,
                         int x_bchunks, void* O_hi, void* O_lo, int B, int Cin, int Cout, int taps, int dilation, int init, int L, int Lp,
-                        int halo, int Mpad, void* stream);
+                        int halo, int Mpad, int pair8, void* stream);
 
 /* out[b*ksplit + s][m][n] = sum over time chunks [k0,k1) (split s of ksplit) of A_tm[b][t][m] * X_tm[b][t][n]:
  * B*ksplit split-K slabs; chunks outside [k0,k1) (the zero halo) are skipped */
@@ -428,7 +428,14 @@ int t2s_plane_transpose(const void* src_hi, const void* src_lo, int B, int src_c
 int t2s_tm_ones_row(void* dst_hi, void* dst_lo, int B, int Lp, int halo, int L, int Npad, int n_row, void* stream);
 /* A[c][koff + tap'*O_pad + o] = scale[o] * v[o][c][flip ? Kt-1-tap' : tap'] -> (hi, lo) [k/32][Mpad][32] */
 int t2s_pack_transposed(const float* v, const float* scale, int O, int Cin, int Kt, int flip, int O_pad, int Mpad,
-                        int koff, void* A_hi, void* A_lo, void* stream);
+                        int koff, void* A_hi, void* A_lo, int pair8, void* stream);
+/* ABI v4: pair8 (t2s_pack_transposed, t2s_wg_bwd_gate_dgrad, t2s_conv_accumulate).  pair8 = 1 packs the M rows of the transposed
+ * operand in PERM_PAIR8 order (within every 32 rows, packed row 16 m + 4 q + e = row 8 q + 4 m + e) and tells the two backward GEMMs
+ * that their A operand is packed so: their epilogues then move whole 16-byte pieces per plane (8 consecutive channels per lane)
+ * instead of 8-byte ones.  Only the 256-row ping-pong kernels have that epilogue: ask t2s_wg_bwd_pair8_ok(B, rows, L) (rows = Cout of
+ * t2s_conv_accumulate / C of t2s_wg_bwd_gate_dgrad) before packing; a GEMM call with pair8 = 1 on a shape that takes the 128-row
+ * kernels returns T2S_EINVAL.  T2S_BWD_PAIR8=0: t2s_wg_bwd_pair8_ok answers 0. */
+int t2s_wg_bwd_pair8_ok(int B, int rows, int L);
 /* per-row scale g/|v| of a weight-normed conv (what the forward pack applied), for t2s_pack_transposed */
 int t2s_weightnorm_scale(const float* v, const float* g, int O, int K, float* scale, void* stream);
 /* reduce split-K slabs P[nsplit][Prows][Pcols] and apply weight_norm's backward (g NULL: plain weight); the bias gradient is

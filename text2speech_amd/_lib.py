@@ -65,6 +65,7 @@ SIGNATURES = {
     "t2s_embedding_grad": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp],
     "t2s_bn_running_update": [c_vp, c_vp, c_vp, c_vp, c_vp, c_float, ctypes.c_longlong, c_int, c_vp],
     "t2s_zero_fill": [c_vp, ctypes.c_size_t, c_vp],
+    "t2s_wg_bwd_pair8_ok": [c_int, c_int, c_int],
     "t2s_taco_attention": [c_vp] * 14 + [c_int] * 7 + [c_vp],
     "t2s_bernoulli_mask": [c_vp, ctypes.c_size_t, ctypes.c_ulonglong, ctypes.c_ulonglong, c_float, c_vp],
     "t2s_taco_decode_steps": [c_vp, c_int, c_int, c_vp],
@@ -89,17 +90,17 @@ SIGNATURES = {
     "t2s_planes_to_f32": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp],
     "t2s_wg_in_cond_gate_train": [c_vp] * 13 + [c_int] * 9 + [c_vp],
     "t2s_wg_res_skip_train": [c_vp] * 10 + [c_int] * 8 + [c_vp],
-    "t2s_wg_bwd_gate_dgrad": [c_vp] * 11 + [c_int] + [c_vp] * 2 + [c_int] * 7 + [c_vp],
+    "t2s_wg_bwd_gate_dgrad": [c_vp] * 11 + [c_int] + [c_vp] * 2 + [c_int] * 8 + [c_vp],
     "t2s_wg_in_cond_gate_fold_train": [c_vp] * 11 + [c_int] + [c_vp] * 2 + [c_int] * 10 + [c_vp],
     "t2s_wg_res_only_train": [c_vp] * 5 + [c_int] + [c_vp] * 4 + [c_int] * 7 + [c_vp],
     "t2s_wg_skip_sum": [c_vp] * 5 + [c_int] * 2 + [c_vp] + [c_int] * 6 + [c_vp],
-    "t2s_conv_accumulate": [c_vp] * 5 + [c_int] + [c_vp] * 2 + [c_int] * 10 + [c_vp],
+    "t2s_conv_accumulate": [c_vp] * 5 + [c_int] + [c_vp] * 2 + [c_int] * 11 + [c_vp],
     "t2s_wgrad_gemm": [c_vp] * 6 + [c_int] * 9 + [c_vp],
     "t2s_wgrad_gemm_flat": [c_vp] * 6 + [c_int] * 9 + [c_vp],
     "t2s_wgrad_cl": [c_vp, c_int, c_vp, c_int, c_vp] + [c_int] * 8 + [c_vp],
     "t2s_plane_transpose": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_vp],
     "t2s_tm_ones_row": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
-    "t2s_pack_transposed": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
+    "t2s_pack_transposed": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp],
     "t2s_weightnorm_scale": [c_vp, c_vp, c_int, c_int, c_vp, c_vp],
     "t2s_wn_backward": [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp,
                         c_vp, c_int, c_vp],

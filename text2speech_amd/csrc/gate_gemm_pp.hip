@@ -550,6 +550,49 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
         }
     }
   } else if constexpr (EPI == EPI_RESSKIP) {
+    typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+    if (a.pair8) {
+      // Rows packed with PERM_PAIR8 (t2s_pack_transposed(pair8 = 1)): the two m-tiles (m0, m0 + 1) of a 32-row group give this lane the 8
+      // CONSECUTIVE channels 8 q .. 8 q + 7 of one time step - one 16-byte read-modify-write per plane where the identity order
+      // needs two 8-byte ones (a quarter of a 128-byte line per request; the backward GEMMs sit at the L2's request limit in
+      // their epilogue just as the forward's residual GEMM did, DESIGN.md section 5 "whole 16-byte pieces").
+#pragma unroll
+      for (int m0 = 0; m0 < 8; m0 += 2) {
+        const int grp = mt * 256 + (m0 >> 2) * 128 + wr * 64 + (m0 & 3) * 16;      // first packed row of the 32-row group
+        const bool rok = grp < a.n_res;                                            // (n_res % 32 == 0: whole groups)
+        const int chc = rok ? grp + 2 * rq : 0;                                    // channel 8 q of the group
+        const f32x4 b0 = *(const f32x4*)(a.bias + chc), b1 = *(const f32x4*)(a.bias + chc + 4);
+        const size_t ob = ((size_t)(chc >> 5) * a.Lp + a.halo) * 32 + (chc & 31);
+        u16x8_t oh[4], ol[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            oh[n] = (u16x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+            ol[n] = oh[n];
+            if (rok && cok[n] && !a.res_init) {
+                const size_t o = ob + ((size_t)cb[n] * a.oc * a.Lp + (size_t)ct[n]) * 32;
+                oh[n] = *(const u16x8_t*)((a.R_hi ? a.R_hi : a.O_hi) + o);
+                ol[n] = *(const u16x8_t*)((a.R_lo ? a.R_lo : a.O_lo) + o);
+            }
+        }
+        if (!rok) continue;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            if (!cok[n]) continue;
+            u16x8_t hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float add = e < 4 ? acc[m0][n][e & 3] + b0[e & 3] : acc[m0 + 1][n][e & 3] + b1[e & 3];
+                u16 h, l;
+                split_bf16(join_bf16(oh[n][e], ol[n][e]) + add, h, l);
+                hi[e] = h;
+                lo[e] = l;
+            }
+            const size_t o = ob + ((size_t)cb[n] * a.oc * a.Lp + (size_t)ct[n]) * 32;
+            *(u16x8_t*)(a.O_hi + o) = hi;
+            *(u16x8_t*)(a.O_lo + o) = lo;
+        }
+      }
+    } else {
     // O (+)= acc (+ bias): rows = output channels in identity order, a lane holds channels prow .. prow+3 of one time step.
     // The old values of two m-tiles (8 pieces of 8 bytes per plane) are requested together before any of them is consumed.
 #pragma unroll
@@ -597,10 +640,58 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
             }
         }
     }
+    }
   } else {
     // EPI_GATE_BWD (csrc/conv_gemm.hip has the derivation): acc = d_acts[c][t]; with the saved a = tanh * sigmoid and g = sigmoid,
     // t = a / g:  d_pre[c] = d_acts g (1 - t^2),  d_pre[C + c] = d_acts a (1 - g).  T_hi / T_lo hold a, G_hi / G_lo hold g (tc =
     // their batch stride in chunks), O planes take 2C channels (oc = their batch stride).
+    typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+    if (a.pair8) {
+      // PERM_PAIR8 rows (see EPI_RESSKIP above): 8 consecutive acts channels per lane and time step - the saved a / g planes are
+      // read and both halves of d_pre written in 16-byte pieces
+#pragma unroll
+      for (int m0 = 0; m0 < 8; m0 += 2) {
+        const int grp = mt * 256 + (m0 >> 2) * 128 + wr * 64 + (m0 & 3) * 16;
+        const bool rok = grp < a.C;
+        const int ch = rok ? grp + 2 * rq : 0, ch2 = ch + a.C;
+        const size_t tgb = ((size_t)(ch >> 5) * a.Lp + a.halo) * 32 + (ch & 31);
+        u16x8_t th[4], tl[4], gh[4], gl[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const size_t o = tgb + ((size_t)(cok[n] ? cb[n] : 0) * a.tc * a.Lp + (size_t)(cok[n] ? ct[n] : 0)) * 32;
+            th[n] = *(const u16x8_t*)(a.T_hi + o);
+            tl[n] = *(const u16x8_t*)(a.T_lo + o);
+            gh[n] = *(const u16x8_t*)(a.G_hi + o);
+            gl[n] = *(const u16x8_t*)(a.G_lo + o);
+        }
+        if (!rok) continue;
+        const size_t o1b = ((size_t)(ch >> 5) * a.Lp + a.halo) * 32 + (ch & 31);
+        const size_t o2b = ((size_t)(ch2 >> 5) * a.Lp + a.halo) * 32 + (ch2 & 31);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            if (!cok[n]) continue;
+            u16x8_t h1, l1, h2, l2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float av = join_bf16(th[n][e], tl[n][e]), gv = join_bf16(gh[n][e], gl[n][e]);
+                const float tv = gv != 0.0f ? av / gv : 0.0f;
+                const float da = e < 4 ? acc[m0][n][e & 3] : acc[m0 + 1][n][e & 3];
+                u16 h, l;
+                split_bf16(da * gv * (1.0f - tv * tv), h, l);
+                h1[e] = h;
+                l1[e] = l;
+                split_bf16(da * av * (1.0f - gv), h, l);
+                h2[e] = h;
+                l2[e] = l;
+            }
+            const size_t bo = ((size_t)cb[n] * a.oc * a.Lp + (size_t)ct[n]) * 32;
+            *(u16x8_t*)(a.O_hi + o1b + bo) = h1;
+            *(u16x8_t*)(a.O_lo + o1b + bo) = l1;
+            *(u16x8_t*)(a.O_hi + o2b + bo) = h2;
+            *(u16x8_t*)(a.O_lo + o2b + bo) = l2;
+        }
+      }
+    } else {
 #pragma unroll
     for (int m0 = 0; m0 < 8; m0 += 2) {
         u16x4 th[2][4], tl[2][4], gh[2][4], gl[2][4];
@@ -652,6 +743,7 @@ __global__ __launch_bounds__(512) void gate_gemm_pp_kernel(const ConvGemmArgs a)
                 pp_store8(a.O_lo + o2b + bo, l2);
             }
         }
+    }
     }
   }
 #ifdef T2S_GEMM_STAMPS

@@ -28,6 +28,15 @@ static bool bwd_pp256(const ConvGemmArgs& a, int rows) {
 
 static int planes_ok(const void* a, const void* b) { return a && b && al16(a) && al16(b); }
 
+// Can the backward GEMM with `rows` output rows over B x L columns take PERM_PAIR8-packed operands (16-byte epilogue pieces)?  Only
+// the 256-row ping-pong kernels have that epilogue: the grid rule of bwd_pp256 above, whole 32-row groups.  T2S_BWD_PAIR8=0: never.
+extern "C" int t2s_wg_bwd_pair8_ok(int B, int rows, int L) {
+    static const int on = getenv("T2S_BWD_PAIR8") ? atoi(getenv("T2S_BWD_PAIR8")) : 1;
+    static const int pp = getenv("T2S_BWD_PP256") ? atoi(getenv("T2S_BWD_PP256")) : 1;
+    if (!on || !pp || B <= 0 || rows <= 0 || L <= 0 || rows % 32) return 0;
+    return (long)cdiv(rows, 256) * cdiv(L, 256) * B >= 100 ? 1 : 0;
+}
+
 // rows [row0, row0+1) scale kernel lives in waveglow_ops.hip's weightnorm_small (scale-only form below)
 __global__ void weightnorm_scale_kernel(const float* v, const float* g, int O, int K, float* scale) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
@@ -171,7 +180,7 @@ int t2s_wg_res_skip_train(const void* A_hi, const void* A_lo, const float* bias,
 int t2s_wg_bwd_gate_dgrad(const void* A_hi, const void* A_lo, const float* zero_bias, const void* DX_hi,
                           const void* DX_lo, const void* DS_hi, const void* DS_lo, const void* T_hi, const void* T_lo,
                           const void* G_hi, const void* G_lo, int tg_bchunks, void* DP_hi, void* DP_lo, int dp_bchunks, int B, int C,
-                          int L, int Lp, int halo, int Mpad, void* stream) {
+                          int L, int Lp, int halo, int Mpad, int pair8, void* stream) {
     if (!planes_ok(A_hi, A_lo) || !planes_ok(DS_hi, DS_lo) || !planes_ok(T_hi, T_lo) || !planes_ok(G_hi, G_lo) ||
         !planes_ok(DP_hi, DP_lo) || !zero_bias)
         return T2S_EINVAL;
@@ -196,11 +205,13 @@ int t2s_wg_bwd_gate_dgrad(const void* A_hi, const void* A_lo, const float* zero_
     a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
     a.n_ttiles = cdiv(L, 256);
     a.C = C;
+    a.pair8 = pair8 ? 1 : 0;
     if (bwd_pp256(a, C)) {
         a.n_mtiles = cdiv(C, 256);
         T2S_CHECK_HIP(t2s_launch_bwd_gemm_pp(a, EPI_GATE_BWD, (hipStream_t)stream));
         return T2S_OK;
     }
+    if (pair8) return T2S_EINVAL;        // PERM_PAIR8 operands need the 256-row ping-pong kernel (t2s_wg_bwd_pair8_ok)
     // 128-row tiles when 256-row tiles would leave half the CUs without a workgroup (C = 512: 2 x 64 tiles)
     const int mt_rows = cdiv(C, 256) * a.n_ttiles * B < 200 ? 128 : 256;
     a.n_mtiles = cdiv(C, mt_rows);
@@ -210,7 +221,7 @@ int t2s_wg_bwd_gate_dgrad(const void* A_hi, const void* A_lo, const float* zero_
 
 int t2s_conv_accumulate(const void* A_hi, const void* A_lo, const float* zero_bias, const void* X_hi, const void* X_lo,
                         int x_bchunks, void* O_hi, void* O_lo, int B, int Cin, int Cout, int taps, int dilation, int init, int L, int Lp,
-                        int halo, int Mpad, void* stream) {
+                        int halo, int Mpad, int pair8, void* stream) {
     if (!planes_ok(A_hi, A_lo) || !planes_ok(X_hi, X_lo) || !planes_ok(O_hi, O_lo) || !zero_bias) return T2S_EINVAL;
     if (B <= 0 || L <= 0 || Cin <= 0 || Cout <= 0 || Cout % 4 || taps <= 0 || !(taps & 1) || dilation <= 0) return T2S_EINVAL;
     if ((taps / 2) * dilation > halo || Lp != t2s_plane_rows(L, halo) || Mpad % 256 || Mpad < Cout) return T2S_EINVAL;
@@ -225,11 +236,14 @@ int t2s_conv_accumulate(const void* A_hi, const void* A_lo, const float* zero_bi
     a.Mpad = Mpad; a.Lp = Lp; a.halo = halo; a.L = L; a.B = B;
     a.n_ttiles = cdiv(L, 256);
     a.C = 0; a.n_res = Cout; a.res_init = init;      // every row takes the residual branch
+    if (pair8 && Cout % 32) return T2S_EINVAL;
+    a.pair8 = pair8 ? 1 : 0;
     if (bwd_pp256(a, Cout)) {
         a.n_mtiles = cdiv(Cout, 256);
         T2S_CHECK_HIP(t2s_launch_bwd_gemm_pp(a, EPI_RESSKIP, (hipStream_t)stream));
         return T2S_OK;
     }
+    if (pair8) return T2S_EINVAL;        // PERM_PAIR8 operands need the 256-row ping-pong kernel (t2s_wg_bwd_pair8_ok)
     // 128-row tiles when 256-row tiles would leave most CUs without a workgroup
     const int mt_rows = (cdiv(Cout, 256) * a.n_ttiles * B <= 128 || Cout % 256 == 0) && cdiv(Cout, 256) * a.n_ttiles * B < 200 ? 128 : 256;
     a.n_mtiles = cdiv(Cout, mt_rows);
@@ -316,11 +330,11 @@ int t2s_tm_ones_row(void* dst_hi, void* dst_lo, int B, int Lp, int halo, int L, 
 }
 
 int t2s_pack_transposed(const float* v, const float* scale, int O, int Cin, int Kt, int flip, int O_pad, int Mpad,
-                        int koff, void* A_hi, void* A_lo, void* stream) {
+                        int koff, void* A_hi, void* A_lo, int pair8, void* stream) {
     if (!v || !planes_ok(A_hi, A_lo) || O <= 0 || Cin <= 0 || Kt <= 0 || O_pad % 32 || O_pad < O || Mpad % 256 ||
-        Mpad < Cin || koff % 32)
+        Mpad < Cin || koff % 32 || (pair8 && Cin % 32))
         return T2S_EINVAL;
-    T2S_CHECK_HIP(t2s_launch_pack_transposed(v, scale, O, Cin, Kt, flip, O_pad, Mpad, koff, (u16*)A_hi, (u16*)A_lo,
+    T2S_CHECK_HIP(t2s_launch_pack_transposed(v, scale, O, Cin, Kt, flip, O_pad, Mpad, koff, (u16*)A_hi, (u16*)A_lo, pair8 ? 1 : 0,
                                              (hipStream_t)stream));
     return T2S_OK;
 }

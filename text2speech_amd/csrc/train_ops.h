@@ -39,7 +39,7 @@ hipError_t t2s_launch_plane_transpose(const u16* src_hi, const u16* src_lo, int 
 hipError_t t2s_launch_tm_ones_row(u16* dst_hi, u16* dst_lo, int B, int Lp, int halo, int L, int Npad, int n_row,
                                   hipStream_t stream);
 hipError_t t2s_launch_pack_transposed(const float* v, const float* scale, int O, int Cin, int Kt, int flip, int O_pad,
-                                      int Mpad, int koff, u16* A_hi, u16* A_lo, hipStream_t stream);
+                                      int Mpad, int koff, u16* A_hi, u16* A_lo, int pair8, hipStream_t stream);
 hipError_t t2s_launch_wn_backward(const WnBwdArgs& a, hipStream_t stream);
 hipError_t t2s_launch_affine_backward(float* z, float* dz, const float* wn_out, const float* g_ls, int g_ls_scalar, float* d_out,
                                       int B, int G, int c_off, int nh, int L, hipStream_t stream);

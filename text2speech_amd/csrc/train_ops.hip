@@ -68,9 +68,11 @@ hipError_t t2s_launch_tm_ones_row(u16* dst_hi, u16* dst_lo, int B, int Lp, int h
 // ------------------------------------------------------------------------------------------------
 // Data-gradient weights: A[c][koff + tap' * O_pad + o] = scale[o] * v[o][c][flip ? Kt-1-tap' : tap']
 // (the transpose of a conv weight, taps mirrored), split to (hi, lo) planes [k/32][Mpad][32].
+// pair8: the M rows (= input channels c of the convolution, output channels of the transposed one) in PERM_PAIR8 order - within
+// every 32 channels, packed row 16 m + 4 q + e holds channel 8 q + 4 m + e - for the 16-byte epilogues of the backward GEMMs.
 __global__ __launch_bounds__(256) void pack_transposed_kernel(const float* __restrict__ v, const float* __restrict__ scale,
                                                               int O, int Cin, int Kt, int flip, int O_pad, int Mpad,
-                                                              int koff, u16* A_hi, u16* A_lo) {
+                                                              int koff, u16* A_hi, u16* A_lo, int pair8) {
     __shared__ float tile[32][33];
     const int o0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tid = threadIdx.x;
@@ -100,7 +102,9 @@ __global__ __launch_bounds__(256) void pack_transposed_kernel(const float* __res
                     vl[e] = l;
                 }
                 const int k = koff + tp * O_pad + o0 + oq * 4;
-                const size_t idx = ((size_t)(k >> 5) * Mpad + c) * 32 + (k & 31);
+                const int w = c & 31;
+                const int crow = pair8 ? (c & ~31) + ((w >> 2) & 1) * 16 + (w >> 3) * 4 + (w & 3) : c;
+                const size_t idx = ((size_t)(k >> 5) * Mpad + crow) * 32 + (k & 31);
                 *(u16x4*)(A_hi + idx) = vh;
                 *(u16x4*)(A_lo + idx) = vl;
             }
@@ -109,9 +113,9 @@ __global__ __launch_bounds__(256) void pack_transposed_kernel(const float* __res
     }
 }
 hipError_t t2s_launch_pack_transposed(const float* v, const float* scale, int O, int Cin, int Kt, int flip, int O_pad,
-                                      int Mpad, int koff, u16* A_hi, u16* A_lo, hipStream_t stream) {
+                                      int Mpad, int koff, u16* A_hi, u16* A_lo, int pair8, hipStream_t stream) {
     hipLaunchKernelGGL(pack_transposed_kernel, dim3((O_pad + 31) / 32, (Cin + 31) / 32), dim3(256), 0, stream, v, scale, O,
-                       Cin, Kt, flip, O_pad, Mpad, koff, A_hi, A_lo);
+                       Cin, Kt, flip, O_pad, Mpad, koff, A_hi, A_lo, pair8);
     return hipGetLastError();
 }
 

@@ -128,6 +128,10 @@ def _alloc_train(eng, B, L, dev):
     st.P1b = torch.empty_like(st.P1)        # second slab set: the res/skip weight gradient on the data-gradient stream (backward_train)
     st.Mc = _lib.padded_rows(C)
     st.Ms = _lib.padded_rows(g["n_cond"])
+    # PERM_PAIR8 row order for the backward's transposed operands (16-byte epilogue pieces) where the consuming GEMM runs on 256-row
+    # ping-pong tiles: rows = C for W_rs^T / W_in^T, n_cond for W_cond^T
+    st.p8_x = int(_lib.load().t2s_wg_bwd_pair8_ok(B, C, L))
+    st.p8_c = int(_lib.load().t2s_wg_bwd_pair8_ok(B, g["n_cond"], L))
     # Transposed weight operands of the backward's data-gradient GEMMs, one set per (flow, layer) (0.8 GB at config.json
     # defaults): they depend on the weights only, so the forward produces them on its pack stream, under its own GEMMs, and the
     # backward's dependent chain has three small launches per layer less.
@@ -288,12 +292,14 @@ def forward_train(eng, mel, audio):
                 v_in = _f32c(_vg(wn_k.in_layers[i])[0])
                 v_c = _f32c(_vg(wn_k.cond_layers[i])[0])
                 keep.extend([v_rs, v_in, v_c])
+                # (PERM_PAIR8 row order where the backward GEMM that consumes the operand runs on 256-row ping-pong tiles: 16-byte
+                # epilogue pieces, t2s_wg_bwd_pair8_ok; the flags are kept in ts for the calls of the backward)
                 _lib.call("t2s_pack_transposed", _ptr(v_rs), _ptr(pk["s_rs"]), rows2, C, 1, 0, rows2, ts.Mc, 0,
-                          _ptr(ts.A_rsT[k][i][0]), _ptr(ts.A_rsT[k][i][1]), stp)
+                          _ptr(ts.A_rsT[k][i][0]), _ptr(ts.A_rsT[k][i][1]), ts.p8_x, stp)
                 _lib.call("t2s_pack_transposed", _ptr(v_in), _ptr(pk["s_in"]), 2 * C, C, ks, 1, 2 * C, ts.Mc, 0,
-                          _ptr(ts.A_inT[k][i][0]), _ptr(ts.A_inT[k][i][1]), stp)
+                          _ptr(ts.A_inT[k][i][0]), _ptr(ts.A_inT[k][i][1]), ts.p8_x, stp)
                 _lib.call("t2s_pack_transposed", _ptr(v_c), _ptr(pk["s_cond"]), 2 * C, g["n_cond"], 1, 0, 2 * C, ts.Ms, i * 2 * C,
-                          _ptr(ts.A_cT[k][0]), _ptr(ts.A_cT[k][1]), stp)
+                          _ptr(ts.A_cT[k][0]), _ptr(ts.A_cT[k][1]), ts.p8_c, stp)
         log_s = torch.empty(B, n_half, L, dtype=torch.float32, device=dev)
         ts.wn_out[k] = torch.empty(B, 2 * n_half, L, dtype=torch.float32, device=dev)
         if ts.fold_train:
@@ -495,7 +501,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             g_h, g_l = _act_ptrs(ts, k, i, "G")
             _lib.call("t2s_wg_bwd_gate_dgrad", _ptr(A_rsT[0]), _ptr(A_rsT[1]), _ptr(zb),
                       None if last else _ptr(ts.DX[0]), None if last else _ptr(ts.DX[1]), _ptr(DS[0]), _ptr(DS[1]),
-                      a_h, a_l, g_h, g_l, ts.act_bchunks, dp_h, dp_l, ts.dp_chunks, B, C, L, Lp, halo, ts.Mc, st)
+                      a_h, a_l, g_h, g_l, ts.act_bchunks, dp_h, dp_l, ts.dp_chunks, B, C, L, Lp, halo, ts.Mc, ts.p8_x, st)
             ev_dp = None
             if not few_ev:
                 ev_dp = torch.cuda.Event()
@@ -567,20 +573,20 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             if ev_tdrs is not None:
                 main_s.wait_event(ev_tdrs)  # (events of one stream complete in order: this covers every earlier read of DX too)
             _lib.call("t2s_conv_accumulate", _ptr(A_inT[0]), _ptr(A_inT[1]), _ptr(zb), dp_h, dp_l, ts.dp_chunks,
-                      _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, 2 * C, C, ks, d, 1 if last else 0, L, Lp, halo, ts.Mc, st)
+                      _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, 2 * C, C, ks, d, 1 if last else 0, L, Lp, halo, ts.Mc, ts.p8_x, st)
             # (W_cond,i^T sits in K-chunks [2 xc i, 2 xc (i + 1)) of the flow's conditioning-gradient operand A_cT)
             if per_layer_cond:          # A/B switch (T2S_WCOND_PER_LAYER=1): the round-2 form, one accumulate per layer
                 a_off = 2 * i * 2 * xc * ts.Ms * 32
                 _lib.call("t2s_conv_accumulate", _lib.c_vp(A_cT[0].data_ptr() + a_off), _lib.c_vp(A_cT[1].data_ptr() + a_off),
                           _ptr(zb), dp_h, dp_l, ts.dp_chunks, _ptr(ts.DSp[0]), _ptr(ts.DSp[1]), B, 2 * C, n_cond, 1, 1, dsp_init,
-                          L, Lp, halo, ts.Ms, st)
+                          L, Lp, halo, ts.Ms, ts.p8_c, st)
                 dsp_init = 0
         # d_spect (+)= [W_cond,0^T | ... | W_cond,nl-1^T] [d_pre_0 ; ... ; d_pre_nl-1]: one GEMM per flow, K = nl * 2C       [main]
         if not per_layer_cond:
             # (T2S_WG_WCOND_SIDE=1: on the weight-gradient stream - it feeds the upsampler's gradient only, not the chain; that
             # stream has waited for every d_pre of the flow by now, and it owns the d_pre planes' reuse through side_done)
             _lib.call("t2s_conv_accumulate", _ptr(ts.A_cT[k][0]), _ptr(ts.A_cT[k][1]), _ptr(zb), _ptr(DP[0]), _ptr(DP[1]), 0,
-                      _ptr(ts.DSp[0]), _ptr(ts.DSp[1]), B, nl * 2 * C, n_cond, 1, 1, dsp_init, L, Lp, halo, ts.Ms,
+                      _ptr(ts.DSp[0]), _ptr(ts.DSp[1]), B, nl * 2 * C, n_cond, 1, 1, dsp_init, L, Lp, halo, ts.Ms, ts.p8_c,
                       st2 if wcond_side else st)
             dsp_init = 0
         # ---- WN.start ----

@@ -250,10 +250,10 @@ class _Bwd:
             Opad = _ru(Cout, 32)
             Mi = _lib.padded_rows(Cin)
             At = (self.bf(Kt * Opad // 32, Mi, 32, tag=("cs_Ath", cs_)), self.bf(Kt * Opad // 32, Mi, 32, tag=("cs_Atl", cs_)))
-            _lib.call("t2s_pack_transposed", _p(w32), None, Cout, Cin, Kt, 1, Opad, Mi, 0, _p(At[0]), _p(At[1]), self.st)
+            _lib.call("t2s_pack_transposed", _p(w32), None, Cout, Cin, Kt, 1, Opad, Mi, 0, _p(At[0]), _p(At[1]), 0, self.st)
             d_in = (self.bf(B, icc, Lp, 32, tag=("cs_dih", cs_), extent=ex), self.bf(B, icc, Lp, 32, tag=("cs_dil", cs_), extent=ex))
             _lib.call("t2s_conv_accumulate", _p(At[0]), _p(At[1]), _p(self.zero_bias), _p(dconv[0]), _p(dconv[1]), 0, _p(d_in[0]),
-                      _p(d_in[1]), B, Cout, _ru(Cin, 4), Kt, 1, 1, T, Lp, halo, Mi, self.st)
+                      _p(d_in[1]), B, Cout, _ru(Cin, 4), Kt, 1, 1, T, Lp, halo, Mi, 0, self.st)
             self.keep += [w32, At, d_in]
             d_planes = d_in
         return d_planes

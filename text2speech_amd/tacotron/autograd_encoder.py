@@ -80,12 +80,12 @@ def encoder_backward(bw, d_memory):
     w_cat = P["lstm_in"]["keep"][0]                                  # [8H][Cin] (both directions)
     Mi = _lib.padded_rows(Cin)
     At = (bw.bf(M // 32, Mi, 32, tag="enc_Ath"), bw.bf(M // 32, Mi, 32, tag="enc_Atl"))
-    _lib.call("t2s_pack_transposed", _p(w_cat), None, M, Cin, 1, 0, M, Mi, 0, _p(At[0]), _p(At[1]), st)
+    _lib.call("t2s_pack_transposed", _p(w_cat), None, M, Cin, 1, 0, M, Mi, 0, _p(At[0]), _p(At[1]), 0, st)
     dgp = (bw.bf(B, M // 32, Lp, 32, tag="enc_dgph", extent=(T,)), bw.bf(B, M // 32, Lp, 32, tag="enc_dgpl", extent=(T,)))
     _lib.call("t2s_rows_to_planes", _p(dgx), B, T, M, Lp, halo, _p(dgp[0]), _p(dgp[1]), st)
     dx = (bw.bf(B, icc, Lp, 32, tag="enc_dxh", extent=(T,)), bw.bf(B, icc, Lp, 32, tag="enc_dxl", extent=(T,)))
     _lib.call("t2s_conv_accumulate", _p(At[0]), _p(At[1]), _p(bw.zero_bias), _p(dgp[0]), _p(dgp[1]), 0, _p(dx[0]), _p(dx[1]), B, M,
-              Cin, 1, 1, 1, T, Lp, halo, Mi, st)
+              Cin, 1, 1, 1, T, Lp, halo, Mi, 0, st)
     # ---- conv + BatchNorm stack, then the embedding ----
     d_emb_in = bw.conv_bn_stack_backward(sv["enc_convs"], dout_planes=dx, wgrad_side=os.environ.get("T2S_ENC_WGRAD_SIDE", "0") == "1")
     E = m.embedding.embedding_dim
