@@ -242,7 +242,11 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
             gs.W1 = d->dec_w_ih; gs.ld1 = A + E; gs.out1 = d->gate_part + GP;
             gs.W2 = d->att_w_hh; gs.ld2 = A; gs.out2 = d->gate_part + 2 * GP; gs.x12 = ah_out;
             gs.rows = 4 * A; gs.H = A; gs.B = B;
-            stream_gates = true;
+            // (the role must fit this device: one pass of 3-4 row units per wave over one workgroup per CU - else the plain chain)
+            AttArgs probe;
+            memset(&probe, 0, sizeof(probe));
+            probe.B = B; probe.T = T; probe.att_dim = d->att_dim; probe.loc_f = d->loc_filters;
+            stream_gates = t2s_att_fused_stream_ok(probe, gs);
         }
         if (stream_gates) { ca.h_in = nullptr; ca.pre_a = d->gate_part + 2 * GP; }
         // ... and with it the prenet's second layer folded into this launch (every workgroup recomputes the 256 outputs from

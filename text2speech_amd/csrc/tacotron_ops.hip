@@ -1410,9 +1410,25 @@ static bool att_fused_mfma_form(const AttArgs& a) {
     return a.loc_f == 32 && a.att_dim == 128 && !no_mfma;
 }
 
+// Workgroups of the gate-stream role for a launch with B attention workgroups on this device: one workgroup per CU, and the role's
+// ONE pass needs 3 or 4 row units per wave (3 * 16 * blocks <= n_units <= 4 * 16 * blocks).  0: this device has too few CUs - the
+// caller keeps the plain chain.
+static int gate_stream_blocks(int B, int n_units) {
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 16 ? n : 256;
+    }();
+    int blocks = n_cu - B;
+    if (3 * 16 * blocks > n_units) blocks = n_units / 48;      // more CUs than the pass has units for: leave the rest idle
+    if (blocks <= 0 || 4 * 16 * blocks < n_units) return 0;
+    return blocks;
+}
+
 // the gate-stream role rides on the matrix-core form of the fused attention launch only; three [4H][H] blocks, H = 1024
 bool t2s_att_fused_stream_ok(const AttArgs& a, const GateStreamArgs& g) {
     if (!att_fused_mfma_form(a) || a.B > 8 || a.T > ATT_FUSED_MAXT) return false;
+    if (gate_stream_blocks(a.B, 3 * g.rows) == 0) return false;
     if (g.H != 1024 || g.rows != 4 * g.H || g.B != a.B) return false;
     const void* ptrs[] = {g.W0, g.W1, g.W2, g.x0, g.x12, g.out0, g.out1, g.out2};
     for (const void* p : ptrs)
@@ -1435,20 +1451,15 @@ hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream, const Gate
             static std::atomic<unsigned long long> attr_mask3{0};
             const hipError_t e3 = t2s_raise_lds_limit((const void*)att_fused_mfma_kernel<true>, 120 * 1024, attr_mask3);
             if (e3 != hipSuccess) return e3;
-            static const int n_cu = [] {
-                int dev = 0, n = 256;
-                if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-                return n > 16 ? n : 256;
-            }();
+            const int blocks = gate_stream_blocks(a.B, 3 * gs->rows);
+            if (blocks == 0) return hipErrorInvalidValue;
             const size_t lds1 = lds > 84 * 1024 ? lds : 84 * 1024;      // more than half a CU's LDS: never two workgroups on one CU
-            const int n_waves = (n_cu - a.B) * 16, n_units = 3 * gs->rows;  // one pass: 3 or 4 units per wave (gate_stream_role)
-            if (n_cu <= a.B || 3 * n_waves > n_units || 4 * n_waves < n_units) return hipErrorInvalidValue;
             GateStreamArgs g2 = *gs;
 #ifdef T2S_ATTSTREAM_ABLATE
             static const int dbg = getenv("T2S_DBG_ATTSTREAM") ? atoi(getenv("T2S_DBG_ATTSTREAM")) : 0;
             g2.dbg = dbg;
 #endif
-            hipLaunchKernelGGL(att_fused_mfma_kernel<true>, dim3(n_cu), dim3(1024), lds1, stream, a, g2);
+            hipLaunchKernelGGL(att_fused_mfma_kernel<true>, dim3(a.B + blocks), dim3(1024), lds1, stream, a, g2);
             return hipGetLastError();
         }
         static std::atomic<unsigned long long> attr_mask2{0};
