@@ -305,6 +305,12 @@ typedef struct t2s_taco_decoder {
      * ~3/4 exact zeros after ReLU and dropout: one coalesced row of the transpose per nonzero) - instead of a GEMV launch of its own
      * on the serial chain.  NULL (or T2S_DECODE_FOLD_PRE2=0): the separate launch. */
     const float *w_pre2T;
+    /* ABI v4.  [B][T_in][att_dim] scratch, ZERO before step 0, or NULL.  With gate_part: the location term of the attention
+     * (location_dense o location_conv of the current weights / cumulative weights, tacotron.py:96-107) is computed one launch EARLIER,
+     * by extra workgroups of the projection launch of the previous step (which leaves ~170 CUs idle), and the fused attention launch
+     * only adds the query and the processed memory to it: the two exact-f32 matrix-core stages leave the one workgroup the whole
+     * launch waits for (4 us at 128 encoder positions, growing linearly with T_in).  State like gate_part. */
+    float *ploc;
 } t2s_taco_decoder;
 
 /* Enqueue decoder steps [step0, step0+n_steps) (Decoder.decode, tacotron.py:355-393, plus in autoregressive mode

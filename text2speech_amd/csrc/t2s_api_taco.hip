@@ -204,7 +204,7 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         float* dh_out = (s & 1) ? d->dec_h0 : d->dec_h1;
         GateStreamArgs gs;
         memset(&gs, 0, sizeof(gs));
-        bool stream_gates = false, fold_pre2 = false;
+        bool stream_gates = false, fold_pre2 = false, use_ploc = false;
         if (do_att) {
         // 1. attention LSTMCell on [prenet_out | context]
         LstmCellArgs ca;
@@ -274,6 +274,10 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         if (fused_att) {
             // small batch: one fused launch per step (one workgroup per batch element)
             if (stream_gates && !t2s_att_fused_stream_ok(aa, gs)) return T2S_EINVAL;
+            // the location term of this step came out of the previous step's projection launch (zero at step 0).  T2S_DECODE_PLOC=0: off
+            static const bool want_ploc = !(getenv("T2S_DECODE_PLOC") && atoi(getenv("T2S_DECODE_PLOC")) == 0);
+            use_ploc = stream_gates && want_ploc && d->ploc && d->att_dim == 128 && d->loc_filters == 32 && !aa.q_save && !aa.wcum_save;
+            if (use_ploc) aa.ploc = d->ploc;
             T2S_CHECK_HIP(t2s_launch_att_fused(aa, stream, stream_gates ? &gs : nullptr));
         } else {
             GemvArgs qa;
@@ -316,6 +320,16 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
             //       of the next step's prenet through the precomposed matrix W_pre0 . W_proj (always-on dropout,
             //       modules.py:21), so the mel frame needs no extra hop before the prenet.
             const bool more = s + 1 < d->mask_steps;
+            // the projection launch; with use_ploc it also carries the location term of the NEXT step's attention on the CUs the
+            // GEMV leaves idle (whatever form the launch takes: the next attention launch reads ploc)
+            auto launch_proj = [&](const GemvArgs& g) -> hipError_t {
+                if (!use_ploc) return t2s_launch_gemv(g, stream);
+                LocPreArgs lp;
+                memset(&lp, 0, sizeof(lp));
+                lp.w = d->att_w; lp.w_cum = d->att_wcum; lp.w_loc_conv = d->w_loc_conv; lp.w_loc_denseT = d->w_loc_denseT;
+                lp.ploc = d->ploc; lp.B = B; lp.T = T; lp.loc_ks = d->loc_kernel;
+                return t2s_launch_gemv_with_loc(g, lp, stream);
+            };
             const unsigned char* mk = d->prenet_masks + (size_t)(s + 1) * B * 2 * P;
             GemvArgs pa;
             memset(&pa, 0, sizeof(pa));
@@ -327,9 +341,9 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
                 pa.rows = d->n_mel + 1 + P; pa.split_row = d->n_mel + 1;
                 pa.y2 = d->pre1; pa.sy2_item = P; pa.sy2_row = 1; pa.act2 = ACT_RELU;
                 pa.mask2 = mk; pa.smask2_item = 2 * P; pa.mask2_scale = 2.0f;
-                T2S_CHECK_HIP(t2s_launch_gemv(pa, stream));
+                T2S_CHECK_HIP(launch_proj(pa));
             } else {
-                T2S_CHECK_HIP(t2s_launch_gemv(pa, stream));
+                T2S_CHECK_HIP(launch_proj(pa));
                 if (more) {
                     GemvArgs p1;
                     memset(&p1, 0, sizeof(p1));

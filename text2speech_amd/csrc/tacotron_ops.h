@@ -100,10 +100,26 @@ struct AttArgs {
     int n_part;
     float* q_out;              // large-batch form with q_part: the summed query [B][att_dim] is written here (by the first chunk's workgroup)
     float* q_save;             // optional [B][att_dim]: query of this step (training)
+    // B <= 8 autoregressive decode (ABI v4 t2s_taco_decoder::ploc): the location term P_loc[b][t][a] = (location_dense o location_conv)
+    // of the CURRENT (w, w_cum), computed one launch earlier beside the projection GEMV (LocPreArgs) - the fused attention
+    // launch then skips both matrix-core stages (the exact-f32 MFMAs of T x 128 x 94 MACs on ONE CU: 4 us at 128 encoder
+    // positions, growing linearly) and only adds q and the processed memory
+    const float* ploc;
     float* wcum_save;          // optional [B][T]: cumulative weights after this step (training)
 };
 
+// Role-specialised second half of the projection launch (B <= 8 autoregressive decode): while 85 workgroups run the 337 x 1536 GEMV,
+// T/16 x B more compute the location features of the NEXT step's attention from the weights this step's attention just wrote.
+struct LocPreArgs {
+    const float* w; const float* w_cum;       // [B][T] attention weights / cumulative weights after this step
+    const float* w_loc_conv;                  // [32][2][KS]
+    const float* w_loc_denseT;                // [32][128]
+    float* ploc;                              // [B][T][128]
+    int B, T, loc_ks;
+    int n_gemv_blocks;                        // blocks [0, n_gemv_blocks) of the launch run the GEMV
+};
 hipError_t t2s_launch_gemv(const GemvArgs& a, hipStream_t stream);
+hipError_t t2s_launch_gemv_with_loc(const GemvArgs& a, const LocPreArgs& lp, hipStream_t stream);
 // sbgemm.hip: the same two operators on the f32 matrix cores for 9+ items (picked inside t2s_launch_gemv / _lstm_cell)
 bool t2s_sbgemm_plain_ok(const GemvArgs& a);
 hipError_t t2s_launch_sbgemm_plain(const GemvArgs& a, hipStream_t stream);

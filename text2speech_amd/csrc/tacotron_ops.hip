@@ -111,7 +111,7 @@ extern "C" int t2s_debug_read_probe(unsigned long long* host_out, unsigned int* 
 #endif
 
 template <int NV4>
-__global__ __launch_bounds__(256) void gemv_rows_kernel(const GemvArgs a) {
+static __device__ __forceinline__ void gemv_rows_body(const GemvArgs& a) {
     PROBE_BEGIN(100 + NV4)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -156,12 +156,130 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const GemvArgs a) {
     PROBE_END()
 }
 
+template <int NV4>
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const GemvArgs a) {
+    gemv_rows_body<NV4>(a);
+}
+
+// Location term of the NEXT decoder step (LocPreArgs, tacotron_ops.h): P_loc[b][t][a] = sum_f D[a][f] * sum_{c,j} K[f][c][j] cat[c][t + j - pad]
+// (tacotron.py:96-107 location_conv + location_dense) for 16 positions of one batch element per workgroup, on the exact-f32 matrix
+// cores exactly as the fused attention kernel computes it (same operands, same MFMA order per output): 4 waves, stage 1 = two
+// 16 x 16 feature tiles on waves 0 / 1, stage 2 = eight 16 x 16 channel tiles, two per wave, D fragments straight from global.
+static __device__ __forceinline__ void loc_pre_role(const LocPreArgs& p, int rb) {
+    __shared__ float s_cat[2][16 + 64];
+    __shared__ float s_kb[64 * 48];
+    __shared__ float s_f[16 * 33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int T = p.T, KS = p.loc_ks, pad = KS >> 1, K2 = 2 * KS, KP = (K2 + 3) & ~3;
+    const int ntt = (T + 15) >> 4;
+    const int b = rb / ntt, t0 = 16 * (rb - b * ntt);
+    const int W = 16 + KS - 1;
+    constexpr int AD = 128, F = 32;
+    // every load first
+    float rk[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {                       // F * K2 <= 32 * 126 = 4032
+        const int i = tid + j * 256;
+        rk[j] = p.w_loc_conv[i < F * K2 ? i : 0];
+    }
+    float rc = 0.f;
+    {
+        const int c = tid >= W ? 1 : 0, j = tid - c * W;
+        const int t = t0 + j - pad;
+        const bool in = tid < 2 * W && t >= 0 && t < T;
+        rc = (c ? p.w_cum : p.w)[(size_t)b * T + (in ? t : 0)];
+        if (!in) rc = 0.f;
+    }
+    float bd[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bd[i][u] = p.w_loc_denseT[(4 * u + lq) * AD + 16 * (wave + 4 * i) + lr];   // B[k = f][col a] = D[a][f]
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = tid + j * 256;
+        if (i < F * K2) {
+            const int f = i / K2, k = i - f * K2;        // K[f][c][j] -> B operand [k = c * KS + j][f]
+            s_kb[k * 48 + f] = rk[j];
+        }
+    }
+    if (tid < (KP - K2) * F) s_kb[(K2 + tid / F) * 48 + (tid % F)] = 0.f;      // zero rows that pad K to a multiple of 4
+    if (tid < 2 * W) s_cat[tid >= W ? 1 : 0][tid >= W ? tid - W : tid] = rc;
+    __syncthreads();
+    if (wave < 2) {
+        const int ft = wave;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = 4 * u + lq;
+            const int kc = k < K2 ? k : 0;               // (B rows >= 2 KS are zero)
+            const int c = kc >= KS ? 1 : 0, j = kc - c * KS;
+            av[u] = s_cat[c][lr + j];
+            bv[u] = s_kb[(k < KP ? k : 0) * 48 + 16 * ft + lr];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (4 * u < KP) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_f[(4 * lq + r) * 33 + 16 * ft + lr] = acc[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int at = wave + 4 * i;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) av[u] = s_f[lr * 33 + 4 * u + lq];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bd[i][u], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = t0 + 4 * lq + r;
+            if (t < T) p.ploc[((size_t)b * T + t) * AD + 16 * at + lr] = acc[r];
+        }
+    }
+}
+
+template <int NV4>
+__global__ __launch_bounds__(256) void gemv_rows_loc_kernel(const GemvArgs a, const LocPreArgs lp) {
+    if ((int)blockIdx.x >= lp.n_gemv_blocks) {           // whole workgroups: no barrier of either role is skipped
+        loc_pre_role(lp, (int)blockIdx.x - lp.n_gemv_blocks);
+        return;
+    }
+    gemv_rows_body<NV4>(a);
+}
+
 hipError_t t2s_launch_gemv(const GemvArgs& a, hipStream_t stream) {
     if (t2s_sbgemm_plain_ok(a)) return t2s_launch_sbgemm_plain(a, stream);      // 9+ items: f32 matrix cores
     const int K = a.n1 + a.n2 + a.n3;
     const int nv4 = (K + 255) / 256;
     dim3 grid((a.rows + 3) / 4, a.items < 64 ? 1 : (a.items < 4096 ? 16 : 64));
 #define GL(N) hipLaunchKernelGGL(gemv_rows_kernel<N>, grid, dim3(256), 0, stream, a)
+    if (nv4 <= 1) GL(1);
+    else if (nv4 <= 2) GL(2);
+    else if (nv4 <= 4) GL(4);
+    else if (nv4 <= 7) GL(7);
+    else if (nv4 <= 10) GL(10);
+    else if (nv4 <= 16) GL(16);
+    else return hipErrorInvalidValue;
+#undef GL
+    return hipGetLastError();
+}
+
+// the same GEMV (wave-per-row form, few items) with the location-term role riding on the launch
+hipError_t t2s_launch_gemv_with_loc(const GemvArgs& a, const LocPreArgs& lp_in, hipStream_t stream) {
+    const int K = a.n1 + a.n2 + a.n3;
+    const int nv4 = (K + 255) / 256;
+    if (a.items >= 64 || !lp_in.ploc || !lp_in.w || !lp_in.w_cum || !lp_in.w_loc_conv || !lp_in.w_loc_denseT || lp_in.B <= 0 ||
+        lp_in.T <= 0 || lp_in.loc_ks > 63 || !(lp_in.loc_ks & 1))
+        return hipErrorInvalidValue;
+    LocPreArgs lp = lp_in;
+    lp.n_gemv_blocks = (a.rows + 3) / 4;
+    dim3 grid(lp.n_gemv_blocks + lp.B * ((lp.T + 15) / 16), 1);
+#define GL(N) hipLaunchKernelGGL(gemv_rows_loc_kernel<N>, grid, dim3(256), 0, stream, a, lp)
     if (nv4 <= 1) GL(1);
     else if (nv4 <= 2) GL(2);
     else if (nv4 <= 4) GL(4);
@@ -1106,7 +1224,8 @@ static __device__ __forceinline__ void gate_stream_role(const GateStreamArgs& g,
     }
 }
 
-template <bool STREAM>
+// PLOC: the location term of this step was computed one launch earlier (AttArgs::ploc): no matrix-core stage here.
+template <bool STREAM, bool PLOC = false>
 __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a, const GateStreamArgs gs) {
     if constexpr (STREAM) {
         if ((int)blockIdx.x >= a.B) {           // whole workgroups take this branch: no barrier of the attention role is skipped
@@ -1125,7 +1244,7 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a, c
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // s_f [max(Tp*33, 4096)] | s_e [Tp] | s_ep [8][Tp] | s_kb [KP][48]
     __shared__ float s_q[128];
     __shared__ float s_v[128];
-    __shared__ float s_d[32 * 144];
+    __shared__ __attribute__((aligned(16))) float s_d[128 * 36];     // location_dense weight D[a][f] (natural layout), rows padded to 36
     __shared__ float s_cat[2][ATT_FUSED_MAXT + 16 + 64];
     __shared__ float red[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1133,22 +1252,30 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a, c
     const int T = a.T, KS = a.loc_ks, pad = KS >> 1, A = a.att_rnn;
     constexpr int AD = 128, F = 32;
     const int Tp = (T + 15) & ~15, K2 = 2 * KS, KP = (K2 + 3) & ~3, TKp = Tp + KS - 1;
-    const int nF = Tp * 33 > 4096 ? Tp * 33 : 4096;   // s_f doubles as [32][128] / [8][512] reduction scratch
+    constexpr int FS = 36;                            // floats per row of s_f / s_d: 16-byte aligned rows for b128 fragment reads
+    const int nF = Tp * FS > 4096 ? Tp * FS : 4096;   // s_f doubles as [32][128] / [8][512] reduction scratch
     float* s_f = s_dyn;
     float* s_e = s_f + nF;
     float* s_ep = s_e + Tp;
     float* s_kb = s_ep + 8 * Tp;
     const int lr = lane & 15, lq = lane >> 4;
     // ---- every independent global load first, in one batch (fixed trip counts, clamped addresses) ----
-    float pm[4][4];
+    float pm[3][4];
+    // the partial queries the attention cell's launch left (written by 256 other workgroups: they come out of memory, the slowest
+    // loads of this kernel) are requested with the first batch, not after it
+    const bool q_parts = a.q_part && (a.n_part & 31) == 0 && a.n_part <= 256;
+    f32x4 qpv[8];
+    f32x4 plv[PLOC ? 4 : 1];
     {
         const int nK = F * K2;
         float rk[4], rd[4], rc[2];
+        if constexpr (!PLOC) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                          // nK <= 32 * 2 * 63 = 4032; D is 32 x 128 = 4096
-            const int i = tid + j * 1024;
-            rk[j] = a.w_loc_conv[i < nK ? i : 0];
-            rd[j] = a.w_loc_denseT[i];
+            for (int j = 0; j < 4; ++j) {                      // nK <= 32 * 2 * 63 = 4032; D is 32 x 128 = 4096
+                const int i = tid + j * 1024;
+                rk[j] = a.w_loc_conv[i < nK ? i : 0];
+                rd[j] = a.w_loc_dense[i];                      // D[a][f]: i = a * 32 + f
+            }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {                          // 2 * TKp <= 2 * (512 + 62) = 1148
@@ -1159,28 +1286,50 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a, c
             if (!in) rc[j] = 0.f;
         }
         const float vv = tid < AD ? a.w_v[tid] : 0.f;
-        // processed memory of this wave's first four stage-2 tiles (tile id = wave + 16 i: t-tile id >> 3, a-tile id & 7): every tile
-        // up to T = 128 (two were prefetched before: at 128 encoder positions the third and fourth tile loaded inside the loop, two
-        // exposed memory round trips on the launch's critical workgroup)
+        // processed memory of this wave's first three stage-2 tiles (tile id = wave + 16 i: t-tile id >> 3, a-tile id & 7: T <= 96);
+        // later tiles are requested one tile ahead inside the loop (two were prefetched at first: beyond 64 encoder
+        // positions the later tiles loaded where they were used, one exposed memory round trip each on the launch's critical
+        // workgroup)
+        if constexpr (!PLOC) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = wave + 16 * i, tt = id >> 3, at = id & 7;
+            for (int i = 0; i < 3; ++i) {
+                const int id = wave + 16 * i, tt = id >> 3, at = id & 7;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int t = 16 * tt + 4 * lq + r;
-                pm[i][r] = a.pmem[((size_t)b * T + (t < T ? t : 0)) * AD + 16 * at + lr];
+                for (int r = 0; r < 4; ++r) {
+                    const int t = 16 * tt + 4 * lq + r;
+                    pm[i][r] = a.pmem[((size_t)b * T + (t < T ? t : 0)) * AD + 16 * at + lr];
+                }
+            }
+        } else {
+            // location term + processed memory of the first 128 positions (thread = four channels of positions tid / 32 + 32 j)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = (tid >> 5) + 32 * j;
+                const size_t o = ((size_t)b * T + (t < T ? t : 0)) * AD + 4 * (tid & 31);
+                plv[j] = *(const f32x4*)(a.ploc + o);         // (written by the previous launch: out of memory, the slow ones - early)
             }
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = tid + j * 1024;
-            if (i < nK) {
-                const int f = i / K2, k = i - f * K2;          // K[f][c][j] -> B operand [k = c*KS + j][f]
-                s_kb[k * 48 + f] = rk[j];
-            }
-            s_d[(i >> 7) * 144 + (i & 127)] = rd[j];
+        // (issued BEHIND the loads above: a counted wait then lets those - L2 hits - be staged while the partials are in flight)
+        {
+            const int aq = tid & 31, part = tid >> 5;
+            const int per = q_parts ? a.n_part >> 5 : 0;         // 8 for 256 partials
+            const float* qp = q_parts ? a.q_part + ((size_t)part * per * a.B + b) * AD + 4 * aq : a.w_v;
+            const size_t qs = q_parts ? (size_t)a.B * AD : 0;
+    #pragma unroll
+            for (int u = 0; u < 8; ++u) qpv[u] = *(const f32x4*)(qp + (size_t)(u < per ? u : 0) * qs);
         }
-        if (tid < (KP - K2) * F) s_kb[(K2 + tid / F) * 48 + (tid % F)] = 0.f;      // zero rows that pad K to a multiple of 4
+        if constexpr (!PLOC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = tid + j * 1024;
+                if (i < nK) {
+                    const int f = i / K2, k = i - f * K2;      // K[f][c][j] -> B operand [k = c*KS + j][f]
+                    s_kb[k * 48 + f] = rk[j];
+                }
+                s_d[(i >> 5) * 36 + (i & 31)] = rd[j];
+            }
+            if (tid < (KP - K2) * F) s_kb[(K2 + tid / F) * 48 + (tid % F)] = 0.f;  // zero rows that pad K to a multiple of 4
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int i = tid + j * 1024;
@@ -1190,22 +1339,16 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a, c
     }
     PROBE_MID(0)
     // ---- query: sum of the per-workgroup partials the attention LSTM cell just wrote, or W_q h_att ----
-    if (a.q_part && (a.n_part & 31) == 0 && a.n_part <= 512) {
-        // thread = (slice of the partial list, four consecutive outputs): n_part / 32 float4 loads each, all in flight at once
-        // (one memory round trip for the 128 KB of partials), then a 32-way sum through LDS in a fixed order
+    if (PLOC || q_parts) {      // (the PLOC form is launched with partial queries only: its W_q . h_att branch is compiled out)
+        // thread = (slice of the partial list, four consecutive outputs): the n_part / 32 float4 partials requested at entry, then a
+        // 32-way sum through LDS in a fixed order
         const int aq = tid & 31, part = tid >> 5;
-        const int per = a.n_part >> 5;                        // 8 for 256 partials, 16 for 512 (training: 2 units per workgroup)
+        const int per = a.n_part >> 5;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* qp = a.q_part + ((size_t)part * per * a.B + b) * AD + 4 * aq;
-        const size_t qs = (size_t)a.B * AD;
-        for (int u0 = 0; u0 < per; u0 += 8) {                  // exactly `per` loads per thread, eight in flight at a time
-            f32x4 pv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) pv[u] = *(const f32x4*)(qp + (size_t)(u0 + u) * qs);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += pv[u];
-        }
-        float* s_q32 = s_f;                                   // [32][128] scratch (s_f is not live yet; Tp * 33 >= 16 * 33... see below)
+        for (int u = 0; u < 8; ++u)
+            if (u < per) acc += qpv[u];
+        float* s_q32 = s_f;                                   // [32][128] scratch (s_f is not live yet)
         *(f32x4*)(s_q32 + part * 128 + 4 * aq) = acc;
         __syncthreads();
         if (tid < AD) {
@@ -1247,6 +1390,36 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a, c
     __syncthreads();
     PROBE_MID(1)
     if (a.q_save && tid < AD) a.q_save[(size_t)b * AD + tid] = s_q[tid];
+    if constexpr (PLOC) {
+        // ---- energies from the precomputed location term: e[t] = sum_a v[a] tanh(P_loc[t][a] + q[a] + pmem[t][a]) (tacotron.py:137-143).
+        // thread = (four channels, position tid / 32 + 32 j); the 32 lanes of a position meet by shuffles ----
+        const int a4 = tid & 31, tr = tid >> 5;
+        const f32x4 q4 = *(const f32x4*)&s_q[4 * a4], v4 = *(const f32x4*)&s_v[4 * a4];
+        const int len = a.lengths ? a.lengths[b] : T;
+        for (int tb0 = 0; tb0 < T; tb0 += 128) {
+            f32x4 pmv4[4];                                     // processed memory: L2 hits, requested here (all of a pass together)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = tb0 + tr + 32 * j;
+                const size_t o = ((size_t)b * T + (t < T ? t : 0)) * AD + 4 * a4;
+                if (tb0 > 0) plv[j] = *(const f32x4*)(a.ploc + o);     // (beyond 128 positions)
+                pmv4[j] = *(const f32x4*)(a.pmem + o);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = tb0 + tr + 32 * j;
+                float e = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float x = plv[j][c] + q4[c] + pmv4[j][c];
+                    e += v4[c] * (1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f));
+                }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
+                if (a4 == 0 && t < T) s_e[t] = t < len ? e : -INFINITY;
+            }
+        }
+    } else {
     // ---- stage 1: location features on the matrix cores.  A[t][k] = cat[c][t + j] (k = c*KS + j), B[k][f] = K[f][c][j] ----
     {
         const int n_tiles = (Tp >> 4) * 2;
@@ -1268,7 +1441,7 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a, c
                     if (ks0 + 4 * u < KP) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s_f[(16 * tt + 4 * lq + r) * 33 + 16 * ft + lr] = acc[r];
+            for (int r = 0; r < 4; ++r) s_f[(16 * tt + 4 * lq + r) * FS + 16 * ft + lr] = acc[r];
         }
     }
     __syncthreads();
@@ -1277,28 +1450,31 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a, c
     {
         const int n_tiles = (Tp >> 4) * 8;
         int it = 0;
+        float pmn[4] = {0.f, 0.f, 0.f, 0.f};                   // tiles 3, 4, ...: requested during the tile before
         for (int id = wave; id < n_tiles; id += 16, ++it) {
             const int tt = id >> 3, at = id & 7;
             float pmv[4];
-            if (it < 4) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pmv[r] = it == 0 ? pm[0][r] : it == 1 ? pm[1][r] : it == 2 ? pm[2][r] : pm[3][r];
-            } else {
+            for (int r = 0; r < 4; ++r) pmv[r] = it == 0 ? pm[0][r] : it == 1 ? pm[1][r] : it == 2 ? pm[2][r] : pmn[r];
+            if (it >= 2 && id + 16 < n_tiles) {
+                const int tn = (id + 16) >> 3, an = (id + 16) & 7;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int t = 16 * tt + 4 * lq + r;
-                    pmv[r] = a.pmem[((size_t)b * T + (t < T ? t : 0)) * AD + 16 * at + lr];
+                    const int t = 16 * tn + 4 * lq + r;
+                    pmn[r] = a.pmem[((size_t)b * T + (t < T ? t : 0)) * AD + 16 * an + lr];
                 }
             }
+            // K order of the eight MFMA steps: step u of lane group lq multiplies k = 8 lq + u (any bijection onto 0 .. 31 serves as
+            // long as A and B agree), so a lane's eight A values and eight B values are CONTIGUOUS: two ds_read_b128 per operand
+            // instead of eight ds_read_b32 with 2- to 4-way bank conflicts (this stage was LDS-bound: 1.3 us per tile, growing
+            // linearly with the encoder length on the one workgroup the whole launch waits for)
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            float av[8], bv[8];
+            const f32x4 a0 = *(const f32x4*)(s_f + (16 * tt + lr) * FS + 8 * lq), a1 = *(const f32x4*)(s_f + (16 * tt + lr) * FS + 8 * lq + 4);
+            const f32x4 b0 = *(const f32x4*)(s_d + (16 * at + lr) * 36 + 8 * lq), b1 = *(const f32x4*)(s_d + (16 * at + lr) * 36 + 8 * lq + 4);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                av[u] = s_f[(16 * tt + lr) * 33 + 4 * u + lq];
-                bv[u] = s_d[(4 * u + lq) * 144 + 16 * at + lr];
-            }
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b0[u], acc, 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b1[u], acc, 0, 0, 0);
             const float qa = s_q[16 * at + lr], va = s_v[16 * at + lr];
             float ev[4];
 #pragma unroll
@@ -1328,6 +1504,7 @@ __global__ __launch_bounds__(1024) void att_fused_mfma_kernel(const AttArgs a, c
             for (int at = 0; at < 8; ++at) e += s_ep[at * Tp + t];      // fixed order: bitwise reproducible
             s_e[t] = t < len ? e : -INFINITY;
         }
+    }
     }
     __syncthreads();
     PROBE_MID(3)
@@ -1443,7 +1620,7 @@ hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream, const Gate
     if (gs && !t2s_att_fused_stream_ok(a, *gs)) return hipErrorInvalidValue;
     if (att_fused_mfma_form(a)) {
         const int Tp = (a.T + 15) & ~15, KP = (2 * a.loc_ks + 3) & ~3;
-        const size_t nF = (size_t)Tp * 33 > 4096 ? (size_t)Tp * 33 : 4096;
+        const size_t nF = (size_t)Tp * 36 > 4096 ? (size_t)Tp * 36 : 4096;      // (FS = 36 floats per feature row in the kernel)
         const size_t lds = (nF + Tp + 8 * Tp + (size_t)KP * 48) * sizeof(float);
         if (gs) {
             // one workgroup per CU (1024 threads, > 64 KB of LDS at any T): the attention workgroups take B CUs, the gate-stream
@@ -1459,12 +1636,21 @@ hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream, const Gate
             static const int dbg = getenv("T2S_DBG_ATTSTREAM") ? atoi(getenv("T2S_DBG_ATTSTREAM")) : 0;
             g2.dbg = dbg;
 #endif
+            if (a.ploc) {
+                if (!a.q_part || (a.n_part & 31) || a.n_part > 256) return hipErrorInvalidValue;
+                static std::atomic<unsigned long long> attr_mask4{0};
+                const hipError_t e4 = t2s_raise_lds_limit((const void*)att_fused_mfma_kernel<true, true>, 120 * 1024, attr_mask4);
+                if (e4 != hipSuccess) return e4;
+                hipLaunchKernelGGL((att_fused_mfma_kernel<true, true>), dim3(a.B + blocks), dim3(1024), lds1, stream, a, g2);
+                return hipGetLastError();
+            }
             hipLaunchKernelGGL(att_fused_mfma_kernel<true>, dim3(a.B + blocks), dim3(1024), lds1, stream, a, g2);
             return hipGetLastError();
         }
         static std::atomic<unsigned long long> attr_mask2{0};
         const hipError_t e2 = t2s_raise_lds_limit((const void*)att_fused_mfma_kernel<false>, 120 * 1024, attr_mask2);
         if (e2 != hipSuccess) return e2;
+        if (a.ploc) return hipErrorInvalidValue;            // (the precomputed location term rides with the gate-stream form only)
         hipLaunchKernelGGL(att_fused_mfma_kernel<false>, dim3(a.B), dim3(1024), lds, stream, a, GateStreamArgs{});
         return hipGetLastError();
     }

@@ -241,7 +241,7 @@ class _DecoderStruct(ctypes.Structure):
     _F = ["att_drop_scale", "dec_drop_scale"]
     _P2 = ["att_h0", "att_h1", "att_c", "dec_h0", "dec_h1", "dec_c", "att_w", "att_wcum", "ctx", "q", "energies",
            "pre1", "pre2", "q_part", "mel_gate_out", "align_out", "hc_all", "att_gates_all", "att_c_all",
-           "dec_gates_all", "dec_c_all", "att_h_all", "q_all", "wcum_all", "gate_part", "w_pre2T"]
+           "dec_gates_all", "dec_c_all", "att_h_all", "q_all", "wcum_all", "gate_part", "w_pre2T", "ploc"]
     _fields_ = ([(n, ctypes.c_int) for n in _I] + [(n, ctypes.c_void_p) for n in _P1] +
                 [(n, ctypes.c_float) for n in _F] + [(n, ctypes.c_void_p) for n in _P2])
 
@@ -571,6 +571,7 @@ class _TacoEngine:
             shapes["align_out"] = (B, T_cap, T_in)          # rows past the stop step stay zero
             if B <= 8 and A == 1024 and D == 1024 and getattr(self, "decode_stream", True):
                 shapes["gate_part"] = (3, B, 4 * A)         # streamed gate partials (ABI v4): zero = h_att(-1) . W_hh_att
+                shapes["ploc"] = (B, T_in, ad)              # location term of the next step's attention (zero: w = w_cum = 0)
         offs, tot = {}, 0
         for name, sh in shapes.items():
             n = 1

@@ -22,7 +22,8 @@ def main():
     m = Tacotron(dict(synth.TACOTRON_HPARAMS), 80, num_speakers=2)
     m.load_state_dict(synth.tacotron_state())
     m = m.cuda().eval()
-    ids = (torch.arange(64) % 78 + 2)[None].cuda()
+    n_sym = int(sys.argv[1]) if len(sys.argv) > 1 else 64       # usage: decode_probe.py [symbols]
+    ids = (torch.arange(n_sym) % 78 + 2)[None].cuda()
     n = 400
     m.decoder.gate_threshold, m.decoder.max_decoder_steps = 2.0, n
     for _ in range(3):
@@ -50,7 +51,9 @@ def main():
         per[int(kid)].append(((r1 - r0) * 10.0, (t1 - t0) / ((r1 - r0) * 10.0)))
         if i + 1 < len(rows) and rows[i + 1][2] > r1:
             gaps[int(kid)].append((rows[i + 1][2] - r1) * 10.0)
-    names = {101: "gemv<1> prenet layer 2 (256x256)", 107: "gemv<7> projection + prenet layer 1 (337x1536)", 300: "att_fused",
+    names = {301: "att_fused_mfma (attention role, workgroup 0; stamps: loads staged / query / features / energies / softmax)",
+             210: "lstm_cell_p2 attention cell + sparse prenet layer (round 4)", 201: "lstm_cell<1> decoder cell, context columns only (round 4)",
+             101: "gemv<1> prenet layer 2 (256x256)", 107: "gemv<7> projection + prenet layer 1 (337x1536)", 300: "att_fused",
              202: "lstm_cell<2> attention cell (4096x1792)", 203: "lstm_cell<3> decoder cell (4096x2560)"}
     out = {}
     for k in sorted(per):
