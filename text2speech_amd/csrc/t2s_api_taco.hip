@@ -276,7 +276,8 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
             if (stream_gates && !t2s_att_fused_stream_ok(aa, gs)) return T2S_EINVAL;
             // the location term of this step came out of the previous step's projection launch (zero at step 0).  T2S_DECODE_PLOC=0: off
             static const bool want_ploc = !(getenv("T2S_DECODE_PLOC") && atoi(getenv("T2S_DECODE_PLOC")) == 0);
-            use_ploc = stream_gates && want_ploc && d->ploc && d->att_dim == 128 && d->loc_filters == 32 && !aa.q_save && !aa.wcum_save;
+            use_ploc = stream_gates && want_ploc && d->ploc && d->att_dim == 128 && d->loc_filters == 32 && d->loc_kernel <= 31 && !aa.q_save &&
+                       !aa.wcum_save;
             if (use_ploc) aa.ploc = d->ploc;
             T2S_CHECK_HIP(t2s_launch_att_fused(aa, stream, stream_gates ? &gs : nullptr));
         } else {

@@ -274,7 +274,7 @@ hipError_t t2s_launch_gemv_with_loc(const GemvArgs& a, const LocPreArgs& lp_in, 
     const int K = a.n1 + a.n2 + a.n3;
     const int nv4 = (K + 255) / 256;
     if (a.items >= 64 || !lp_in.ploc || !lp_in.w || !lp_in.w_cum || !lp_in.w_loc_conv || !lp_in.w_loc_denseT || lp_in.B <= 0 ||
-        lp_in.T <= 0 || lp_in.loc_ks > 63 || !(lp_in.loc_ks & 1))
+        lp_in.T <= 0 || lp_in.loc_ks > 31 || !(lp_in.loc_ks & 1))      // (one 64-wide K pass: 2 * KS <= 64)
         return hipErrorInvalidValue;
     LocPreArgs lp = lp_in;
     lp.n_gemv_blocks = (a.rows + 3) / 4;
