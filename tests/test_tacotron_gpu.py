@@ -157,11 +157,12 @@ def test_inference_1000_frames_vs_reference_and_oracle(model, golden_dir):
         print("frame %4d: vs reference mel %.1e post %.1e align %.1e | vs oracle mel %.1e align %.1e" % ((f,) + r_ref + r_orc))
 
 
-@pytest.mark.parametrize("B,T_in,n", [(1, 48, 150), (3, 48, 150), (8, 48, 150), (2, 300, 40), (1, 512, 24)])
+@pytest.mark.parametrize("B,T_in,n", [(1, 48, 150), (3, 37, 150), (8, 48, 150), (2, 300, 40), (1, 512, 24), (1, 5, 30)])
 def test_streamed_gate_partials_match_unstreamed_decode(model, B, T_in, n):
-    """ABI v4 `gate_part`: at B <= 8 the fused attention launch of step t also streams
+    """ABI v4 `gate_part` / `w_pre2T` / `ploc`: at B <= 8 the fused attention launch of step t also streams
     W_hh_dec . h_dec(t-1), W_ih_dec[:, :1024] . h_att(t) and next step's W_hh_att . h_att(t) on the CUs the attention leaves
-    idle; the cells add those partials.  Same operator (tacotron.py:355-393), different summation order: both forms against
+    idle and the cells add those partials; the prenet's second layer is a sparse product inside the attention cell's launch; the
+    attention's location term comes out of the previous step's projection launch.  Same operator (tacotron.py:355-393), different summation order: both forms against
     each other over up to 150 recurrent steps (the goldens above hold the streamed default to the reference)."""
     gen = torch.Generator().manual_seed(30 + B)
     ids = torch.randint(2, 80, (B, T_in), generator=gen).to(DEV)      # (300 / 512 positions: the attention role's large-LDS shapes)
