@@ -189,6 +189,17 @@ def tacotron_metrics(dev):
                                "step time, encoder + postnet included.  Since round 4 the step is four launches: attention cell "
                                "(+ the sparse prenet layer), attention + gate-stream role (50 MB of the weights on the CUs the "
                                "attention leaves idle), decoder cell, projection"}
+    try:        # HBM-side bytes of the four launches of a decode step, from the committed PMC passes (not measured in this run)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r04_decode_pmc_traffic.json")))["kernels"]
+        names = ("att_fused_mfma_kernelILb1ELb1", "lstm_cell_p2_kernel", "lstm_cell_kernelILi1ELi4ELb0", "gemv_rows_loc_kernelILi7")
+        per = [next(v["traffic_bytes_per_launch"] for k, v in pm.items() if n in k) for n in names]
+        out["roofline"]["traffic"] = sum(per)
+        out["roofline"]["traffic_note"] = ("FROM THE COMMITTED PROFILE, NOT MEASURED IN THIS RUN: profiles/r04_decode_pmc_traffic.json "
+                                           "(separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the gfx950 note): attention + "
+                                           "gate stream %.1f MB, attention cell %.1f, decoder cell %.1f, projection %.1f per launch"
+                                           % tuple(x / 1e6 for x in per))
+    except (OSError, KeyError, ValueError, StopIteration):
+        out["roofline"]["traffic"] = None
     B, T_in, T_out = 32, 256, 800
     gen = torch.Generator().manual_seed(21)
     text = torch.randint(2, 80, (B, T_in), generator=gen).to(dev)
