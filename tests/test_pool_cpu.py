@@ -47,3 +47,21 @@ def test_zero_once_is_cleared_at_creation_only():
     gc.collect()
     b = pool_take(pool, h, "planes", (3, 32), torch.float32, "cpu", zero_once=True)
     assert float(b.min()) == 5.0, "... and a reused buffer is handed back as it is (its padding depends on the shape only)"
+
+
+def test_zero_once_with_extent_is_cleared_again_when_the_extent_changes():
+    """Planes whose padded shape is shared by several valid lengths (Lp = ceil(T / 256) * 256 + 2 * halo): same extent -> handed back
+    as it is, other extent -> cleared (the producers write rows below T only)."""
+    pool, h = BufferPool(), []
+    a = pool_take(pool, h, "planes", (4, 8), torch.float32, "cpu", zero_once=True, extent=(40,))
+    a.fill_(7.0)
+    del a
+    h.clear()
+    gc.collect()
+    b = pool_take(pool, h, "planes", (4, 8), torch.float32, "cpu", zero_once=True, extent=(40,))
+    assert float(b.min()) == 7.0
+    del b
+    h.clear()
+    gc.collect()
+    c = pool_take(pool, h, "planes", (4, 8), torch.float32, "cpu", zero_once=True, extent=(37,))
+    assert float(c.abs().max()) == 0.0

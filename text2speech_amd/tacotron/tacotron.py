@@ -341,7 +341,10 @@ def pool_take(pool, holder, tag, shape, dtype, device, zero_once=False, extent=N
     if t is None:
         t = (torch.zeros if zero_once else torch.empty)(*shape, dtype=dtype, device=device)
     elif zero_once and extent is not None and getattr(t, "_t2s_extent", None) != tuple(extent):
-        _lib.call("t2s_zero_fill", _lib.ptr(t), t.numel() * t.element_size(), _lib.current_stream())
+        if t.is_cuda:
+            _lib.call("t2s_zero_fill", _lib.ptr(t), t.numel() * t.element_size(), _lib.current_stream())
+        else:
+            t.zero_()
     if zero_once and extent is not None:
         t._t2s_extent = tuple(extent)
     holder.append(_Lease(pool, key, t))
