@@ -171,6 +171,11 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
     // stream waits once per chunk: a cross-stream wait costs ~6 us on the critical stream (profiles/r03_taco_timeline_bwd_fused.md).
     static const int chunk_env = getenv("T2S_BPTT_CHUNK") ? atoi(getenv("T2S_BPTT_CHUNK")) : 16;
     const int chunk = two_streams ? (chunk_env > 0 ? chunk_env : 1) : 1;
+    // T2S_BPTT_SPLIT_ROWS=1 (two streams, 9+ items): the transposed decoder-cell GEMM [KD = A + E + D rows] x [4 D] of every step is
+    // split by consumer - the D rows of d h_dec(t-1), which the next decoder-cell step needs, per step; the A + E rows of d h_att /
+    // d ctx, which only the attention chain reads (a chunk of steps later), as ONE launch over the chunk's (steps x batch) items
+    static const bool want_split_rows = getenv("T2S_BPTT_SPLIT_ROWS") && atoi(getenv("T2S_BPTT_SPLIT_ROWS")) != 0;
+    const bool split_rows = want_split_rows && two_streams && chunk > 1 && B > 8 && ((A + E) & 15) == 0 && (D & 15) == 0;
     for (int tc = t_hi - 1; tc >= t_lo; tc -= chunk) {
     const int tl = tc - chunk + 1 > t_lo ? tc - chunk + 1 : t_lo;
     for (int t = tc; t >= tl; --t) {
@@ -190,6 +195,19 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         memset(&g, 0, sizeof(g));
         g.W1 = p->W_dT; g.ld1 = 4 * D; g.k1 = 4 * D; g.x1 = cd.dgates; g.n1 = 4 * D; g.sx1 = 4 * D;
         g.y = p->out_d + (size_t)t * B * KD; g.sy_item = KD; g.sy_row = 1; g.rows = KD; g.items = B; g.mask_scale = 1.f;
+        if (split_rows) {
+            // only the rows the NEXT decoder-cell step reads (d h_dec(t-1) = rows A + E .. KD of [W_ih | W_hh]^T dgates) stay per step;
+            // the d h_att / d ctx rows, which the attention chain reads a chunk later, are one GEMM over the chunk's items below
+            g.W1 = p->W_dT + (size_t)(A + E) * 4 * D; g.y += A + E; g.rows = D;
+        }
+        T2S_CHECK_HIP(t2s_launch_gemv(g, dstream));
+    }
+    if (split_rows) {
+        GemvArgs g;
+        memset(&g, 0, sizeof(g));
+        g.W1 = p->W_dT; g.ld1 = 4 * D; g.k1 = 4 * D; g.x1 = p->dg_d + (size_t)tl * B * 4 * D; g.n1 = 4 * D; g.sx1 = 4 * D;
+        g.y = p->out_d + (size_t)tl * B * KD; g.sy_item = KD; g.sy_row = 1; g.rows = A + E; g.items = (tc - tl + 1) * B;
+        g.mask_scale = 1.f;
         T2S_CHECK_HIP(t2s_launch_gemv(g, dstream));
     }
     if (two_streams) {       // out_d[tl .. tc] are ready: the wait below binds to THIS record, so one event object serves every chunk
