@@ -83,8 +83,8 @@ def test_waveglow_gate_tile_heights(B, frames, rows):
 @pytest.mark.parametrize("B,frames", [(4, 264), (1, 1100)])
 def test_waveglow_infer_composed_conditioning(B, frames, monkeypatch):
     """Inverse flow with the conditioning layers composed with the upsampler (opt-in T2S_COND_COMPOSE=1: K = 640 -> 320 in the gate
-    GEMM, phase-major column tiles, mel-window planes) against the default kernels on the same inputs - which the golden and oracle
-    tests pin - at batch entries and frame counts that do not fill the 256-column tiles."""
+    GEMM, phase-major column tiles, mel-window planes) against the default kernels on the same inputs AND against the CPU oracle, at
+    batch entries and frame counts that do not fill the 256-column tiles."""
     _lib.load()
     cfg = synth.WAVEGLOW_SMALL
     m = _wg(cfg)
@@ -104,6 +104,11 @@ def test_waveglow_infer_composed_conditioning(B, frames, monkeypatch):
     assert eng.packed.get("compose_key") is not None, "the composed path did not run"
     assert bool(torch.isfinite(a_comp).all())
     assert _rel(a_comp, a_plain) < 2e-5
+    # ... and both against the CPU oracle (a HIP-vs-HIP comparison is not oracle evidence by itself)
+    from oracle import waveglow_oracle as O
+    with torch.no_grad():
+        ao = O.waveglow_infer(synth.waveglow_state(cfg), cfg, mel, nf, ne, sigma=0.6)
+    assert _rel(a_comp, ao) < 1e-3 and _rel(a_plain, ao) < 1e-3, (_rel(a_comp, ao), _rel(a_plain, ao))
 
 
 def test_waveglow_rejects_short_mel():
