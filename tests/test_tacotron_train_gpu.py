@@ -136,9 +136,7 @@ def _seeded_masks(B, T_in, T_out, gen):
 
 @pytest.mark.parametrize("B,T_in,T_out", [
     (12, 22, 20),     # > 8 items: f32 matrix-core cells (csrc/sbgemm.hip); T_in % 4 != 0: in-loop d_memory accumulation
-    (32, 64, 40),     # BASELINE configs[1] batch (train.py:216-225): two 16-item groups per sbgemm workgroup, deferred d_memory
-                      # (40 decoder steps: the CPU autograd of the oracle is what this test's time goes to; the full 800-step
-                      # shape is held by test_benchmarked_shape_b32_t800_vs_reference_golden)
+    (32, 64, 64),     # BASELINE configs[1] batch (train.py:216-225): two 16-item groups per sbgemm workgroup, deferred d_memory
 ])
 def test_step_vs_oracle(B, T_in, T_out):
     """Loss, the four outputs and every parameter gradient against CPU autograd through the oracle, seeded masks, ragged
