@@ -1667,7 +1667,10 @@ hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream, const Gate
 // bidirectional, H per direction).  gx[b][t][dir*4H + j] already holds W_ih x + b_ih + b_hh (one GEMM
 // for all steps).  One workgroup = one direction x BT batch elements; thread j owns gate row j and
 // streams W_hh^T (coalesced) each step; h lives in LDS.
-template <int BT>
+// Round 4: part of the matrix stays ON the CU for the whole sequence - thread j keeps W_hh^T[k][j] for k < KR in registers and the
+// workgroup keeps rows KR .. KR + KL in LDS (KL * 4 KB), so a step streams H - KR - KL rows instead of H: the kernel is bound by what
+// one CU pulls out of L2 (1 MB per step and workgroup before: 14 us per step at B = 32, 8.6 at B = 1).
+template <int BT, int KR, int KL>
 __global__ __launch_bounds__(1024) void lstm_seq_kernel(const float* __restrict__ gx, const float* __restrict__ whhT_f,
                                                         const float* __restrict__ whhT_r, const int* __restrict__ lengths,
                                                         float* out, int B, int T, int H, int T_out, float* gates_save,
@@ -1691,6 +1694,13 @@ __global__ __launch_bounds__(1024) void lstm_seq_kernel(const float* __restrict_
     if (j < H)
 #pragma unroll
         for (int i = 0; i < BT; ++i) s_h[i][j] = 0.f;
+    // resident part of W_hh^T: rows [0, KR) in registers, rows [KR, KR + KL) in LDS (dynamic, KL * 1024 floats)
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    float wr[KR > 0 ? KR : 1];
+#pragma unroll
+    for (int k = 0; k < KR; ++k) wr[k] = WT[(size_t)k * 4 * H + j];
+#pragma unroll 8
+    for (int kk = 0; kk < KL; ++kk) s_w[kk * 1024 + j] = WT[(size_t)(KR + kk) * 4 * H + j];
     __syncthreads();
     for (int s = 0; s < maxlen; ++s) {
         float acc[BT];
@@ -1701,13 +1711,32 @@ __global__ __launch_bounds__(1024) void lstm_seq_kernel(const float* __restrict_
         }
         // four k per trip: one 16-byte broadcast LDS read per item instead of four 4-byte ones (the loop was LDS-issue
         // bound: 1024 ds_read per thread per step), four independent weight loads in flight
+        // (the streamed rows first: their loads are in flight while the resident rows are multiplied)
 #pragma unroll 4
-        for (int k = 0; k < H; k += 4) {
+        for (int k = KR + KL; k < H; k += 4) {
             const float w0 = WT[(size_t)k * 4 * H + j], w1 = WT[(size_t)(k + 1) * 4 * H + j];
             const float w2 = WT[(size_t)(k + 2) * 4 * H + j], w3 = WT[(size_t)(k + 3) * 4 * H + j];
 #pragma unroll
             for (int i = 0; i < BT; ++i) {
                 const f32x4 h4 = *(const f32x4*)&s_h[i][k];
+                acc[i] += (w0 * h4[0] + w1 * h4[1]) + (w2 * h4[2] + w3 * h4[3]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KR; k += 4) {
+#pragma unroll
+            for (int i = 0; i < BT; ++i) {
+                const f32x4 h4 = *(const f32x4*)&s_h[i][k];
+                acc[i] += (wr[k] * h4[0] + wr[k + 1] * h4[1]) + (wr[k + 2] * h4[2] + wr[k + 3] * h4[3]);
+            }
+            if ((k & 15) == 12) __builtin_amdgcn_sched_barrier(0);      // (keeps hipcc from hoisting every LDS read of h in front: spills)
+        }
+#pragma unroll 4
+        for (int kk = 0; kk < KL; kk += 4) {
+            const float w0 = s_w[kk * 1024 + j], w1 = s_w[(kk + 1) * 1024 + j], w2 = s_w[(kk + 2) * 1024 + j], w3 = s_w[(kk + 3) * 1024 + j];
+#pragma unroll
+            for (int i = 0; i < BT; ++i) {
+                const f32x4 h4 = *(const f32x4*)&s_h[i][KR + kk];
                 acc[i] += (w0 * h4[0] + w1 * h4[1]) + (w2 * h4[2] + w3 * h4[3]);
             }
         }
@@ -1750,9 +1779,25 @@ hipError_t t2s_launch_lstm_seq(const float* gx, const float* whhT_f, const float
     if (4 * H != 1024) return hipErrorInvalidValue;
     // elements per workgroup: the recurrent matrix (1 MB per direction) is re-streamed by every workgroup each step, the
     // FMAs scale with the elements it carries - 2 per workgroup up to 128 elements (<= 128 workgroups), then 4
-    if (B > 128) hipLaunchKernelGGL(lstm_seq_kernel<4>, dim3((B + 3) / 4, 2), dim3(1024), 0, stream, gx, whhT_f, whhT_r, lengths, out, B, T, H, T_out, gates_save, c_save);
-    else if (B >= 8) hipLaunchKernelGGL(lstm_seq_kernel<2>, dim3((B + 1) / 2, 2), dim3(1024), 0, stream, gx, whhT_f, whhT_r, lengths, out, B, T, H, T_out, gates_save, c_save);
-    else hipLaunchKernelGGL(lstm_seq_kernel<1>, dim3(B, 2), dim3(1024), 0, stream, gx, whhT_f, whhT_r, lengths, out, B, T, H, T_out, gates_save, c_save);
+    // resident rows (T2S_LSTM_SEQ_RESIDENT=0: none, the round-3 kernel): 64 / 24 / 16 in registers (by elements per workgroup: the
+    // 128-VGPR cap of a 1024-thread workgroup) + 36 / 36 / 32 in LDS (144 / 128 KB) of the 256
+    static const bool resident = !(getenv("T2S_LSTM_SEQ_RESIDENT") && atoi(getenv("T2S_LSTM_SEQ_RESIDENT")) == 0);
+#define LSEQ(BT_, KR_, KL_, GRID)                                                                                      \
+    do {                                                                                                               \
+        static std::atomic<unsigned long long> am{0};                                                                  \
+        const hipError_t e_ = t2s_raise_lds_limit((const void*)lstm_seq_kernel<BT_, KR_, KL_>, KL_ * 4096 + 16, am);   \
+        if (e_ != hipSuccess) return e_;                                                                               \
+        hipLaunchKernelGGL((lstm_seq_kernel<BT_, KR_, KL_>), GRID, dim3(1024), KL_ * 4096, stream, gx, whhT_f, whhT_r, \
+                           lengths, out, B, T, H, T_out, gates_save, c_save);                                          \
+    } while (0)
+    if (B > 128) {
+        if (resident) LSEQ(4, 16, 32, dim3((B + 3) / 4, 2)); else LSEQ(4, 0, 0, dim3((B + 3) / 4, 2));
+    } else if (B >= 8) {
+        if (resident) LSEQ(2, 24, 36, dim3((B + 1) / 2, 2)); else LSEQ(2, 0, 0, dim3((B + 1) / 2, 2));
+    } else {
+        if (resident) LSEQ(1, 64, 36, dim3(B, 2)); else LSEQ(1, 0, 0, dim3(B, 2));
+    }
+#undef LSEQ
     return hipGetLastError();
 }
 
