@@ -1,5 +1,5 @@
 #!/bin/bash
-# Reproduce the evidence under profiles/ on a 1-GPU MI355X box (run from the repo root; ~8 GPU-minutes).
+# Reproduce the evidence under profiles/ on a 1-GPU MI355X box (run from the repo root; ~10 GPU-minutes).
 # rocprofv3 7.2 writes a rocpd SQLite database; tools/rocpd_stats.py, tools/pmc_traffic.py and tools/pmc_counters.py turn
 # it into the tables / JSON that profiles/r02_summary.md quotes.  Counters are collected in their own passes (no trace
 # domains next to --pmc).  The program after `--` is always python3 itself (never env / bash -c: MI355X pool rule).
@@ -34,4 +34,15 @@ python3 tools/microbench/sbgemm_bench.py > "$OUT/sbgemm_bench.json" 2> /dev/null
 python3 tools/prof_ops.py waveglow_train > "$OUT/ops_waveglow_train.txt" 2> /dev/null
 python3 tools/prof_ops.py tacotron_train > "$OUT/ops_tacotron_train.txt" 2> /dev/null
 python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+# round 4: the B = 1 decode chain (streamed gates / folded prenet / location term one launch early, each against its switch), the
+# operand-format A/B and - when the diagnostic builds exist (python -m text2speech_amd.build --variant ...) - the role ablation and the
+# in-kernel stamps of the attention role
+python3 tools/r4_decode_ab.py 1 > "$OUT/decode_stream_ab.json" 2> /dev/null
+bash tools/r4_decode_env_ab.sh "T2S_DECODE_FOLD_PRE2=1" "T2S_DECODE_FOLD_PRE2=0" > "$OUT/decode_fold_ab.txt" 2>&1
+bash tools/r4_decode_env_ab.sh "T2S_DECODE_PLOC=1" "T2S_DECODE_PLOC=0" > "$OUT/decode_ploc_ab.txt" 2>&1
+[ -f build/f16x3/libt2s_hip.so ] && bash tools/r4_operand_ab.sh > "$OUT/operand_format_ab.txt" 2>&1
+[ -f build/attstream_ablate/libt2s_hip.so ] && bash tools/r4_attstream_ablate.sh > /dev/null 2>&1 && cp gpurun_out/r4_attstream/summary.md "$OUT/attstream_role_ablation.md"
+if [ -f build/probe/libt2s_hip.so ]; then
+  for n in 64 128 256; do echo "== $n symbols"; T2S_LIB_PATH=$R/build/probe/libt2s_hip.so python3 tools/decode_probe.py $n 2> /dev/null; done > "$OUT/att_role_probe.txt"
+fi
 echo "wrote $OUT"
