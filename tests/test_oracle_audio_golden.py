@@ -61,6 +61,17 @@ def test_mel_filterbank_shape_and_normalisation():
     assert (np.diff(peaks) > 0).all()
 
 
+def test_mel_filterbank_published_example_value():
+    """The only published number available for `librosa.filters.mel` (absent here, unpinned upstream): its documentation prints
+    `melfb = librosa.filters.mel(sr=22050, n_fft=2048)` with melfb[0][1] shown as 0.016 (three decimals), zeros at both ends of every
+    row.  The restated Slaney filterbank gives 0.01618 there.  A weak pin - one rounded value - and labelled as such: the 80 x 513
+    table the model uses stays "parity unpinned" (DESIGN.md section 6b, N3)."""
+    w = A.mel_filterbank(22050, 2048, 128, 0.0, 11025.0)
+    assert w.shape == (128, 1025)
+    assert abs(round(float(w[0, 1]), 3) - 0.016) < 1e-9
+    assert float(abs(w[:, 0]).max()) == 0.0 and float(abs(w[1:, 1]).max()) == 0.0 and float(w[-1, -1]) == 0.0
+
+
 def test_mel_spectrogram_and_denoise_shapes():
     gen = torch.Generator().manual_seed(4)
     audio = torch.rand(2, 4096, generator=gen) * 1.8 - 0.9
