@@ -354,6 +354,7 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
     st2 = _lib.c_vp(side_s.cuda_stream)
     side_s.wait_stream(main_s)
     cl = ts.cl_ok       # weight-gradient GEMMs straight from the channel-last planes (no time-major copies)
+    cl_third_ok = cl
     if not cl:
         # conditioning rows + the ones row of the in/cond weight-gradient GEMM are the same for every layer
         _lib.call("t2s_plane_transpose", _ptr(ts.S_planes[0]), _ptr(ts.S_planes[1]), B, sc, sc, Lp, 0, _ptr(ts.TM_x[0]),
@@ -420,6 +421,18 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
     # T2S_WG_P1_MAIN=0: the res/skip weight gradient on the weight-gradient stream (the round-3 start)
     p1_main = two and os.environ.get("T2S_WG_P1_MAIN", "1") != "0"
     p1_count, p1_free = [0], [None, None]
+    # T2S_WG_P1_THIRD=1 (experimental): the res/skip weight gradient on a THIRD stream, started beside the gate backward - both
+    # are 128-workgroup launches that only READ DX / DS, so together they fill the chip; the chain waits for it only in front of
+    # W_in^T's in-place update of DX
+    p1_third = p1_main and cl_third_ok and os.environ.get("T2S_WG_P1_THIRD", "0") == "1"
+    p1_s = None
+    if p1_third:
+        p1_s = getattr(eng, "bwd_p1_stream", None)
+        if p1_s is None:
+            p1_s = eng.bwd_p1_stream = torch.cuda.Stream(device=dev)
+        p1_s.wait_stream(main_s)
+    st3 = _lib.c_vp(p1_s.cuda_stream) if p1_third else None
+    ev_p1_done = None
     wcond_side = two and cl and not per_layer_cond and os.environ.get("T2S_WG_WCOND_SIDE", "1") == "1"
     for k in reversed(range(m.n_flows)):
         c_off, n_rem, n_half = eng._flow_geom(k)
@@ -499,6 +512,10 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             dp_h, dp_l = _lib.c_vp(DP[0].data_ptr() + dp_off), _lib.c_vp(DP[1].data_ptr() + dp_off)
             a_h, a_l = _act_ptrs(ts, k, i, "A")
             g_h, g_l = _act_ptrs(ts, k, i, "G")
+            ev_dx = None
+            if p1_third:
+                ev_dx = torch.cuda.Event()          # DX / DS of this layer are final: the third stream's res/skip weight gradient may read them
+                ev_dx.record(main_s)
             _lib.call("t2s_wg_bwd_gate_dgrad", _ptr(A_rsT[0]), _ptr(A_rsT[1]), _ptr(zb),
                       None if last else _ptr(ts.DX[0]), None if last else _ptr(ts.DX[1]), _ptr(DS[0]), _ptr(DS[1]),
                       a_h, a_l, g_h, g_l, ts.act_bchunks, dp_h, dp_l, ts.dp_chunks, B, C, L, Lp, halo, ts.Mc, ts.p8_x, st)
@@ -510,7 +527,25 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             d = 2 ** i
             P1 = ts.P1
             ev_tdrs = None
-            if cl and p1_main:
+            if cl and p1_third:
+                # third stream: needs DX / DS final (the record sits in front of the gate backward on the main stream) and a free slab set
+                ta1, tb1, ta2, tb2 = _cl_tables(ts, (k, i), sv, last, xc, sc, ks, d, dev, i)
+                ks1 = ts.ks1_last if last else ts.ks1
+                pb = p1_count[0] & 1
+                p1_count[0] += 1
+                P1 = ts.P1b if pb else ts.P1
+                p1_s.wait_event(ev_dx)
+                if p1_free[pb] is not None:
+                    p1_s.wait_event(p1_free[pb])
+                _lib.call("t2s_wgrad_cl", _ptr(ta1), ta1.size(0), _ptr(tb1), tb1.size(0), _ptr(P1), B, rows2, ts.N1g, ts.ld1,
+                          ts.k0, ts.k1, ks1, ts.bias_cols, st3)
+                ev_p1_done = torch.cuda.Event()
+                ev_p1_done.record(p1_s)
+                side_s.wait_event(ev_p1_done)
+                ev_p1 = torch.cuda.Event()          # d_pre of this layer is final (gate backward): the weight-gradient stream's cue
+                ev_p1.record(main_s)
+                side_s.wait_event(ev_p1)
+            elif cl and p1_main:
                 # On the data-gradient stream, between the two GEMMs that bracket it there: the chain then never waits for the
                 # weight-gradient stream before it updates DX (that wait was 135 us of the 463 us a layer took,
                 # profiles/r03_wg_train_timeline_before.md), and 74 us of half-chip work leave the longer stream.  Its slab
@@ -572,6 +607,8 @@ def backward_train(eng, ts, gz, g_log_s, g_log_det):
             # 4. dx (+)= W_in^T (*) d_pre ;  d_spect += W_cond^T d_pre                                       [main]
             if ev_tdrs is not None:
                 main_s.wait_event(ev_tdrs)  # (events of one stream complete in order: this covers every earlier read of DX too)
+            if p1_third and ev_p1_done is not None:
+                main_s.wait_event(ev_p1_done)       # the third stream has read DX: W_in^T may update it in place
             _lib.call("t2s_conv_accumulate", _ptr(A_inT[0]), _ptr(A_inT[1]), _ptr(zb), dp_h, dp_l, ts.dp_chunks,
                       _ptr(ts.DX[0]), _ptr(ts.DX[1]), B, 2 * C, C, ks, d, 1 if last else 0, L, Lp, halo, ts.Mc, ts.p8_x, st)
             # (W_cond,i^T sits in K-chunks [2 xc i, 2 xc (i + 1)) of the flow's conditioning-gradient operand A_cT)
