@@ -294,8 +294,8 @@ typedef struct t2s_taco_decoder {
     float *dec_gates_all, *dec_c_all;    /* same for the decoder LSTM */
     float *att_h_all;                    /* [T][B][H] attention-LSTM output after dropout */
     float *q_all, *wcum_all;             /* [T][B][att_dim] queries, [T][B][T_in] cumulative weights after the step */
-    /* ABI v4.  [3][B][4H] scratch, ZERO before step 0, or NULL.  Autoregressive decode at B <= 8 with att_rnn_dim = dec_rnn_dim =
-     * 1024: the fused attention launch of step t also streams W_hh_dec . h_dec(t-1), W_ih_dec[:, :att_rnn] . h_att(t) and
+    /* ABI v4.  [3][B][4H] scratch, ZERO before step 0, or NULL.  Autoregressive decode at B <= 4 (T2S_DECODE_STREAM_MAXB) with
+     * att_rnn_dim = dec_rnn_dim = 1024: the fused attention launch of step t also streams W_hh_dec . h_dec(t-1), W_ih_dec[:, :att_rnn] . h_att(t) and
      * W_hh_att . h_att(t) on the CUs the attention leaves idle and keeps the products here; the decoder cell of step t and the
      * attention cell of step t+1 then add them instead of streaming those 50 MB themselves.  State like h / c: carried between
      * calls that continue one utterance.  NULL (or T2S_DECODE_STREAM=0): every cell streams its own weights (ABI v3 behaviour). */

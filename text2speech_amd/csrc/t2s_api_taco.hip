@@ -237,7 +237,11 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
             if (!q_big) { ca.w_q = nullptr; ca.q_part = nullptr; ca.q_dim = 0; }
         }
         // streamed gates: W_hh_att . h_att(s-1) was left in gate_part[2] by the previous step's attention launch (zero at step 0)
-        if (want_stream && d->gate_part && !d->teacher_forced && fused_att && q_parts && !ca.gates_out && A == 1024 && D == 1024) {
+        // (up to 4 items: the role's dot products and reductions are per item - at B = 8 the launch takes longer than the two cells save,
+        // 73.9 vs 67.4 us per step; B = 4: 48.2 vs 49.9, B = 2: 36.2 vs 42.0, B = 1: 29.6 vs 37.3.  T2S_DECODE_STREAM_MAXB overrides)
+        static const int stream_max_b = getenv("T2S_DECODE_STREAM_MAXB") ? atoi(getenv("T2S_DECODE_STREAM_MAXB")) : 4;
+        if (want_stream && d->gate_part && B <= stream_max_b && !d->teacher_forced && fused_att && q_parts && !ca.gates_out && A == 1024 &&
+            D == 1024) {
             gs.W0 = d->dec_w_hh; gs.ld0 = D; gs.x0 = dh_in; gs.out0 = d->gate_part;
             gs.W1 = d->dec_w_ih; gs.ld1 = A + E; gs.out1 = d->gate_part + GP;
             gs.W2 = d->att_w_hh; gs.ld2 = A; gs.out2 = d->gate_part + 2 * GP; gs.x12 = ah_out;
