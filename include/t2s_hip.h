@@ -54,6 +54,9 @@ int t2s_abi_version(void);
  * to spare - the no-grad WaveGlow forward / infer only; the host side refuses the training path and turns a non-finite result,
  * i.e. an operand plane that overflowed 65504, into an error instead of returning it). */
 int t2s_operand_format(void);
+/* ABI v4.  sizeof(t2s_taco_decoder) / sizeof(t2s_taco_bptt) as this library was compiled: a binding that mirrors the structs field by
+ * field (ctypes, cgo, JNI) checks its own size against these before the first call. */
+int t2s_sizeof_taco_decoder(void);
 const char* t2s_error_string(int code);
 /* last HIP error text seen by a failing entry point on this thread ("" if none) */
 const char* t2s_last_hip_error(void);
@@ -311,6 +314,13 @@ typedef struct t2s_taco_decoder {
      * only adds the query and the processed memory to it: the two exact-f32 matrix-core stages leave the one workgroup the whole
      * launch waits for (4 us at 128 encoder positions, growing linearly with T_in).  State like gate_part. */
     float *ploc;
+    /* ABI v4.  [16][B][4 * dec_rnn] scratch (not state: written before it is read inside one call), or NULL.  Teacher forced at 9+ items
+     * with att_h_all: the decoder cells run a chunk of 16 steps behind the attention chain (helper stream), so the input half of
+     * their pre-activations, W_ih_dec . [h_att(s) | ctx(s)], is ONE matrix product per chunk over 16 x B items - its 25 MB of
+     * weights read once per 16 steps instead of once per step - and the per-step cell streams only W_hh_dec (17 of 42 MB).
+     * Used only with T2S_DECODE_CHUNK_GEMM=1 (measured no faster); otherwise, or NULL: every decoder
+     * cell streams all of [W_ih | W_hh]. */
+    float *dec_in_part;
 } t2s_taco_decoder;
 
 /* Enqueue decoder steps [step0, step0+n_steps) (Decoder.decode, tacotron.py:355-393, plus in autoregressive mode

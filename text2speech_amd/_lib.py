@@ -16,6 +16,7 @@ c_int, c_float, c_vp, c_long = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ct
 SIGNATURES = {
     "t2s_abi_version": [],
     "t2s_operand_format": [],
+    "t2s_sizeof_taco_decoder": [],
     "t2s_error_string": [c_int],
     "t2s_last_hip_error": [],
     "t2s_plane_rows": [c_int, c_int],

@@ -122,6 +122,18 @@ static __device__ __forceinline__ void sb_glds16(const void* gsrc, void* lds_dst
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
+// the weight rows: read once per launch by ONE workgroup - the textbook case for nt (MI355X_MICROARCH.md nt-weights, aux = 2), and
+// measured NEGATIVE here (-DT2S_SB_NT_WEIGHTS, profiles/r04_cache_policy_ab.txt, same box, alternating): teacher-forced forward at
+// B = 32 35.98 / 35.86 against 34.35 / 34.54 ms, train step 93.5 / 92.7 against 89.3 / 90.1 ms.  Default policy is what ships.
+#ifdef T2S_SB_NT_WEIGHTS
+#define SB_W_AUX 2
+#else
+#define SB_W_AUX 0
+#endif
+static __device__ __forceinline__ void sb_glds16w(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, SB_W_AUX);
+}
 
 // HALF: the workgroup takes 16 items instead of 32 (no second B fragment): for launches whose row count fills less than half the
 // chip - the per-CU fill is what bounds the kernel, and two workgroups with half the input vectors each pull 2/3 of the bytes per CU
@@ -157,12 +169,12 @@ static __device__ __forceinline__ void sb_core(const SbOperands& o, size_t grow_
         else { xp = o.x2 + (k - o.n0 - o.n1); sx = o.sx2; }
         char* dst = my + slot_in * SB_SLOT;
         if constexpr (KW == 16) {
-            sb_glds16(wbase + grow_of_r16 * wld + dp * 4, dst);
+            sb_glds16w(wbase + grow_of_r16 * wld + dp * 4, dst);
             sb_glds16(xp + dp * 4 + ia0 * sx, dst + 1024);
             if constexpr (!HALF) sb_glds16(xp + dp * 4 + ib0 * sx, dst + 2048);
         } else {
-            sb_glds16(wbase + grow_lo8 * wld + dp * 4, dst);
-            sb_glds16(wbase + grow_hi8 * wld + dp * 4, dst + 1024);
+            sb_glds16w(wbase + grow_lo8 * wld + dp * 4, dst);
+            sb_glds16w(wbase + grow_hi8 * wld + dp * 4, dst + 1024);
             sb_glds16(xp + dp * 4 + ia0 * sx, dst + 2048);
             sb_glds16(xp + dp * 4 + ia1 * sx, dst + 3072);
             if constexpr (!HALF) {
@@ -332,7 +344,7 @@ hipError_t t2s_launch_sbgemm_plain(const GemvArgs& a, hipStream_t stream) {
     static const bool half_ok = !(getenv("T2S_SB_HALF") && atoi(getenv("T2S_SB_HALF")) == 0);
     const bool half = half_ok && a.items > 16 && (long)grid.x * ((a.items + 15) / 16) <= 256;
     if (half) grid.y = (a.items + 15) / 16;
-    if (sb_wide_ok(a.n1 + a.n2 + a.n3, a.k1, a.n1, a.n2, a.n3))
+    if (!a.narrow_ring && sb_wide_ok(a.n1 + a.n2 + a.n3, a.k1, a.n1, a.n2, a.n3))
         return half ? sb_launch<32, GemvArgs, 1>(sbgemm_plain_kernel<32, true>, a, grid, stream) : sb_launch<32>(sbgemm_plain_kernel<32>, a, grid, stream);
     return half ? sb_launch<16, GemvArgs, 1>(sbgemm_plain_kernel<16, true>, a, grid, stream) : sb_launch<16>(sbgemm_plain_kernel<16>, a, grid, stream);
 #else
@@ -360,6 +372,16 @@ __global__ __launch_bounds__(512) void sbgemm_lstm_kernel(const LstmCellArgs a) 
     __shared__ float s_hq[4][32];
     f32x4 wq = {0.f, 0.f, 0.f, 0.f};
     if (a.q_part) wq = *(const f32x4*)(a.w_q + (size_t)(threadIdx.x & 127) * a.H + u0);
+    // partial pre-activations (LstmCellArgs::pre_a, [B][4H]: the input half of the product, computed for a whole chunk of steps by
+    // one GEMM - t2s_taco_decoder::dec_in_part): requested in front of the K loop, added in the epilogue
+    float pre[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.pre_a && threadIdx.x < 128) {
+        const int item = item_base + (threadIdx.x >> 2), u = u0 + (threadIdx.x & 3);
+        if (item < a.B) {
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) pre[gi] = a.pre_a[(size_t)item * 4 * a.H + (size_t)gi * a.H + u];
+        }
+    }
     sb_core<KW>(o, wrow(threadIdx.x & 15), true, item_base, s_part, sb_ring, wrow(dr), wrow(dr + 8));
     if (threadIdx.x < 128) s_hq[threadIdx.x & 3][threadIdx.x >> 2] = 0.f;
     if (threadIdx.x < 128) {
@@ -369,7 +391,7 @@ __global__ __launch_bounds__(512) void sbgemm_lstm_kernel(const LstmCellArgs a) 
             float g[4];
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi)
-                g[gi] = sb_sum<KW>(s_part, sb_ring, ul * 4 + gi, it) + (a.b_ih[gi * a.H + u] + a.b_hh[gi * a.H + u]);
+                g[gi] = (sb_sum<KW>(s_part, sb_ring, ul * 4 + gi, it) + pre[gi]) + (a.b_ih[gi * a.H + u] + a.b_hh[gi * a.H + u]);
             const size_t idx = (size_t)item * a.H + u;
             const float gi_ = sb_sigmoid(g[0]), gf = sb_sigmoid(g[1]), gg = tanhf(g[2]), go_ = sb_sigmoid(g[3]);
             const float c2 = gf * a.c[idx] + gi_ * gg;
@@ -402,7 +424,8 @@ __global__ __launch_bounds__(512) void sbgemm_lstm_kernel(const LstmCellArgs a) 
 }
 
 bool t2s_sbgemm_lstm_ok(const LstmCellArgs& a) {
-    if (a.B <= 8 || (a.H & 15) || (a.n1 & 15) || (a.n2 & 15) || a.pre_a || !a.h_in || a.ld_ih > 0) return false;
+    if (a.B <= 8 || (a.H & 15) || (a.n1 & 15) || (a.n2 & 15) || a.pre_b || !a.h_in || a.ld_ih > 0 || a.w_p2) return false;
+    if (a.n1 > 0 && !a.x1) return false;
     if (a.q_part && (a.q_dim != 128 || !a.w_q || ((uintptr_t)a.w_q & 15))) return false;
     if ((a.sx1 & 3) || (a.x2 && (a.sx2 & 3))) return false;
     if (((uintptr_t)a.W_ih & 15) || ((uintptr_t)a.W_hh & 15) || ((uintptr_t)a.x1 & 15) || ((uintptr_t)a.x2 & 15) ||

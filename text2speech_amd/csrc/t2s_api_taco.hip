@@ -197,6 +197,14 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
     // Streamed gate partials (ABI v4, t2s_taco_decoder::gate_part): autoregressive small-batch decode only.  T2S_DECODE_STREAM=0: off.
     static const bool want_stream = !(getenv("T2S_DECODE_STREAM") && atoi(getenv("T2S_DECODE_STREAM")) == 0);
     const size_t GP = (size_t)B * 4 * A;                   // one [B][4H] block of gate_part
+    // Decoder cells a chunk behind the chain (split): the input half of their pre-activations as ONE product per chunk
+    // (t2s_taco_decoder::dec_in_part, 16 steps of scratch).  Built and measured NEGATIVE (profiles/r04_taco_chunk_gemm_ab.txt, same
+    // box, alternating: teacher-forced forward at B = 32 35.5 / 35.6 with it against 35.0 / 34.7 ms, train step equal): the small-batch
+    // GEMM kernel re-reads its 16 weight rows per group of 32 items and the 32 input vectors per 16 rows (1.2 GB of L2 reads per
+    // 512-item chunk), which costs what the per-step cells save.  Off unless T2S_DECODE_CHUNK_GEMM=1.
+    static const bool want_chunk_gemm = getenv("T2S_DECODE_CHUNK_GEMM") && atoi(getenv("T2S_DECODE_CHUNK_GEMM")) != 0;
+    const bool chunk_gemm = split && want_chunk_gemm && d->dec_in_part && B > 8 && !((A | D | E) & 31);
+    int part_c0 = 0;                                       // first step of the chunk whose products dec_in_part holds
     auto body = [&](int s, bool do_att, bool do_dec) -> int {
         float* ah_in = (s & 1) ? d->att_h1 : d->att_h0;
         float* ah_out = (s & 1) ? d->att_h0 : d->att_h1;
@@ -316,6 +324,11 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
             cd.W_ih = d->dec_w_ih + A; cd.ld_ih = A + E; cd.x1 = d->ctx; cd.n1 = E; cd.sx1 = E; cd.x2 = nullptr; cd.n2 = 0; cd.sx2 = 0;
             cd.h_in = nullptr; cd.pre_a = d->gate_part; cd.pre_b = d->gate_part + GP;
         }
+        if (chunk_gemm) {
+            // W_ih . [h_att(s) | ctx(s)] is in dec_in_part[s - part_c0]: only W_hh . h_dec(s-1) is left to stream (17 of 42 MB)
+            cd.x1 = nullptr; cd.n1 = 0; cd.sx1 = 0; cd.x2 = nullptr; cd.n2 = 0; cd.sx2 = 0;
+            cd.pre_a = d->dec_in_part + (size_t)(s - part_c0) * B * 4 * D;
+        }
         if (d->dec_drop) { cd.drop_mask = d->dec_drop + (size_t)s * B * D; cd.drop_scale = d->dec_drop_scale; }
         if (d->teacher_forced) { cd.h_copy = d->hc_all + (size_t)s * B * (D + E); cd.s_copy = D + E; }
         if (d->dec_gates_all) { cd.gates_out = d->dec_gates_all + (size_t)s * B * 4 * D; cd.c_out = d->dec_c_all + (size_t)s * B * D; }
@@ -374,12 +387,24 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         // the attention chain of `chunk` steps, ONE event, then the decoder cells of those steps on the helper stream while the
         // caller's stream goes on with the next chunk (T2S_DECODE_CHUNK, default 16)
         static const int chunk_env = getenv("T2S_DECODE_CHUNK") ? atoi(getenv("T2S_DECODE_CHUNK")) : 16;
-        const int chunk = chunk_env > 0 ? chunk_env : 1;
+        int chunk = chunk_env > 0 ? chunk_env : 1;
+        if (chunk_gemm && chunk > 16) chunk = 16;          // (dec_in_part holds 16 steps)
         for (int c0 = step0; c0 < step0 + n_steps; c0 += chunk) {
             const int c1 = c0 + chunk < step0 + n_steps ? c0 + chunk : step0 + n_steps;
             for (int s = c0; s < c1; ++s) { const int rc = body(s, true, false); if (rc != T2S_OK) return rc; }
             T2S_CHECK_HIP(hipEventRecord(hs.ev_step, stream));        // h_att, ctx of the chunk saved (and all earlier work of the caller)
             T2S_CHECK_HIP(hipStreamWaitEvent(hs.side, hs.ev_step, 0));
+            if (chunk_gemm) {
+                GemvArgs g;
+                memset(&g, 0, sizeof(g));
+                g.W1 = d->dec_w_ih; g.ld1 = A + E; g.k1 = A + E;
+                g.x1 = d->att_h_all + (size_t)c0 * B * A; g.n1 = A; g.sx1 = A;
+                g.x2 = d->hc_all + (size_t)c0 * B * (D + E) + D; g.n2 = E; g.sx2 = D + E;
+                g.y = d->dec_in_part; g.sy_item = 4 * D; g.sy_row = 1; g.rows = 4 * D; g.items = (c1 - c0) * B; g.mask_scale = 1.f;
+                if (!gemv_args_ok(g)) return T2S_EINVAL;
+                T2S_CHECK_HIP(t2s_launch_gemv(g, hs.side));
+                part_c0 = c0;
+            }
             for (int s = c0; s < c1; ++s) { const int rc = body(s, false, true); if (rc != T2S_OK) return rc; }
         }
     } else {

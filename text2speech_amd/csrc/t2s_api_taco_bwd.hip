@@ -33,8 +33,16 @@ BpttStreams g_bptt[kMaxDevices];
 hipError_t bptt_streams_init(BpttStreams& s) {      // caller holds s.mu; the current device is the one s belongs to
     if (s.ready) return hipSuccess;
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking)) != hipSuccess) return e;
-    if ((e = hipStreamCreateWithFlags(&s.side2, hipStreamNonBlocking)) != hipSuccess) return e;
+    // T2S_HELPER_PRIO: stream priority of the helpers (HIP: lower number = higher priority; the range is clamped to the device's).
+    // The helpers carry the chains nothing waits for per step (decoder cells), so a LOWER priority than the caller's stream lets the
+    // serial chain's workgroups go first whenever both have some pending.
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);         // lo = least (largest number), hi = greatest
+    int prio = getenv("T2S_HELPER_PRIO") ? atoi(getenv("T2S_HELPER_PRIO")) : 0;
+    prio = prio > lo ? lo : (prio < hi ? hi : prio);
+    if ((e = hipStreamCreateWithPriority(&s.side, hipStreamNonBlocking, prio)) != hipSuccess) return e;
+    if ((e = hipStreamCreateWithPriority(&s.side2, hipStreamNonBlocking, prio)) != hipSuccess) return e;
+    if (getenv("T2S_HELPER_PRIO")) fprintf(stderr, "[t2s] helper streams at priority %d (device range %d .. %d)\n", prio, hi, lo);
     hipEvent_t* evs[] = {&s.ev_main, &s.ev_side, &s.ev_energy, &s.ev_conv, &s.ev_join};
     for (hipEvent_t* ev : evs)
         if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return e;
@@ -171,10 +179,18 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
     // stream waits once per chunk: a cross-stream wait costs ~6 us on the critical stream (profiles/r03_taco_timeline_bwd_fused.md).
     static const int chunk_env = getenv("T2S_BPTT_CHUNK") ? atoi(getenv("T2S_BPTT_CHUNK")) : 16;
     const int chunk = two_streams ? (chunk_env > 0 ? chunk_env : 1) : 1;
-    // T2S_BPTT_SPLIT_ROWS=1 (two streams, 9+ items): the transposed decoder-cell GEMM [KD = A + E + D rows] x [4 D] of every step is
+    // Two streams, 9+ items: the transposed decoder-cell GEMM [KD = A + E + D rows] x [4 D] of every step is
     // split by consumer - the D rows of d h_dec(t-1), which the next decoder-cell step needs, per step; the A + E rows of d h_att /
     // d ctx, which only the attention chain reads (a chunk of steps later), as ONE launch over the chunk's (steps x batch) items
-    static const bool want_split_rows = getenv("T2S_BPTT_SPLIT_ROWS") && atoi(getenv("T2S_BPTT_SPLIT_ROWS")) != 0;
+    // (-1 % of the train step: 88.45 / 88.2 / 87.8 / 88.2 against 89.4 / 89.7 / 89.5 / 89.5 ms in three same-box sessions,
+    // profiles/r04_taco_bptt_streams_ab.txt, r04_taco_bptt_narrow_ab.txt, r04_taco_chunk_gemm_ab.txt.  T2S_BPTT_SPLIT_ROWS=0: off)
+    static const bool want_split_rows = !(getenv("T2S_BPTT_SPLIT_ROWS") && atoi(getenv("T2S_BPTT_SPLIT_ROWS")) == 0);
+    // T2S_BPTT_SIDE_NARROW=1: the decoder-cell chain's GEMM (helper stream) on the 96 KB ring, so that the attention chain's
+    // att_bwd_fused workgroups (61 KB of LDS) can share its CUs instead of queueing behind it.  Measured NEGATIVE: 96.6 / 96.3
+    // against 89.5 / 90.0 ms per train step (profiles/r04_taco_bptt_narrow_ab.txt) - the 64-byte fragment rows cost the GEMM more
+    // CU time than the sharing returns; the loop is the sum of its kernels' CU time.  Off.
+    static const bool want_narrow = getenv("T2S_BPTT_SIDE_NARROW") && atoi(getenv("T2S_BPTT_SIDE_NARROW")) != 0;
+    const bool side_narrow = want_narrow && two_streams;
     const bool split_rows = want_split_rows && two_streams && chunk > 1 && B > 8 && ((A + E) & 15) == 0 && (D & 15) == 0;
     for (int tc = t_hi - 1; tc >= t_lo; tc -= chunk) {
     const int tl = tc - chunk + 1 > t_lo ? tc - chunk + 1 : t_lo;
@@ -195,6 +211,7 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         memset(&g, 0, sizeof(g));
         g.W1 = p->W_dT; g.ld1 = 4 * D; g.k1 = 4 * D; g.x1 = cd.dgates; g.n1 = 4 * D; g.sx1 = 4 * D;
         g.y = p->out_d + (size_t)t * B * KD; g.sy_item = KD; g.sy_row = 1; g.rows = KD; g.items = B; g.mask_scale = 1.f;
+        g.narrow_ring = side_narrow ? 1 : 0;
         if (split_rows) {
             // only the rows the NEXT decoder-cell step reads (d h_dec(t-1) = rows A + E .. KD of [W_ih | W_hh]^T dgates) stay per step;
             // the d h_att / d ctx rows, which the attention chain reads a chunk later, are one GEMM over the chunk's items below

@@ -30,6 +30,9 @@ struct GemvArgs {
     float* y2; long sy2_item; long sy2_row;
     int act2;
     const unsigned char* mask2; long smask2_item; float mask2_scale;
+    // small-batch GEMM only: the 96 KB operand ring (64-byte fragment rows) instead of the 144 KB one, so that a 61 KB workgroup of
+    // another stream's kernel (att_bwd_fused_kernel) fits on the same CU - for launches on a helper stream with slack
+    int narrow_ring;
 };
 
 struct LstmCellArgs {
@@ -106,6 +109,7 @@ struct AttArgs {
     // positions, growing linearly) and only adds q and the processed memory
     const float* ploc;
     float* wcum_save;          // optional [B][T]: cumulative weights after this step (training)
+    int tile_major;            // att_energy_mfma_kernel: block -> (tile, item) in launch order instead of item-per-XCD (A/B: T2S_ENERGY_XCD=0)
 };
 
 // Role-specialised second half of the projection launch (B <= 8 autoregressive decode): while 85 workgroups run the 337 x 1536 GEMV,

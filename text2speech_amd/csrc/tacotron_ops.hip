@@ -311,8 +311,17 @@ hipError_t t2s_launch_gemv_with_loc(const GemvArgs& a, const LocPreArgs& lp_in, 
 #else
 #define T2S_WLOAD(p) __builtin_nontemporal_load(p)
 #endif
+// With the streamed gate partials (LstmCellArgs::pre_a) a cell reads 8-13 MB per step, and those columns are better loaded with the
+// default policy while the attention launch's 50 MB stream stays nt: 29.04 / 29.04 vs 29.70 / 29.33 us per step at B = 1, same box
+// (profiles/r04_cache_policy_ab.txt; all-plain: 31.4 / 31.3; the unstreamed chain prefers nt in the cells: 37.5-37.7 vs 38.3-38.7).
+// -DT2S_CELL_NT_LOADS: nt in the streamed cells too (the A/B's other side).
+#ifdef T2S_CELL_NT_LOADS
+#define T2S_CLOAD(p) T2S_WLOAD(p)
+#else
+#define T2S_CLOAD(p) (*(p))
+#endif
 
-template <int NVW, int UNITS, bool SAVE>
+template <int NVW, int UNITS, bool SAVE, bool STREAMED = false>
 __global__ __launch_bounds__(UNITS * 256) void lstm_cell_kernel(const LstmCellArgs a) {
     PROBE_BEGIN(200 + NVW)
     __shared__ float s_part[UNITS][4][4][64];        // [unit][kq][gate][item]
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(UNITS * 256) void lstm_cell_kernel(const LstmCellAr
         for (int g = 0; g < 4; ++g) {
             const size_t row = (size_t)g * a.H + u;
             const float* wp = kc < K1 ? a.W_ih + row * ldi + kc : a.W_hh + row * a.H + (kc - K1);
-            w[g][j] = T2S_WLOAD((const f32x4*)wp);
+            w[g][j] = STREAMED ? T2S_CLOAD((const f32x4*)wp) : T2S_WLOAD((const f32x4*)wp);
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -468,7 +477,7 @@ __global__ __launch_bounds__(768) void lstm_cell_p2_kernel(const LstmCellArgs a)
     // LSTM rows (HBM, non-temporal: read once per step by this wave)
     f32x4 w[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) w[g] = T2S_WLOAD((const f32x4*)(a.W_ih + ((size_t)g * a.H + u) * ldi + kq * 256 + 4 * lane));
+    for (int g = 0; g < 4; ++g) w[g] = T2S_CLOAD((const f32x4*)(a.W_ih + ((size_t)g * a.H + u) * ldi + kq * 256 + 4 * lane));
     // prenet: this wave's 64-entry segment of pre1 (three waves share a segment and take its entries k = sub, sub + 3, ...)
     const int seg = wave & 3, sub = wave >> 2;
     float p1 = a.p1[seg * 64 + lane];
@@ -579,6 +588,7 @@ hipError_t t2s_launch_lstm_cell(const LstmCellArgs& a, hipStream_t stream) {
 #define LL(N)                                                                                                     \
     do {                                                                                                          \
         if (a.gates_out) hipLaunchKernelGGL((lstm_cell_kernel<N, 2, true>), dim3(a.H / 2), dim3(512), 0, stream, a); \
+        else if (a.pre_a) hipLaunchKernelGGL((lstm_cell_kernel<N, 4, false, true>), dim3(a.H / 4), dim3(1024), 0, stream, a); \
         else hipLaunchKernelGGL((lstm_cell_kernel<N, 4, false>), dim3(a.H / 4), dim3(1024), 0, stream, a);          \
     } while (0)
     if (a.w_p2) {           // folded prenet layer 1 (lstm_cell_p2_kernel): K = 256 (pre2) + 512 (context), W_hh . h streamed earlier
@@ -785,7 +795,15 @@ __global__ __launch_bounds__(512) void att_energy_mfma_kernel(const AttArgs a) {
     float (*s_e)[ATT_MQ] = (float (*)[ATT_MQ])s_kb;      // [8][32] partial energies (after the features: s_kb is free)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int b = blockIdx.y, t0 = blockIdx.x * ATT_MQ;
+    // Block -> (item, tile of 32 positions): all tiles of one item on ONE XCD (workgroups go round the 8 XCDs by block number), so
+    // that the item's 128 KB of partial queries cross the fabric once and its other tiles find them in that XCD's L2 - with the
+    // plain (tile, item) grid every XCD pulled every item's partials (32 MB per launch at B = 32, T = 256 instead of 4 MB).
+    const int n_tiles = (a.T + ATT_MQ - 1) / ATT_MQ;
+    const int slot = blockIdx.x >> 3;
+    int b = (slot / n_tiles) * 8 + (blockIdx.x & 7), tile = slot - (slot / n_tiles) * n_tiles;
+    if (a.tile_major) { b = blockIdx.x / n_tiles; tile = blockIdx.x - b * n_tiles; }
+    if (b >= a.B) return;
+    const int t0 = tile * ATT_MQ;
     const int T = a.T, KS = a.loc_ks, pad = KS >> 1, K2 = 2 * KS;
     for (int i = tid; i < 2 * 64 * 16; i += 512) s_kb[i] = 0.f;
     for (int i = tid; i < 2 * (ATT_MQ + KS - 1); i += 512) {
@@ -845,7 +863,7 @@ __global__ __launch_bounds__(512) void att_energy_mfma_kernel(const AttArgs a) {
 #pragma unroll
         for (int p16 = 0; p16 < 16; ++p16) q += s_qp[p16][ach];
         qv = q;
-        if (blockIdx.x == 0 && lq == 0) {
+        if (tile == 0 && lq == 0) {
             if (a.q_out) a.q_out[(size_t)b * AD + ach] = q;
             if (a.q_save) a.q_save[(size_t)b * AD + ach] = q;
         }
@@ -901,8 +919,11 @@ hipError_t t2s_launch_att_energy(const AttArgs& a, hipStream_t stream) {
     static const bool no_mfma = getenv("T2S_ATT_VALU") != nullptr;
     if (!no_mfma && a.att_dim == 128 && a.loc_f == 32 && a.loc_ks <= 31 && a.w_loc_denseT) {
         if (a.q_part && a.n_part != 256) return hipErrorInvalidValue;
-        dim3 grid((a.T + ATT_MQ - 1) / ATT_MQ, a.B);
-        hipLaunchKernelGGL(att_energy_mfma_kernel, grid, dim3(512), 0, stream, a);
+        static const bool plain = getenv("T2S_ENERGY_XCD") && atoi(getenv("T2S_ENERGY_XCD")) == 0;
+        AttArgs aa = a;
+        aa.tile_major = plain ? 1 : 0;
+        dim3 grid(8 * ((a.B + 7) / 8) * ((a.T + ATT_MQ - 1) / ATT_MQ));
+        hipLaunchKernelGGL(att_energy_mfma_kernel, grid, dim3(512), 0, stream, aa);
         return hipGetLastError();
     }
     if (a.q_part) return hipErrorInvalidValue;          // (only the matrix-core kernel sums partial queries)

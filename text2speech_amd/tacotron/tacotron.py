@@ -241,7 +241,7 @@ class _DecoderStruct(ctypes.Structure):
     _F = ["att_drop_scale", "dec_drop_scale"]
     _P2 = ["att_h0", "att_h1", "att_c", "dec_h0", "dec_h1", "dec_c", "att_w", "att_wcum", "ctx", "q", "energies",
            "pre1", "pre2", "q_part", "mel_gate_out", "align_out", "hc_all", "att_gates_all", "att_c_all",
-           "dec_gates_all", "dec_c_all", "att_h_all", "q_all", "wcum_all", "gate_part", "w_pre2T", "ploc"]
+           "dec_gates_all", "dec_c_all", "att_h_all", "q_all", "wcum_all", "gate_part", "w_pre2T", "ploc", "dec_in_part"]
     _fields_ = ([(n, ctypes.c_int) for n in _I] + [(n, ctypes.c_void_p) for n in _P1] +
                 [(n, ctypes.c_float) for n in _F] + [(n, ctypes.c_void_p) for n in _P2])
 
@@ -843,6 +843,9 @@ class _TacoEngine:
             # off the serial chain (helper stream, a chunk of steps behind the attention chain: t2s_taco_decode_steps) exactly as in
             # training - the only save that path needs besides hc_all
             extra["att_h_all"] = torch.empty(T_out, B, dec.attention_rnn_dim, dtype=torch.float32, device=dev)
+        if B > 8 and extra.get("att_h_all") is not None:
+            # scratch of the decoder cells' per-chunk input product (t2s_taco_decoder::dec_in_part: 16 steps x B items x 4 D)
+            extra["dec_in_part"] = torch.empty(16, B, 4 * D, dtype=torch.float32, device=dev)
         d, S = self._decoder_struct(memory, len32, T_out, True, extra)
         if m.training:
             d.att_drop_scale = 1.0 / (1.0 - dec.p_attention_dropout)
