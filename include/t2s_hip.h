@@ -250,11 +250,26 @@ int t2s_zero_fill(void* p, size_t bytes, void* stream);
 int t2s_taco_encoder_lstm(const float* gx, const float* whhT_fwd, const float* whhT_rev, const int* lengths, float* out,
                           int B, int T, int H, int T_out, float* gates_save /* [B][T][2][4H] or NULL */,
                           float* c_save /* [B][T][2][H] or NULL */, void* stream);
+/* ABI v4.  The same recurrence with W_hh resident on the chip: four workgroups per (batch element, direction), each with a quarter
+ * of the matrix in registers for the whole sequence, exchange their 64 new h values per step through tagged 8-byte granules in
+ * `xbuf` (t2s_taco_lstm_xbuf_bytes(B) bytes, caller-owned, ZERO before its first use, not shared by launches that may overlap in
+ * time; the last 8 bytes are an error word the kernel raises if a bounded wait expires - a caller that wants to know reads it
+ * after synchronising).  `epoch` is the caller's launch counter for this buffer (any value that differs from the previous launches'
+ * in its low 20 bits): tags of an earlier launch never match.  Same results as t2s_taco_encoder_lstm up to summation order.
+ * H must be 256, T < 4095. */
+int t2s_taco_encoder_lstm_split(const float* gx, const float* whhT_fwd, const float* whhT_rev, const int* lengths, float* out,
+                                int B, int T, int H, int T_out, float* gates_save, float* c_save, void* xbuf, unsigned epoch,
+                                void* stream);
+long t2s_taco_lstm_xbuf_bytes(int B);
 /* BPTT of that recurrence: d_out[B][T_out][2H] -> dgx[B][T][8H] (zero beyond each length), hprev[B][T][2H] (the h each
  * step consumed; the X operand of the W_hh weight-gradient GEMM); whh_* are the natural [4H][H] matrices */
 int t2s_taco_encoder_lstm_bwd(const float* d_out, const float* out, const float* gates_save, const float* c_save,
                               const float* whh_fwd, const float* whh_rev, const int* lengths, float* dgx, float* hprev,
                               int B, int T, int H, int T_out, void* stream);
+/* ABI v4.  ... and its BPTT in the same form (xbuf / epoch as above; a buffer of its own if a forward may be in flight). */
+int t2s_taco_encoder_lstm_bwd_split(const float* d_out, const float* out, const float* gates_save, const float* c_save,
+                                    const float* whh_fwd, const float* whh_rev, const int* lengths, float* dgx, float* hprev,
+                                    int B, int T, int H, int T_out, void* xbuf, unsigned epoch, void* stream);
 /* f32 channel-last rows x[b][t][c] -> planes ; embedding gradient d_emb[v][e] = sum over (b,t) with ids == v of planes */
 int t2s_rows_to_planes(const float* x, int B, int T, int C, int Lp, int halo, void* X_hi, void* X_lo, void* stream);
 int t2s_embedding_grad(const long* ids, const void* D_hi, const void* D_lo, int B, int T, int E, int V, int Lp, int halo,

@@ -100,6 +100,66 @@ def test_encoder_vs_golden(model, golden_dir):
     assert _rel(memory, g2["enc"]) < 1e-3 and _maxrel(memory, g2["enc"]) < 1e-3
 
 
+@pytest.mark.parametrize("B,T,lens", [(5, 23, [23, 20, 17, 5, 1]), (1, 64, None), (12, 40, [40] * 6 + [31, 30, 9, 8, 2, 2])])
+def test_split_bilstm_recurrence_matches_one_workgroup_kernels(B, T, lens):
+    """t2s_taco_encoder_lstm_split / _bwd_split (W_hh resident over four workgroups per (element, direction), h exchanged per step
+    through tagged granules) against the one-workgroup kernels on the same inputs: same sums in another order (1e-5), ragged lengths,
+    a group count that is not a multiple of 8 (whole blocks of the grid exit), two launches on one buffer (second epoch), and the
+    buffer's error word (no bounded wait expired).  The golden / oracle tests above and the gradient tests run through the split
+    kernels too - this one isolates them."""
+    from text2speech_amd import _lib
+    H = 256
+    gen = torch.Generator().manual_seed(B * 100 + T)
+    gx = (torch.randn(B, T, 8 * H, generator=gen) * 0.5).to(DEV)
+    whhT = [(torch.randn(H, 4 * H, generator=gen) * 0.06).to(DEV) for _ in range(2)]
+    whh = [w.t().contiguous() for w in whhT]
+    len32 = None if lens is None else torch.tensor(lens, dtype=torch.int32, device=DEV)
+    T_out = T if lens is None else max(lens)
+    st = _lib.current_stream()
+    n = _lib.load().t2s_taco_lstm_xbuf_bytes(B)
+    xbuf = torch.zeros(n // 8, dtype=torch.int64, device=DEV)
+
+    def fwd(split, epoch):
+        out = torch.full((B, T_out, 2 * H), float("nan"), device=DEV)
+        gs = torch.zeros(B, T, 2, 4 * H, device=DEV)
+        cs = torch.zeros(B, T, 2, H, device=DEV)
+        if split:
+            _lib.call("t2s_taco_encoder_lstm_split", _lib.ptr(gx), _lib.ptr(whhT[0]), _lib.ptr(whhT[1]), _lib.ptr(len32), _lib.ptr(out),
+                      B, T, H, T_out, _lib.ptr(gs), _lib.ptr(cs), _lib.ptr(xbuf), epoch, st)
+        else:
+            _lib.call("t2s_taco_encoder_lstm", _lib.ptr(gx), _lib.ptr(whhT[0]), _lib.ptr(whhT[1]), _lib.ptr(len32), _lib.ptr(out),
+                      B, T, H, T_out, _lib.ptr(gs), _lib.ptr(cs), st)
+        return out, gs, cs
+
+    o0, g0, c0 = fwd(False, 0)
+    for epoch in (1, 2):
+        o1, g1, c1 = fwd(True, epoch)
+        torch.cuda.synchronize()
+        assert int(xbuf[-1].item()) == 0, "a hand-off wait expired"
+        assert not torch.isnan(o1).any()
+        for a, b in ((o1, o0), (g1, g0), (c1, c0)):
+            assert float((a - b).abs().max()) < 1e-5
+    d_out = torch.randn(B, T_out, 2 * H, generator=gen).to(DEV)
+
+    def bwd(split, epoch):
+        dgx = torch.zeros(B, T, 8 * H, device=DEV)
+        hp = torch.zeros(B, T, 2 * H, device=DEV)
+        args = [_lib.ptr(d_out), _lib.ptr(o0), _lib.ptr(g0), _lib.ptr(c0), _lib.ptr(whh[0]), _lib.ptr(whh[1]), _lib.ptr(len32),
+                _lib.ptr(dgx), _lib.ptr(hp), B, T, H, T_out]
+        if split:
+            _lib.call("t2s_taco_encoder_lstm_bwd_split", *args, _lib.ptr(xbuf), epoch, st)
+        else:
+            _lib.call("t2s_taco_encoder_lstm_bwd", *args, st)
+        return dgx, hp
+
+    d0, h0 = bwd(False, 0)
+    for epoch in (3, 4):
+        d1, h1 = bwd(True, epoch)
+        torch.cuda.synchronize()
+        assert int(xbuf[-1].item()) == 0, "a hand-off wait expired"
+        assert float((d1 - d0).abs().max()) < 1e-4 * max(1.0, float(d0.abs().max())) and torch.equal(h1, h0)
+
+
 def test_inference_vs_golden(model, golden_dir):
     """BASELINE configs[0]: 64 symbols -> 200 forced frames, B=1, the reference's own dropout draws."""
     g = np.load(os.path.join(golden_dir, "tacotron_infer.npz"))

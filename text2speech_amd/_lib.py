@@ -62,6 +62,9 @@ SIGNATURES = {
                      c_vp, c_vp, c_vp],
     "t2s_taco_encoder_lstm": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
     "t2s_taco_encoder_lstm_bwd": [c_vp] * 9 + [c_int] * 4 + [c_vp],
+    "t2s_taco_encoder_lstm_split": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, ctypes.c_uint, c_vp],
+    "t2s_taco_lstm_xbuf_bytes": [c_int],
+    "t2s_taco_encoder_lstm_bwd_split": [c_vp] * 9 + [c_int] * 4 + [c_vp, ctypes.c_uint, c_vp],
     "t2s_rows_to_planes": [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp],
     "t2s_embedding_grad": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp],
     "t2s_bn_running_update": [c_vp, c_vp, c_vp, c_vp, c_vp, c_float, ctypes.c_longlong, c_int, c_vp],
@@ -117,7 +120,7 @@ SIGNATURES = {
     "t2s_adam_table": [c_vp, c_int, c_long, c_float, c_float, c_float, c_float, c_int, c_float, c_float, c_vp],
 }
 _RESTYPE = {"t2s_error_string": ctypes.c_char_p, "t2s_last_hip_error": ctypes.c_char_p,
-            "t2s_small_wgrad_scratch": ctypes.c_long}
+            "t2s_small_wgrad_scratch": ctypes.c_long, "t2s_taco_lstm_xbuf_bytes": ctypes.c_long}
 
 
 class T2SError(RuntimeError):

@@ -113,6 +113,20 @@ int t2s_taco_encoder_lstm(const float* gx, const float* whhT_fwd, const float* w
     return T2S_OK;
 }
 
+long t2s_taco_lstm_xbuf_bytes(int B) { return B > 0 ? ((long)2 * B * 2 * 256 + 1) * 8 : -1; }
+
+int t2s_taco_encoder_lstm_split(const float* gx, const float* whhT_fwd, const float* whhT_rev, const int* lengths, float* out,
+                                int B, int T, int H, int T_out, float* gates_save, float* c_save, void* xbuf, unsigned epoch,
+                                void* stream) {
+    if (!gx || !whhT_fwd || !whhT_rev || !out || !xbuf || B <= 0 || T <= 0 || T >= 4095 || T_out <= 0 || T_out > T || H != 256 ||
+        ((uintptr_t)xbuf & 7))
+        return T2S_EINVAL;
+    if ((gates_save == nullptr) != (c_save == nullptr)) return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_lstm_seq_split(gx, whhT_fwd, whhT_rev, lengths, out, B, T, T_out, gates_save, c_save,
+                                            (unsigned long long*)xbuf, epoch, (hipStream_t)stream));
+    return T2S_OK;
+}
+
 int t2s_bernoulli_mask(unsigned char* mask, size_t n, unsigned long long seed, unsigned long long offset, float keep_prob,
                        void* stream) {
     if (!mask || n == 0 || !(keep_prob > 0.f && keep_prob <= 1.f)) return T2S_EINVAL;

@@ -343,6 +343,16 @@ int t2s_taco_encoder_lstm_bwd(const float* d_out, const float* out, const float*
                                           T_out, (hipStream_t)stream));
     return T2S_OK;
 }
+int t2s_taco_encoder_lstm_bwd_split(const float* d_out, const float* out, const float* gates_save, const float* c_save,
+                                    const float* whh_fwd, const float* whh_rev, const int* lengths, float* dgx, float* hprev,
+                                    int B, int T, int H, int T_out, void* xbuf, unsigned epoch, void* stream) {
+    if (!d_out || !out || !gates_save || !c_save || !whh_fwd || !whh_rev || !dgx || !hprev || !xbuf || B <= 0 || T <= 0 ||
+        T >= 4095 || H != 256 || T_out <= 0 || T_out > T || ((uintptr_t)xbuf & 7))
+        return T2S_EINVAL;
+    T2S_CHECK_HIP(t2s_launch_lstm_seq_bwd_split(d_out, out, gates_save, c_save, whh_fwd, whh_rev, lengths, dgx, hprev, B, T, T_out,
+                                                (unsigned long long*)xbuf, epoch, (hipStream_t)stream));
+    return T2S_OK;
+}
 int t2s_rows_to_planes(const float* x, int B, int T, int C, int Lp, int halo, void* X_hi, void* X_lo, void* stream) {
     if (!x || !X_hi || !X_lo || B <= 0 || T <= 0 || C <= 0 || Lp < t2s_plane_rows(T, halo)) return T2S_EINVAL;
     T2S_CHECK_HIP(t2s_launch_rows_to_planes(x, B, T, C, Lp, halo, (u16*)X_hi, (u16*)X_lo, (hipStream_t)stream));

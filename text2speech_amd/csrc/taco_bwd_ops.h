@@ -78,6 +78,9 @@ hipError_t t2s_launch_planes_to_f32(const u16* X_hi, const u16* X_lo, int B, int
 hipError_t t2s_launch_sum_axis0(const float* in, int n0, int n, float* out, hipStream_t stream);
 hipError_t t2s_launch_add3(const float* a, const float* b, const float* c, size_t n, float* out, hipStream_t stream);
 hipError_t t2s_launch_scale_by_scalar(const float* in, size_t n, const float* scalar, float mul, float* out, hipStream_t stream);
+hipError_t t2s_launch_lstm_seq_bwd_split(const float* d_out, const float* out, const float* gates, const float* csave,
+                                         const float* whh_f, const float* whh_r, const int* lengths, float* dgx, float* hprev,
+                                         int B, int T, int T_out, unsigned long long* xbuf, unsigned epoch, hipStream_t stream);
 hipError_t t2s_launch_lstm_seq_bwd(const float* d_out, const float* out, const float* gates, const float* csave,
                                    const float* whh_f, const float* whh_r, const int* lengths, float* dgx, float* hprev,
                                    int B, int T, int H, int T_out, hipStream_t stream);

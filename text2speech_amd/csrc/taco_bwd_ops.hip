@@ -1389,6 +1389,130 @@ hipError_t t2s_launch_lstm_seq_bwd(const float* d_out, const float* out, const f
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same BPTT with W_hh RESIDENT (the forward's lstm_seq_split_kernel, csrc/tacotron_ops.hip, has the scheme): four workgroups per
+// (batch element, direction); workgroup q owns the 64 outputs d_h[64 q .. 64 q + 63] and keeps W_hh[:, those 64 columns] (256 KB)
+// in registers - thread (jq, kk) the 64 rows 64 jq .. of column 64 q + kk.  Per step every workgroup redoes the pointwise part for
+// all 256 units (a few hundred flops; its 8 loads per unit are requested one step ahead), multiplies its quarter, and exchanges 64
+// values with the other three through tagged 8-byte granules.  The one-workgroup kernel above streams 1 MB per step through one CU
+// (25 us per step at B = 32: 6.5 ms of a train step, behind which the encoder's whole backward waits).
+#define LSEQB_SPIN_MAX (1 << 22)
+__global__ __launch_bounds__(1024) void lstm_seq_bwd_split_kernel(const float* __restrict__ d_out, const float* __restrict__ out,
+                                                                  const float* __restrict__ gates, const float* __restrict__ csave,
+                                                                  const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                                                  const int* __restrict__ lengths, float* dgx, float* hprev, int B,
+                                                                  int T, int T_out, unsigned long long* xbuf, unsigned epoch) {
+    constexpr int H = 256;
+    __shared__ __attribute__((aligned(16))) float s_dg[4 * H];
+    __shared__ float s_dh[H];
+    __shared__ float s_part[16][64];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x;
+    const int id = blockIdx.x, group = (id >> 5) * 8 + (id & 7), q = (id >> 3) & 3;
+    if (group >= 2 * B) return;                              // (whole workgroups)
+    const int b = group >> 1, dir = group & 1;
+    const int kk = tid & 63, jq = tid >> 6;
+    const float* W = dir ? whh_r : whh_f;                    // [4H][H]
+    const int len = lengths ? lengths[b] : T;
+    float wr[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) wr[i] = W[(size_t)(64 * jq + i) * H + 64 * q + kk];
+    if (tid < H) s_dh[tid] = 0.f;
+    if (tid == 0) s_fail = 0;
+    unsigned long long* xg = xbuf + (size_t)group * 2 * H;
+    const unsigned tag0 = epoch << 12;
+    const int pu = tid >= 64 && tid < 256 ? ((tid - 64) < 64 * q ? (tid - 64) : tid) : 0;
+    const bool mine = tid < H && (tid >> 6) == q;            // the units whose dgx / hprev rows this workgroup writes
+    // operands of the pointwise part of step s, requested one step ahead (thread u < 256)
+    float p_do = 0.f, p_g[4] = {0.f, 0.f, 0.f, 0.f}, p_cn = 0.f, p_cp = 0.f, p_hp = 0.f;
+    auto fetch = [&](int s) {
+        const int t = dir ? s : len - 1 - s;
+        const int tp = dir ? t + 1 : t - 1;
+        const bool has_prev = dir ? (t < len - 1) : (t > 0);
+        const int u = tid;
+        p_do = d_out[((size_t)b * T_out + t) * 2 * H + dir * H + u];
+        const size_t gb = (((size_t)b * T + t) * 2 + dir) * 4 * H + u;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) p_g[gi] = gates[gb + (size_t)gi * H];
+        p_cn = csave[(((size_t)b * T + t) * 2 + dir) * H + u];
+        const int tq = has_prev ? tp : t;                    // (clamped address; dropped below)
+        p_cp = csave[(((size_t)b * T + tq) * 2 + dir) * H + u];
+        p_hp = out[((size_t)b * T_out + tq) * 2 * H + dir * H + u];
+    };
+    if (tid < H && len > 0) fetch(0);
+    float dc = 0.f;
+    __syncthreads();
+    for (int s = 0; s < len; ++s) {
+        const int t = dir ? s : len - 1 - s;                 // reverse of the forward order
+        const bool has_prev = dir ? (t < len - 1) : (t > 0);
+        if (tid < H) {
+            const int u = tid;
+            const float dh = p_do + s_dh[u];
+            const float gi = p_g[0], gf = p_g[1], gg = p_g[2], go = p_g[3];
+            const float cn = p_cn, cp = has_prev ? p_cp : 0.f;
+            const float tc = tanhf(cn);
+            const float dct = dc + dh * go * (1.f - tc * tc);
+            const float d0 = dct * gg * gi * (1.f - gi), d1 = dct * cp * gf * (1.f - gf), d2 = dct * gi * (1.f - gg * gg),
+                        d3 = dh * tc * go * (1.f - go);
+            dc = dct * gf;
+            s_dg[u] = d0; s_dg[H + u] = d1; s_dg[2 * H + u] = d2; s_dg[3 * H + u] = d3;
+            if (mine) {
+                float* o = dgx + ((size_t)b * T + t) * 8 * H + dir * 4 * H + u;
+                o[0] = d0; o[H] = d1; o[2 * H] = d2; o[3 * H] = d3;
+                hprev[((size_t)b * T + t) * 2 * H + dir * H + u] = has_prev ? p_hp : 0.f;
+            }
+            if (s + 1 < len) fetch(s + 1);                   // in flight across the product and the hand-off
+        }
+        __syncthreads();
+        {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 64; i += 4) {
+                const f32x4 d4 = *(const f32x4*)&s_dg[64 * jq + i];
+                acc += (wr[i] * d4[0] + wr[i + 1] * d4[1]) + (wr[i + 2] * d4[2] + wr[i + 3] * d4[3]);
+            }
+            s_part[jq][kk] = acc;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; w += 4) v += (s_part[w][tid] + s_part[w + 1][tid]) + (s_part[w + 2][tid] + s_part[w + 3][tid]);
+            const unsigned long long g = ((unsigned long long)(tag0 + (unsigned)s + 1u) << 32) | (unsigned long long)__float_as_uint(v);
+            __hip_atomic_store(xg + (size_t)(s & 1) * H + 64 * q + tid, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_dh[64 * q + tid] = v;
+        } else if (tid < 256) {
+            float v = 0.f;
+            bool ok = true;
+            if (s + 1 < len) {
+                ok = false;
+                const unsigned want = tag0 + (unsigned)s + 1u;
+                const unsigned long long* slot = xg + (size_t)(s & 1) * H + pu;
+                for (int it = 0; it < LSEQB_SPIN_MAX; ++it) {
+                    const unsigned long long g = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(g >> 32) == want) { v = __uint_as_float((unsigned)g); ok = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            if (!ok) s_fail = 1;
+            s_dh[pu] = v;
+        }
+        __syncthreads();
+        if (s_fail) {
+            if (tid == 0) __hip_atomic_store(xbuf + (size_t)2 * B * 2 * H, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+hipError_t t2s_launch_lstm_seq_bwd_split(const float* d_out, const float* out, const float* gates, const float* csave,
+                                         const float* whh_f, const float* whh_r, const int* lengths, float* dgx, float* hprev,
+                                         int B, int T, int T_out, unsigned long long* xbuf, unsigned epoch, hipStream_t stream) {
+    if (T >= 4095) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lstm_seq_bwd_split_kernel, dim3(((2 * B + 7) / 8) * 32), dim3(1024), 0, stream, d_out, out, gates, csave,
+                       whh_f, whh_r, lengths, dgx, hprev, B, T, T_out, xbuf, epoch & 0xFFFFFu);
+    return hipGetLastError();
+}
+
 // f32 channel-last rows x[b][t][c] -> planes
 __global__ void rows_to_planes_kernel(const float* x, int T, int C, int Lp, int halo, u16* X_hi, u16* X_lo) {
     const int t = blockIdx.x, b = blockIdx.y;

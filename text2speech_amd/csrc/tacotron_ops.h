@@ -134,6 +134,9 @@ hipError_t t2s_launch_att_energy(const AttArgs& a, hipStream_t stream);
 hipError_t t2s_launch_att_softmax_ctx(const AttArgs& a, hipStream_t stream);
 hipError_t t2s_launch_att_fused(const AttArgs& a, hipStream_t stream, const GateStreamArgs* gs = nullptr);
 bool t2s_att_fused_stream_ok(const AttArgs& a, const GateStreamArgs& g);
+hipError_t t2s_launch_lstm_seq_split(const float* gx, const float* whhT_f, const float* whhT_r, const int* lengths, float* out,
+                                     int B, int T, int T_out, float* gates_save, float* c_save, unsigned long long* xbuf,
+                                     unsigned epoch, hipStream_t stream);
 hipError_t t2s_launch_lstm_seq(const float* gx, const float* whhT_f, const float* whhT_r, const int* lengths, float* out,
                                int B, int T, int H, int T_out, float* gates_save, float* c_save, hipStream_t stream);
 hipError_t t2s_launch_transpose(const float* in, float* out, int R, int C, hipStream_t stream);

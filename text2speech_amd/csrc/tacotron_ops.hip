@@ -1823,6 +1823,124 @@ hipError_t t2s_launch_lstm_seq(const float* gx, const float* whhT_f, const float
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same recurrence with W_hh RESIDENT: the matrix of one direction (1 MB) does not fit one CU, a quarter of it (256 KB = 64
+// registers on each of 1024 threads) does.  Four workgroups share one (batch element, direction): workgroup q owns hidden units
+// 64 q .. 64 q + 63 (their four gate rows each), keeps W_hh^T[k][those 256 rows] in registers for the whole sequence and per step
+// exchanges its 64 new h values with the other three through 8-byte {value, tag} granules (MI355X_MICROARCH.md handoff-1to1 /
+// "R2's granule": one sc1 store per value, the consumer lane polls its own granule with an sc1 load until the tag is this launch's
+// step number - no flag, no fence, nothing streamed).  A step is then one hand-off (~1 us) + 64 FMAs per thread instead of 1 MB
+// through one CU (12.7 us per step at B = 32).
+//   * xbuf: [2 B groups][2 step parities][256 units] granules, caller-owned, zero before its first use; tags carry `epoch` (the
+//     caller's launch counter) so that nothing a previous launch left can match.  Slot parity: a workgroup overwrites slot s & 1 at
+//     step s + 2, after it has seen every partner's step s + 1, which they publish after reading step s.
+//   * block number -> (group, quarter): id = 32 G + 8 m + x is quarter m of group 8 G + x - the four workgroups of a group are
+//     within 32 consecutive blocks (they become resident together; a group whose partners are not resident yet spins, complete
+//     groups in front of it always finish) and share an XCD under round-robin placement (speed only).
+//   * every wait is bounded (LSEQ_SPIN_MAX polls, seconds): on expiry the workgroup raises xbuf's error word and leaves the loop.
+#define LSEQ_SPIN_MAX (1 << 22)
+static __device__ __forceinline__ void lseq_publish(unsigned long long* slot, float v, unsigned tag) {
+    const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+    __hip_atomic_store(slot, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // global_store_dwordx2 sc1
+}
+// polls until the granule carries `tag`; false on expiry
+static __device__ __forceinline__ bool lseq_await(const unsigned long long* slot, unsigned tag, float& v) {
+    for (int it = 0; it < LSEQ_SPIN_MAX; ++it) {
+        const unsigned long long g = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // global_load_dwordx2 sc1
+        if ((unsigned)(g >> 32) == tag) { v = __uint_as_float((unsigned)g); return true; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(1024) void lstm_seq_split_kernel(const float* __restrict__ gx, const float* __restrict__ whhT_f,
+                                                              const float* __restrict__ whhT_r, const int* __restrict__ lengths,
+                                                              float* out, int B, int T, int T_out, float* gates_save, float* c_save,
+                                                              unsigned long long* xbuf, unsigned epoch) {
+    constexpr int H = 256;
+    __shared__ __attribute__((aligned(16))) float s_h[H];
+    __shared__ float s_part[4][256];
+    __shared__ float s_g[256];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x;
+    const int id = blockIdx.x, group = (id >> 5) * 8 + (id & 7), q = (id >> 3) & 3;
+    if (group >= 2 * B) return;                              // (whole workgroups)
+    const int b = group >> 1, dir = group & 1;
+    const int r = tid & 255, g = r >> 6, ul = r & 63, kq = tid >> 8;
+    const int j = g * H + 64 * q + ul;                       // this thread's gate row
+    const float* WT = dir ? whhT_r : whhT_f;                 // [H][4H]
+    const int len = lengths ? lengths[b] : T;
+    float wr[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) wr[i] = WT[(size_t)(64 * kq + i) * 4 * H + j];
+    if (tid < H) s_h[tid] = 0.f;
+    if (tid == 0) s_fail = 0;
+    float c = 0.f;
+    unsigned long long* xg = xbuf + (size_t)group * 2 * H;
+    const unsigned tag0 = epoch << 12;
+    // the partner unit this thread fetches each step (threads 64 .. 255: the 192 units of the other three quarters)
+    const int pu = tid >= 64 && tid < 256 ? ((tid - 64) < 64 * q ? (tid - 64) : tid) : 0;
+    __syncthreads();
+    float gxv = 0.f;
+    if (tid < 256 && len > 0) gxv = gx[((size_t)b * T + (dir ? len - 1 : 0)) * (8 * H) + dir * 4 * H + j];
+    for (int s = 0; s < len; ++s) {
+        const int t = dir ? len - 1 - s : s;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; i += 4) {
+            const f32x4 h4 = *(const f32x4*)&s_h[64 * kq + i];
+            acc += (wr[i] * h4[0] + wr[i + 1] * h4[1]) + (wr[i + 2] * h4[2] + wr[i + 3] * h4[3]);
+        }
+        s_part[kq][r] = acc;
+        __syncthreads();
+        if (tid < 256) {
+            s_g[tid] = gxv + ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]));
+            if (s + 1 < len)                                 // next step's input projection: in flight across the hand-off
+                gxv = gx[((size_t)b * T + (dir ? len - 2 - s : s + 1)) * (8 * H) + dir * 4 * H + j];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int u = 64 * q + tid;
+            const float gi = s_g[tid], gf = s_g[64 + tid], gg = s_g[128 + tid], go = s_g[192 + tid];
+            c = sigmoid_acc(gf) * c + sigmoid_acc(gi) * tanhf(gg);
+            const float h = sigmoid_acc(go) * tanhf(c);
+            lseq_publish(xg + (size_t)(s & 1) * H + u, h, tag0 + (unsigned)s + 1u);
+            s_h[u] = h;
+            if (gates_save) {      // training: post-activation gates and cell state per step, for the BPTT kernel
+                const size_t gb = (((size_t)b * T + t) * 2 + dir) * 4 * H + u;
+                gates_save[gb] = sigmoid_acc(gi);
+                gates_save[gb + H] = sigmoid_acc(gf);
+                gates_save[gb + 2 * H] = tanhf(gg);
+                gates_save[gb + 3 * H] = sigmoid_acc(go);
+                c_save[(((size_t)b * T + t) * 2 + dir) * H + u] = c;
+            }
+            out[((size_t)b * T_out + t) * (2 * H) + dir * H + u] = h;
+        } else if (tid < 256) {
+            float v = 0.f;
+            const bool ok = s + 1 < len ? lseq_await(xg + (size_t)(s & 1) * H + pu, tag0 + (unsigned)s + 1u, v) : true;
+            if (!ok) s_fail = 1;
+            s_h[pu] = v;                                     // (the last step's h of the partners is not needed)
+        }
+        __syncthreads();
+        if (s_fail) {
+            if (tid == 0) __hip_atomic_store(xbuf + (size_t)2 * B * 2 * H, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    // zero the padded tail (pad_packed_sequence semantics)
+    if (tid < 64)
+        for (int t = len; t < T_out; ++t) out[((size_t)b * T_out + t) * (2 * H) + dir * H + 64 * q + tid] = 0.f;
+}
+
+hipError_t t2s_launch_lstm_seq_split(const float* gx, const float* whhT_f, const float* whhT_r, const int* lengths, float* out,
+                                     int B, int T, int T_out, float* gates_save, float* c_save, unsigned long long* xbuf,
+                                     unsigned epoch, hipStream_t stream) {
+    if (T >= 4095) return hipErrorInvalidValue;              // (12 tag bits for the step)
+    hipLaunchKernelGGL(lstm_seq_split_kernel, dim3(((2 * B + 7) / 8) * 32), dim3(1024), 0, stream, gx, whhT_f, whhT_r, lengths, out,
+                       B, T, T_out, gates_save, c_save, xbuf, epoch & 0xFFFFFu);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // small helpers
 __global__ void transpose_kernel(const float* in, float* out, int R, int C) {      // out[c][r] = in[r][c]
     __shared__ float tile[32][33];

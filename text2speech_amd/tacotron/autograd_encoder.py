@@ -28,8 +28,14 @@ def encoder_lstm_backward(bw, d_memory):
     ready = torch.cuda.Event()
     ready.record(main)              # d_memory, the cleared dgx / hprev and the forward's saves precede this point on the main stream
     side.wait_event(ready)
-    _lib.call("t2s_taco_encoder_lstm_bwd", _p(d_memory), _p(memory), _p(sv["enc_gates"]), _p(sv["enc_c"]), _p(whh[0]),
-              _p(whh[1]), _p(sv["enc_len32"]), _p(dgx), _p(hprev), B, T, H, memory.size(1), _lib.c_vp(side.cuda_stream))
+    xb = bw.eng._lstm_xbuf("bwd", B, memory.device) if H == 256 and T < 4095 else None
+    if xb is not None:      # W_hh resident over four workgroups per (element, direction): t2s_taco_encoder_lstm_bwd_split
+        _lib.call("t2s_taco_encoder_lstm_bwd_split", _p(d_memory), _p(memory), _p(sv["enc_gates"]), _p(sv["enc_c"]), _p(whh[0]),
+                  _p(whh[1]), _p(sv["enc_len32"]), _p(dgx), _p(hprev), B, T, H, memory.size(1), _p(xb[0]), xb[1],
+                  _lib.c_vp(side.cuda_stream))
+    else:
+        _lib.call("t2s_taco_encoder_lstm_bwd", _p(d_memory), _p(memory), _p(sv["enc_gates"]), _p(sv["enc_c"]), _p(whh[0]),
+                  _p(whh[1]), _p(sv["enc_len32"]), _p(dgx), _p(hprev), B, T, H, memory.size(1), _lib.c_vp(side.cuda_stream))
     done = torch.cuda.Event()
     done.record(side)
     bw.keep += [d_memory, whh]

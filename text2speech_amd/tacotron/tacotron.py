@@ -545,11 +545,41 @@ class _TacoEngine:
             gsave = pool_take(self.pool, leases, "enc_gsave", (B, T, 2, 4 * H), torch.float32, dev)
             csave = pool_take(self.pool, leases, "enc_csave", (B, T, 2, H), torch.float32, dev)
             save.update(enc_gates=gsave, enc_c=csave)
-        _lib.call("t2s_taco_encoder_lstm", _lib.ptr(gx), _lib.ptr(P["whhT"][0][0]), _lib.ptr(P["whhT"][1][0]),
-                  _lib.ptr(len32), _lib.ptr(memory), B, T, H, T_out, _lib.ptr(gsave), _lib.ptr(csave), st)
+        xb = self._lstm_xbuf("fwd", B, dev) if H == 256 and T < 4095 else None
+        if xb is not None:      # W_hh resident, four workgroups per (element, direction) exchanging h per step (t2s_taco_encoder_lstm_split)
+            _lib.call("t2s_taco_encoder_lstm_split", _lib.ptr(gx), _lib.ptr(P["whhT"][0][0]), _lib.ptr(P["whhT"][1][0]),
+                      _lib.ptr(len32), _lib.ptr(memory), B, T, H, T_out, _lib.ptr(gsave), _lib.ptr(csave), _lib.ptr(xb[0]), xb[1], st)
+        else:
+            _lib.call("t2s_taco_encoder_lstm", _lib.ptr(gx), _lib.ptr(P["whhT"][0][0]), _lib.ptr(P["whhT"][1][0]),
+                      _lib.ptr(len32), _lib.ptr(memory), B, T, H, T_out, _lib.ptr(gsave), _lib.ptr(csave), st)
         if save is not None:
             save.update(enc_ids=ids64, enc_gx=gx, enc_Xh=Xh, enc_Xl=Xl, enc_T=T, enc_Lp=Lp, enc_len32=len32, memory=memory)
         return memory, len32
+
+    def _lstm_xbuf(self, which, B, dev):
+        """Exchange buffer of the split BiLSTM recurrence (t2s_taco_encoder_lstm_split / _bwd_split) and this launch's epoch, or None
+        (T2S_LSTM_SEQ_SPLIT=0: the one-workgroup kernels).  One buffer per direction of use (forward / backward: the two may be in
+        flight on different streams), engine-owned, zeroed once; `check_lstm_xbuf()` reads the error words."""
+        import os
+        if os.environ.get("T2S_LSTM_SEQ_SPLIT", "1") == "0":
+            return None
+        bufs = self.__dict__.setdefault("_xbufs", {})
+        key = (which, int(B), str(dev))
+        ent = bufs.get(key)
+        if ent is None:
+            n = int(_lib.load().t2s_taco_lstm_xbuf_bytes(int(B)))
+            ent = bufs[key] = [torch.zeros(n // 8, dtype=torch.int64, device=dev), 0]
+        ent[1] = (ent[1] + 1) & 0xFFFFF
+        if ent[1] == 0:         # (wrapped: tags of 2^20 launches ago could match again - start over from a clean buffer)
+            ent[0].zero_()
+            ent[1] = 1
+        return ent[0], ent[1]
+
+    def check_lstm_xbuf(self):
+        """Synchronises; raises if a bounded wait of the split BiLSTM kernels ever expired on one of this engine's buffers."""
+        for key, (buf, _) in self.__dict__.get("_xbufs", {}).items():
+            if int(buf[-1].item()) != 0:
+                raise _lib.T2SError("split BiLSTM recurrence %s: a hand-off wait expired (results of that launch are invalid)" % (key,))
 
     def _gemv(self, W, x, rows, items, K, y, act=0, mask=None, smask=0, mask_scale=1.0, bias=None, sy_item=None,
               sx=None):
