@@ -262,6 +262,7 @@ def test_inference_long_inputs_vs_oracle(model, B, n_sym, n):
     with torch.no_grad():
         o_mel, o_post, o_gate, o_align = O.tacotron_inference(synth.tacotron_state(), HP, ids, n, masks.float())
     assert tuple(align.shape) == (B, n, n_sym)
+    model._eng().check_lstm_xbuf()
     for name, a, b in (("mel", mel, o_mel), ("mel_post", mel_post, o_post), ("gate", gate, o_gate), ("align", align, o_align)):
         assert tuple(a.shape) == tuple(b.shape), name
         assert _rel(a, b) < 1e-3, (name, _rel(a, b))

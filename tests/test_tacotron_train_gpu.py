@@ -364,6 +364,7 @@ def test_benchmarked_shape_b32_t800_vs_reference_golden(golden_dir):
             worst.append((_rel(flat[::max(1, flat.numel() // 4096)], g[key]), name))
     worst.sort(reverse=True)
     assert len(worst) == 10 and worst[0][0] < 5e-3, worst[:4]
+    m._eng().check_lstm_xbuf()          # no hand-off wait of the split BiLSTM kernels (forward and BPTT) expired
     print("B=32 T_out=800 step vs reference: loss %.6f / %.6f, worst |dsq|/sq %.2e (%s), worst sampled rel %.2e (%s)"
           % (float(loss), float(g["loss"]), worst_sq[0][0], worst_sq[0][1], worst[0][0], worst[0][1]))
 
