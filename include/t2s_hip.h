@@ -602,8 +602,9 @@ typedef struct t2s_bn_bwd_args {
     float *dgamma, *dbeta; void *dx_hi, *dx_lo;
     int B, C, T, Lp, halo;
 } t2s_bn_bwd_args;
-/* training-mode BatchNorm1d backward fused with the backward of activation + dropout; dx as planes */
-int t2s_bn_bwd(const t2s_bn_bwd_args* a, void* stream);
+/* training-mode BatchNorm1d backward fused with the backward of activation + dropout; dx as planes.
+ * ABI v4: `partial` = scratch of B * C * 2 doubles (the per-batch-element sums S1, S2, added in a fixed order: bitwise reproducible) */
+int t2s_bn_bwd(const t2s_bn_bwd_args* a, void* partial, void* stream);
 /* out[j] = sum_i in[i][j] ; out = a (+ b) (+ c): b and c optional, so it is also the stream-ordered copy of an f32 buffer */
 int t2s_sum_axis0(const float* in, int n0, int n, float* out, void* stream);
 int t2s_add3(const float* a, const float* b, const float* c, size_t n, float* out, void* stream);

@@ -81,7 +81,7 @@ SIGNATURES = {
     "t2s_relu_drop_bwd": [c_vp, c_vp, c_float, ctypes.c_size_t, c_vp, c_vp],
     "t2s_taco_att_bwd": [c_vp, c_vp],
     "t2s_taco_bptt_steps": [c_vp, c_int, c_int, c_vp],
-    "t2s_bn_bwd": [c_vp, c_vp],
+    "t2s_bn_bwd": [c_vp, c_vp, c_vp],
     "t2s_waveglow_loss": [c_vp, ctypes.c_size_t, c_vp, c_vp, c_int, c_vp, c_float, c_vp, c_vp, c_vp, c_vp],
     "t2s_taco_loss": [c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "t2s_stft_transform": [c_vp, c_int, c_int, c_vp, c_int, c_int, c_vp, c_long, c_vp, c_vp, c_vp, c_vp, c_long, c_vp],

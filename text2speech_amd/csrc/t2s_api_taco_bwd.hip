@@ -322,14 +322,14 @@ int t2s_waveglow_loss(const float* z, size_t n_z, const float* const* log_s, con
     return T2S_OK;
 }
 
-int t2s_bn_bwd(const t2s_bn_bwd_args* p, void* stream) {
-    if (!p || !p->x || !p->mean || !p->var || !p->gamma || !p->beta || !p->dgamma || !p->dbeta || !p->dx_hi ||
-        !p->dx_lo || (!p->dout_f32 && (!p->dout_hi || !p->dout_lo)) || p->B <= 0 || p->C <= 0 || p->T <= 0)
+int t2s_bn_bwd(const t2s_bn_bwd_args* p, void* partial, void* stream) {
+    if (!p || !partial || ((uintptr_t)partial & 7) || !p->x || !p->mean || !p->var || !p->gamma || !p->beta || !p->dgamma || !p->dbeta ||
+        !p->dx_hi || !p->dx_lo || (!p->dout_f32 && (!p->dout_hi || !p->dout_lo)) || p->B <= 0 || p->C <= 0 || p->T <= 0)
         return T2S_EINVAL;
     static_assert(sizeof(t2s_bn_bwd_args) == sizeof(BnBwdArgs), "t2s_bn_bwd_args layout");
     BnBwdArgs a;
     memcpy(&a, p, sizeof(a));
-    T2S_CHECK_HIP(t2s_launch_bn_bwd(a, (hipStream_t)stream));
+    T2S_CHECK_HIP(t2s_launch_bn_bwd(a, (double*)partial, (hipStream_t)stream));
     return T2S_OK;
 }
 

@@ -72,7 +72,7 @@ hipError_t t2s_launch_att_bwd_conv(const AttBwdArgs& a, hipStream_t stream);
 // the three parts in one launch (needs ctx, the second carry pair, dctx_out; d_q is left as per-chunk partials in dq_part)
 bool t2s_att_bwd_fused_ok(const AttBwdArgs& a);
 hipError_t t2s_launch_att_bwd_fused(const AttBwdArgs& a, hipStream_t stream);
-hipError_t t2s_launch_bn_bwd(const BnBwdArgs& a, hipStream_t stream);
+hipError_t t2s_launch_bn_bwd(const BnBwdArgs& a, double* partial, hipStream_t stream);
 hipError_t t2s_launch_planes_to_f32(const u16* X_hi, const u16* X_lo, int B, int C, int L, int Lp, int halo, float* out,
                                     int accumulate, hipStream_t stream);
 hipError_t t2s_launch_sum_axis0(const float* in, int n0, int n, float* out, hipStream_t stream);

@@ -34,7 +34,10 @@ __global__ __launch_bounds__(256) void rows_to_tm_kernel(const float* __restrict
                                                          u16* dst_hi, u16* dst_lo, int Npad, int n_off, long x_bstride,
                                                          long dst_bstride) {
     __shared__ float tile[32][33];
-    const int ic = blockIdx.x, cc = blockIdx.y, tid = threadIdx.x;
+    // channel chunk on the FAST block index: the workgroups in flight at one time read consecutive 128-byte pieces of the same 32
+    // rows (whole rows stream) and write one contiguous run of planes.  With the item chunk fastest they touched 128 bytes every
+    // `ld` floats across the whole array at once - 1.6 TB/s on the 2 x 419 MB of the decoder cell's gate gradients.
+    const int cc = blockIdx.x, ic = blockIdx.y, tid = threadIdx.x;
     x += (size_t)blockIdx.z * x_bstride;            // batched form: one set of planes per blockIdx.z
     dst_hi += (size_t)blockIdx.z * dst_bstride;
     dst_lo += (size_t)blockIdx.z * dst_bstride;
@@ -67,14 +70,16 @@ __global__ __launch_bounds__(256) void rows_to_tm_kernel(const float* __restrict
 }
 hipError_t t2s_launch_rows_to_tm(const float* x, long ld, int items, int items_pad, int shift, int C, u16* dst_hi,
                                  u16* dst_lo, int Npad, int n_off, hipStream_t stream) {
-    hipLaunchKernelGGL(rows_to_tm_kernel, dim3(items_pad / 32, (C + 31) / 32), dim3(256), 0, stream, x, ld, items, shift, C,
+    if (items_pad / 32 > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rows_to_tm_kernel, dim3((C + 31) / 32, items_pad / 32), dim3(256), 0, stream, x, ld, items, shift, C,
                        dst_hi, dst_lo, Npad, n_off, 0L, 0L);
     return hipGetLastError();
 }
 hipError_t t2s_launch_rows_to_tm_batched(const float* x, long ld, long x_bstride, int items, int items_pad, int shift, int C,
                                          u16* dst_hi, u16* dst_lo, long dst_bstride, int Npad, int n_off, int nb,
                                          hipStream_t stream) {
-    hipLaunchKernelGGL(rows_to_tm_kernel, dim3(items_pad / 32, (C + 31) / 32, nb), dim3(256), 0, stream, x, ld, items, shift, C,
+    if (items_pad / 32 > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rows_to_tm_kernel, dim3((C + 31) / 32, items_pad / 32, nb), dim3(256), 0, stream, x, ld, items, shift, C,
                        dst_hi, dst_lo, Npad, n_off, x_bstride, dst_bstride);
     return hipGetLastError();
 }
@@ -1205,14 +1210,9 @@ hipError_t t2s_launch_att_bwd(const AttBwdArgs& a, hipStream_t stream) {
 //   dy' = d_out * mask * s * act'(.) ;  sums: S1 = sum dy', S2 = sum dy' xhat  over (B, T) per channel
 //   dx = gamma inv_std / N (N dy' - S1 - xhat S2) ;  dgamma = S2 ; dbeta = S1
 // d_out comes as f32 [B][C][T] or as planes (hi, lo); dx is written as planes (the dgrad / wgrad GEMM operand).
-static __device__ __forceinline__ float bn_dyp(const BnBwdArgs& a, int b, int c, int t, float xhat) {
-    const size_t i = ((size_t)b * a.C + c) * a.T + t;
-    float d;
-    if (a.dout_f32) d = a.dout_f32[i];
-    else {
-        const size_t pi = (((size_t)b * ((a.C + 31) / 32) + (c >> 5)) * a.Lp + a.halo + t) * 32 + (c & 31);
-        d = join_bf16(a.dout_hi[pi], a.dout_lo[pi]);
-    }
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+// dy' of one element given the raw d_out value d (activation + dropout backward)
+static __device__ __forceinline__ float bn_dyp(const BnBwdArgs& a, size_t i, int c, float xhat, float d) {
     if (a.mask) d = a.mask[i] ? d * a.mask_scale : 0.f;
     if (a.act != ACT_NONE) {
         const float ybn = xhat * a.gamma[c] + a.beta[c];
@@ -1221,50 +1221,121 @@ static __device__ __forceinline__ float bn_dyp(const BnBwdArgs& a, int b, int c,
     }
     return d;
 }
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
-    __shared__ double red[2][4];
-    const int c = blockIdx.x, tid = threadIdx.x;
-    const float mu = a.mean[c], istd = 1.0f / sqrtf(a.var[c] + a.eps);
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < a.B; ++b)
-        for (int t = tid; t < a.T; t += 256) {
-            const float xhat = (a.x[((size_t)b * a.C + c) * a.T + t] - mu) * istd;
-            const float d = bn_dyp(a, b, c, t, xhat);
-            s1 += d;
-            s2 += d * xhat;
+// Both kernels work on tiles of 64 time steps x 32 channels (one channel chunk of the planes) and 256 threads.  The planes are
+// [t][32 channels] rows of 64 bytes: read / written 16 bytes per thread (thread = (t, 8 channels)) and turned through LDS, while the
+// f32 operands ([B][C][T]) are accessed time-major (thread = (channel mod 4, t)).  The first version read and wrote the planes
+// 2 bytes per thread at a 64-byte stride: 0.9 TB/s (104 + 113 us per layer at B = 32, 512 channels, 800 frames).
+static __device__ __forceinline__ void bn_stage_dout(const BnBwdArgs& a, int b, int chunk, int t0, float (*s_d)[33]) {
+    const int tid = threadIdx.x, tl = tid >> 2, q = tid & 3, t = t0 + tl;
+    if (!a.dout_f32) {
+        const int nch = (a.C + 31) / 32;
+        u16x8 h = {0, 0, 0, 0, 0, 0, 0, 0}, l = h;
+        if (t < a.T) {
+            const size_t pi = (((size_t)b * nch + chunk) * a.Lp + a.halo + t) * 32 + q * 8;
+            h = *(const u16x8*)(a.dout_hi + pi);
+            l = *(const u16x8*)(a.dout_lo + pi);
         }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = s1; red[1][tid >> 6] = s2; }
-    __syncthreads();
-    if (tid == 0) {
-        a.dbeta[c] = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        a.dgamma[c] = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        for (int e = 0; e < 8; ++e) s_d[tl][q * 8 + e] = join_bf16(h[e], l[e]);
     }
 }
-__global__ void bn_bwd_apply_kernel(const BnBwdArgs a) {
-    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int b = blockIdx.z;
-    const int nch = (a.C + 31) / 32;
-    if (t >= a.T) return;
-    const float n = (float)a.B * a.T;
-    for (int c = blockIdx.y * 32 + (threadIdx.x >> 6); c < blockIdx.y * 32 + 32; c += 4) {
-        float dx = 0.f;
-        if (c < a.C) {
-            const float istd = 1.0f / sqrtf(a.var[c] + a.eps);
-            const float xhat = (a.x[((size_t)b * a.C + c) * a.T + t] - a.mean[c]) * istd;
-            const float d = bn_dyp(a, b, c, t, xhat);
-            dx = a.gamma[c] * istd / n * (n * d - a.dbeta[c] - xhat * a.dgamma[c]);
+// partial[b][c][2] (double): S1, S2 of one batch element; grid (channel chunks, B)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a, double* partial) {
+    __shared__ float s_d[64][33];
+    const int chunk = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int ci = tid >> 6, tl = tid & 63;
+    double s1[8], s2[8];
+    float mu[8], istd[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = chunk * 32 + ci + 4 * k;
+        s1[k] = 0.0; s2[k] = 0.0;
+        mu[k] = c < a.C ? a.mean[c] : 0.f;
+        istd[k] = c < a.C ? 1.0f / sqrtf(a.var[c] + a.eps) : 0.f;
+    }
+    for (int t0 = 0; t0 < a.T; t0 += 64) {
+        bn_stage_dout(a, b, chunk, t0, s_d);
+        __syncthreads();
+        const int t = t0 + tl;
+        if (t < a.T) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int cl = ci + 4 * k, c = chunk * 32 + cl;
+                if (c < a.C) {
+                    const size_t i = ((size_t)b * a.C + c) * a.T + t;
+                    const float xhat = (a.x[i] - mu[k]) * istd[k];
+                    const float d = bn_dyp(a, i, c, xhat, a.dout_f32 ? a.dout_f32[i] : s_d[tl][cl]);
+                    s1[k] += d;
+                    s2[k] += d * xhat;
+                }
+            }
         }
-        u16 h, l;
-        split_bf16(dx, h, l);
-        const size_t idx = (((size_t)b * nch + (c >> 5)) * a.Lp + a.halo + t) * 32 + (c & 31);
-        a.dx_hi[idx] = h;
-        a.dx_lo[idx] = l;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { s1[k] += __shfl_xor(s1[k], off, 64); s2[k] += __shfl_xor(s2[k], off, 64); }
+        const int c = chunk * 32 + ci + 4 * k;
+        if (tl == 0 && c < a.C) {
+            partial[((size_t)b * a.C + c) * 2] = s1[k];
+            partial[((size_t)b * a.C + c) * 2 + 1] = s2[k];
+        }
     }
 }
-hipError_t t2s_launch_bn_bwd(const BnBwdArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(a.C), dim3(256), 0, stream, a);
+__global__ void bn_bwd_reduce_final_kernel(const BnBwdArgs a, const double* partial) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < a.B; ++b) { s1 += partial[((size_t)b * a.C + c) * 2]; s2 += partial[((size_t)b * a.C + c) * 2 + 1]; }
+    a.dbeta[c] = (float)s1;
+    a.dgamma[c] = (float)s2;
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
+    __shared__ float s_d[64][33];
+    const int t0 = blockIdx.x * 64, chunk = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int ci = tid >> 6, tl = tid & 63, t = t0 + tl;
+    const int nch = (a.C + 31) / 32;
+    const float n = (float)a.B * a.T;
+    bn_stage_dout(a, b, chunk, t0, s_d);
+    __syncthreads();
+    float dx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int cl = ci + 4 * k, c = chunk * 32 + cl;
+        dx[k] = 0.f;
+        if (c < a.C && t < a.T) {
+            const size_t i = ((size_t)b * a.C + c) * a.T + t;
+            const float istd = 1.0f / sqrtf(a.var[c] + a.eps);
+            const float xhat = (a.x[i] - a.mean[c]) * istd;
+            const float d = bn_dyp(a, i, c, xhat, a.dout_f32 ? a.dout_f32[i] : s_d[tl][cl]);
+            dx[k] = a.gamma[c] * istd / n * (n * d - a.dbeta[c] - xhat * a.dgamma[c]);
+        }
+    }
+    __syncthreads();                                 // every read of the staged d_out is done: the tile now carries dx
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_d[tl][ci + 4 * k] = dx[k];
+    __syncthreads();
+    {
+        const int tw = tid >> 2, q = tid & 3;
+        if (t0 + tw < a.T) {
+            u16x8 h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                u16 hh, ll;
+                split_bf16(s_d[tw][q * 8 + e], hh, ll);
+                h[e] = hh;
+                l[e] = ll;
+            }
+            const size_t idx = (((size_t)b * nch + chunk) * a.Lp + a.halo + t0 + tw) * 32 + q * 8;
+            *(u16x8*)(a.dx_hi + idx) = h;
+            *(u16x8*)(a.dx_lo + idx) = l;
+        }
+    }
+}
+hipError_t t2s_launch_bn_bwd(const BnBwdArgs& a, double* partial, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((a.C + 31) / 32, a.B), dim3(256), 0, stream, a, partial);
+    hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3((a.C + 255) / 256), dim3(256), 0, stream, a, (const double*)partial);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((a.T + 63) / 64, (a.C + 31) / 32, a.B), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

@@ -2146,17 +2146,23 @@ hipError_t t2s_launch_zero_fill(void* p, size_t bytes, hipStream_t stream) {
     return hipGetLastError();
 }
 // y = act((x - mean) / sqrt(var + eps) * gamma + beta) * mask * mask_scale -> planes (and optional f32 copy)
-__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ var,
-                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int act,
-                                const unsigned char* __restrict__ mask, float mask_scale, int C, int T, int Lp, int halo,
-                                u16* O_hi, u16* O_lo, float* out_f32) {
-    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int b = blockIdx.z;
+// Tile = 64 time steps x one 32-channel chunk, 256 threads: x is read time-major (thread = (channel mod 4, t)), the planes are
+// written as 16-byte pieces (thread = (t, 8 channels)) through LDS - they were written 2 bytes per thread at a 64-byte stride.
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ var, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, int act,
+                                                       const unsigned char* __restrict__ mask, float mask_scale, int C, int T, int Lp,
+                                                       int halo, u16* O_hi, u16* O_lo, float* out_f32) {
+    typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+    __shared__ float s_o[64][33];
+    const int t0 = blockIdx.x * 64, chunk = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const int ci = tid >> 6, tl = tid & 63, t = t0 + tl;
     const int nch = (C + 31) / 32;
-    if (t >= T) return;
-    for (int c = blockIdx.y * 32 + (threadIdx.x >> 6); c < blockIdx.y * 32 + 32; c += 4) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int cl = ci + 4 * k, c = chunk * 32 + cl;
         float v = 0.f;
-        if (c < C) {
+        if (c < C && t < T) {
             const size_t i = ((size_t)b * C + c) * T + t;
             v = (x[i] - mean[c]) / sqrtf(var[c] + eps) * gamma[c] + beta[c];
             if (act == ACT_RELU) v = fmaxf(v, 0.f);
@@ -2164,13 +2170,23 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
             if (mask) v = mask[i] ? v * mask_scale : 0.f;
             if (out_f32) out_f32[i] = v;
         }
-        if (O_hi) {
-            u16 h, l;
-            split_bf16(v, h, l);
-            const size_t idx = (((size_t)b * nch + (c >> 5)) * Lp + halo + t) * 32 + (c & 31);
-            O_hi[idx] = h;
-            O_lo[idx] = l;
+        s_o[tl][cl] = v;
+    }
+    if (!O_hi) return;                               // (uniform)
+    __syncthreads();
+    const int tw = tid >> 2, q = tid & 3;
+    if (t0 + tw < T) {
+        u16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            u16 hh, ll;
+            split_bf16(s_o[tw][q * 8 + e], hh, ll);
+            h[e] = hh;
+            l[e] = ll;
         }
+        const size_t idx = (((size_t)b * nch + chunk) * Lp + halo + t0 + tw) * 32 + q * 8;
+        *(u16x8*)(O_hi + idx) = h;
+        *(u16x8*)(O_lo + idx) = l;
     }
 }
 hipError_t t2s_launch_bn_train(const float* x, const float* gamma, const float* beta, float eps, int act,

@@ -212,7 +212,9 @@ class _Bwd:
                        mask=None if s["mask"] is None else s["mask"].data_ptr(), mask_scale=2.0, act=s["act"],
                        dgamma=dgamma.data_ptr(), dbeta=dbeta.data_ptr(), dx_hi=dconv[0].data_ptr(), dx_lo=dconv[1].data_ptr(),
                        B=B, C=Cout, T=T, Lp=Lp, halo=halo)
-            _lib.call("t2s_bn_bwd", ctypes.byref(a), self.st)
+            part = torch.empty(B * Cout * 2, dtype=torch.float64, device=self.dev)      # per-element sums, added in a fixed order
+            _lib.call("t2s_bn_bwd", ctypes.byref(a), _p(part), self.st)
+            self.keep.append(part)
             self.grads[id(bn.weight)], self.grads[id(bn.bias)] = dgamma, dbeta
             self.keep += [g32, b32, dconv]
             # conv weight gradient: contraction over time per batch element (split-K slabs), bias from the ones row
