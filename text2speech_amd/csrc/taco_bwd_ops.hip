@@ -1254,16 +1254,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a, d
         istd[k] = c < a.C ? 1.0f / sqrtf(a.var[c] + a.eps) : 0.f;
     }
     for (int t0 = 0; t0 < a.T; t0 += 64) {
+        const int t = t0 + tl;
+        // the f32 operands of this tile are requested before the plane tile is staged: one memory round trip per tile, not two
+        float xv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = chunk * 32 + ci + 4 * k;
+            xv[k] = (c < a.C && t < a.T) ? a.x[((size_t)b * a.C + c) * a.T + t] : 0.f;
+        }
         bn_stage_dout(a, b, chunk, t0, s_d);
         __syncthreads();
-        const int t = t0 + tl;
         if (t < a.T) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int cl = ci + 4 * k, c = chunk * 32 + cl;
                 if (c < a.C) {
                     const size_t i = ((size_t)b * a.C + c) * a.T + t;
-                    const float xhat = (a.x[i] - mu[k]) * istd[k];
+                    const float xhat = (xv[k] - mu[k]) * istd[k];
                     const float d = bn_dyp(a, i, c, xhat, a.dout_f32 ? a.dout_f32[i] : s_d[tl][cl]);
                     s1[k] += d;
                     s2[k] += d * xhat;

@@ -68,6 +68,10 @@ def _ru(a, b):
     return -(-a // b) * b
 
 
+import os as _os
+_IW_WGS = int(_os.environ.get("T2S_IW_WGS", "4096"))
+
+
 class _Bwd:
     def __init__(self, eng, sv):
         self.eng, self.sv = eng, sv
@@ -159,7 +163,11 @@ class _Bwd:
         for (ptr, ld, C, off, shift) in x_srcs:
             _lib.call("t2s_rows_to_tm", ptr, ld, items, items_pad, shift, C, _p(X[0]), _p(X[1]), Npad, off, self.st)
         _lib.call("t2s_tm_ones_row", _p(X[0]), _p(X[1]), 1, items_pad, 0, items, Npad, N_cols, self.st)
-        ks = max(1, min(16, nch))
+        # split-K slabs: 16 where the item count allows.  Fewer for the products that are many output tiles already (the LSTM cells':
+        # 176 / 128 tiles, 16 slabs of 4096 x 2561 floats = 671 MB written and read back) measured EQUAL - T2S_IW_WGS = target number
+        # of workgroups, 256 / 768 / 1536 / 4096: 82.2-83.5 ms per train step for all of them (profiles/r04_iw_split_ab.txt)
+        tiles = -(-M4 // 256) * -(-N // 256)
+        ks = max(1, min(16, nch, -(-_IW_WGS // tiles)))
         P = self.new(ks, M4, N)
         _lib.call("t2s_wgrad_gemm", _p(A[0]), _p(A[1]), _p(X[0]), _p(X[1]), _p(self.zero_bias), _p(P), 1, M4, N, Mpad, Npad,
                   nch, 0, nch, ks, self.st)
