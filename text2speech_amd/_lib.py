@@ -140,10 +140,15 @@ def load():
             "libt2s_hip.so not found at %s - build it with `python -m text2speech_amd.build` "
             "(there is no CPU fallback on the product path)" % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    diagnostic = bool(os.environ.get("T2S_LIB_PATH"))
     for name, argtypes in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
+            if diagnostic:
+                # a diagnostic build (explicit T2S_LIB_PATH) may predate the newest entry points: it loads, and CALLING a missing
+                # one raises (`call` below).  The shipped library must export every declared symbol.
+                continue
             raise T2SError("libt2s_hip.so does not export %s" % name) from e
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, c_int)
@@ -173,7 +178,11 @@ def call(name, *args):
         c[0] += 1
         c[1] += time.perf_counter() - t0
     else:
-        rc = getattr(lib, name)(*args)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise T2SError("%s does not export %s (a diagnostic build older than the entry point?)" % (LIB_PATH, name)) from e
+        rc = fn(*args)
     if rc != 0:
         msg = lib.t2s_error_string(rc).decode()
         hip = lib.t2s_last_hip_error().decode()
