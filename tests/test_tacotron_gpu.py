@@ -285,12 +285,15 @@ def test_forward_ragged_vs_golden(model, golden_dir):
     assert float(out[0][3, :, 25:].abs().max()) == 0.0 and float(out[2][3, 25:].min()) == 1e3
 
 
-def test_eval_forward_batch12_split_decoder_cells_vs_oracle(model):
+@pytest.mark.parametrize("B,T_in,T_out", [(12, 30, 41), (12, 260, 24), (9, 512, 10)])
+def test_eval_forward_batch12_split_decoder_cells_vs_oracle(model, B, T_in, T_out):
     """No-grad teacher-forced forward at 9+ items: the decoder cells run on the library's helper stream a chunk of steps behind the
-    attention chain (t2s_taco_decode_steps with att_h_all + hc_all, as in training) - against the oracle, ragged lengths."""
+    attention chain (t2s_taco_decode_steps with att_h_all + hc_all, as in training) - against the oracle, ragged lengths.  At 260
+    and 512 encoder positions (>= enc_dim / 64 tiles of 32) the energies launch also does softmax and context: the tiles of an
+    element exchange their energies through t2s_taco_decoder::att_xbuf; its error word is checked through the outputs (a wait
+    that expired leaves the context unwritten)."""
     from oracle import tacotron_oracle as O
     gen = torch.Generator().manual_seed(61)
-    B, T_in, T_out = 12, 30, 41
     in_len = torch.tensor([T_in - i for i in range(B)])
     out_len = torch.tensor([T_out - 2 * i for i in range(B)])
     text = torch.randint(2, 80, (B, T_in), generator=gen)

@@ -315,8 +315,17 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
             aa.q = qa.y;
             if (q_big) { aa.q_part = d->q_part; aa.n_part = A / 4; aa.q_out = qa.y; aa.q_save = nullptr; }
             else T2S_CHECK_HIP(t2s_launch_gemv(qa, stream));
+            // energies, softmax, cumulative weights and context in ONE launch where the shape allows (t2s_taco_decoder::att_xbuf: the
+            // tiles of an element exchange their energies through tagged granules).  T2S_ATT_ONE_LAUNCH=0: two launches.
+            static const bool want_one = !(getenv("T2S_ATT_ONE_LAUNCH") && atoi(getenv("T2S_ATT_ONE_LAUNCH")) == 0);
+            bool one = false;
+            if (want_one && d->att_xbuf) {
+                aa.xbuf = (unsigned long long*)d->att_xbuf; aa.tag = (unsigned)s + 1u;
+                one = t2s_att_energy_ctx_ok(aa);
+                if (!one) { aa.xbuf = nullptr; aa.tag = 0; }
+            }
             T2S_CHECK_HIP(t2s_launch_att_energy(aa, stream));
-            T2S_CHECK_HIP(t2s_launch_att_softmax_ctx(aa, stream));
+            if (!one) T2S_CHECK_HIP(t2s_launch_att_softmax_ctx(aa, stream));
         }
         }
         if (!do_dec) return T2S_OK;

@@ -110,7 +110,12 @@ struct AttArgs {
     const float* ploc;
     float* wcum_save;          // optional [B][T]: cumulative weights after this step (training)
     int tile_major;            // att_energy_mfma_kernel: block -> (tile, item) in launch order instead of item-per-XCD (A/B: T2S_ENERGY_XCD=0)
+    // one-launch form of energies + softmax + context (t2s_launch_att_energy with xbuf set; t2s_att_energy_ctx_ok says whether the
+    // shape is covered): [B][T] 8-byte granules + 1 error word, zero before step 0; tag = step + 1 (never 0)
+    unsigned long long* xbuf;
+    unsigned tag;
 };
+bool t2s_att_energy_ctx_ok(const AttArgs& a);
 
 // Role-specialised second half of the projection launch (B <= 8 autoregressive decode): while 85 workgroups run the 337 x 1536 GEMV,
 // T/16 x B more compute the location features of the NEXT step's attention from the weights this step's attention just wrote.

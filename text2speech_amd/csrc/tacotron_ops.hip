@@ -785,7 +785,17 @@ __global__ __launch_bounds__(256) void att_softmax_ctx_kernel(const AttArgs a) {
 // then e[t] = sum_a v[a] tanh(P + q + pm) by a 16-lane butterfly and an 8-wave sum through LDS.  The VALU kernel above spends its
 // time on two LDS reads per MAC of the convolution (profiles/r03_taco_step_kernel_counters_before.json).
 #define ATT_MQ 32
-__global__ __launch_bounds__(512) void att_energy_mfma_kernel(const AttArgs a) {
+// FUSE (teacher-forced chain at 9+ items, AttArgs::xbuf): softmax, cumulative weights and context in the SAME launch.  The n_tiles
+// workgroups of a batch element (all on one XCD, above) exchange their 32 energies through tagged 8-byte granules (one sc1 store per
+// value, the consumer lane polls its own granule: the encoder recurrence's hand-off, lstm_seq_split_kernel), every workgroup then
+// has the whole row, redoes the softmax (T exps), writes the weights / cumulative weights of ITS positions and - the first
+// enc_dim / 64 of them - one 64-channel chunk of the context.  The softmax + context launch (7 us at B = 32, T = 256, of which ~5
+// are the launch itself) leaves the serial chain for one hand-off.  In-place update of w / w_cum is safe: a workgroup writes only
+// after it has every partner's energies, which a partner publishes after its own reads of the window (its halo included).
+// xbuf: [B][T] granules + 1 error word, zero before step 0 of a sequence; tag = step + 1.  Waits are bounded.
+#define ATT_FUSE_SPIN_MAX (1 << 22)
+template <bool FUSE>
+__global__ __launch_bounds__(512, 2) void att_energy_mfma_kernel(const AttArgs a) {
     constexpr int AD = 128;
     __shared__ float s_cat[2][ATT_MQ + 64];
     // 13 KB of LDS in all, so that a workgroup fits on a CU next to a small-batch GEMM workgroup (144 KB ring): in training the
@@ -906,14 +916,143 @@ __global__ __launch_bounds__(512) void att_energy_mfma_kernel(const AttArgs a) {
         }
     }
     __syncthreads();
-    if (tid < ATT_MQ) {
-        const int t = t0 + tid;
-        const int len = a.lengths ? a.lengths[b] : T;
-        const float e = ((s_e[0][tid] + s_e[1][tid]) + (s_e[2][tid] + s_e[3][tid])) + ((s_e[4][tid] + s_e[5][tid]) + (s_e[6][tid] + s_e[7][tid]));
-        if (t < T) a.energies[(size_t)b * T + t] = t < len ? e : -INFINITY;
+    if constexpr (!FUSE) {
+        if (tid < ATT_MQ) {
+            const int t = t0 + tid;
+            const int len = a.lengths ? a.lengths[b] : T;
+            const float e = ((s_e[0][tid] + s_e[1][tid]) + (s_e[2][tid] + s_e[3][tid])) + ((s_e[4][tid] + s_e[5][tid]) + (s_e[6][tid] + s_e[7][tid]));
+            if (t < T) a.energies[(size_t)b * T + t] = t < len ? e : -INFINITY;
+        }
+    } else {
+        extern __shared__ float s_w[];                       // [T] energies, then weights
+        __shared__ float s_red[8];
+        __shared__ int s_fail;
+        __shared__ __attribute__((aligned(16))) float s_cpart[8][64];
+        unsigned long long* xrow = a.xbuf + (size_t)b * T;
+        if (tid == 0) s_fail = 0;
+        if (tid < ATT_MQ) {
+            const int t = t0 + tid;
+            const int len = a.lengths ? a.lengths[b] : T;
+            const float e = ((s_e[0][tid] + s_e[1][tid]) + (s_e[2][tid] + s_e[3][tid])) + ((s_e[4][tid] + s_e[5][tid]) + (s_e[6][tid] + s_e[7][tid]));
+            if (t < T) {
+                const float em = t < len ? e : -INFINITY;
+                const unsigned long long g = ((unsigned long long)a.tag << 32) | (unsigned long long)__float_as_uint(em);
+                __hip_atomic_store(xrow + t, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_w[t] = em;
+            }
+        }
+        // the first 256 rows of this workgroup's context chunk do not depend on the weights: requested now, in flight across the hand-off
+        const bool do_ctx = tile * 64 < a.enc_dim;           // (uniform: the first enc_dim / 64 workgroups of the element)
+        const int cg = lane & 15, rg = lane >> 4, tb0 = 4 * wave + rg;
+        const float* mem = a.memory + (size_t)b * T * a.enc_dim + (do_ctx ? tile * 64 : 0) + cg * 4;
+        f32x4 mm0[8];
+        if (do_ctx) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = tb0 + 32 * u;
+                mm0[u] = *(const f32x4*)(mem + (size_t)(t < T ? t : T - 1) * a.enc_dim);
+            }
+        }
+        __syncthreads();                                     // (s_fail = 0 is visible before any waiter may set it)
+        bool ok = true;
+        for (int t = tid; t < T; t += 512) {
+            if (t >= t0 && t < t0 + ATT_MQ) continue;        // own tile: already in s_w
+            bool got = false;
+            for (int it = 0; it < ATT_FUSE_SPIN_MAX; ++it) {
+                const unsigned long long g = __hip_atomic_load(xrow + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(g >> 32) == a.tag) { s_w[t] = __uint_as_float((unsigned)g); got = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            ok = ok && got;
+        }
+        if (!ok) s_fail = 1;
+        __syncthreads();
+        if (s_fail) {
+            if (tid == 0) __hip_atomic_store(a.xbuf + (size_t)a.B * T, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        // softmax over the row (reference tacotron.py:159-160), every workgroup of the element for itself
+        float m = -INFINITY;
+        for (int t = tid; t < T; t += 512) m = fmaxf(m, s_w[t]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if (lane == 0) s_red[wave] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])), fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7])));
+        __syncthreads();
+        float sum = 0.f;
+        for (int t = tid; t < T; t += 512) {
+            const float p = expf(s_w[t] - m);
+            s_w[t] = p;
+            sum += p;
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) s_red[wave] = sum;
+        __syncthreads();
+        const float inv = 1.0f / (((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + (s_red[6] + s_red[7])));
+        for (int t = tid; t < T; t += 512) {
+            const float w = s_w[t] * inv;
+            s_w[t] = w;
+            if (t >= t0 && t < t0 + ATT_MQ) {                // this workgroup's positions
+                a.w_prev[(size_t)b * T + t] = w;
+                const float wc = a.w_cum[(size_t)b * T + t] + w;
+                a.w_cum[(size_t)b * T + t] = wc;
+                if (a.wcum_save) a.wcum_save[(size_t)b * T + t] = wc;
+                if (a.align_out) a.align_out[(size_t)b * a.s_align_b + t] = w;
+            }
+        }
+        __syncthreads();
+        if (do_ctx) {
+            // context chunk `tile`: 16 lanes x 16 bytes cover its 64 channels of a row; 8 waves x 4 lane groups take 32 rows per
+            // round, 8 rounds of loads in flight
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = tb0 + 32 * u;
+                acc += (t < T ? s_w[t] : 0.f) * mm0[u];
+            }
+            for (int tb = tb0 + 256; tb < T; tb += 256) {
+                f32x4 mm[8];
+                float ww[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = tb + 32 * u;
+                    const int tc = t < T ? t : T - 1;
+                    mm[u] = *(const f32x4*)(mem + (size_t)tc * a.enc_dim);
+                    ww[u] = t < T ? s_w[tc] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += ww[u] * mm[u];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i] += __shfl_xor(acc[i], 16, 64);
+                acc[i] += __shfl_xor(acc[i], 32, 64);
+            }
+            if (rg == 0) *(f32x4*)&s_cpart[wave][cg * 4] = acc;
+            __syncthreads();
+            if (wave == 0) {
+                const float v = ((s_cpart[0][lane] + s_cpart[1][lane]) + (s_cpart[2][lane] + s_cpart[3][lane])) +
+                                ((s_cpart[4][lane] + s_cpart[5][lane]) + (s_cpart[6][lane] + s_cpart[7][lane]));
+                const int c = tile * 64 + lane;
+                a.ctx[(size_t)b * a.enc_dim + c] = v;
+                if (a.ctx_copy) a.ctx_copy[(size_t)b * a.s_ctx_copy + c] = v;
+            }
+        }
     }
 }
 
+// shapes the one-launch form (energies + softmax + context, AttArgs::xbuf) covers: the matrix-core energies kernel's, at least
+// enc_dim / 64 tiles per element (each of the first enc_dim / 64 workgroups takes one context chunk), a row of weights within 2 KB
+// of LDS (so that the workgroup still fits beside a small-batch GEMM workgroup)
+bool t2s_att_energy_ctx_ok(const AttArgs& a) {
+    static const bool no_mfma = getenv("T2S_ATT_VALU") != nullptr;
+    static const bool plain = getenv("T2S_ENERGY_XCD") && atoi(getenv("T2S_ENERGY_XCD")) == 0;
+    if (no_mfma || plain || a.att_dim != 128 || a.loc_f != 32 || a.loc_ks > 31 || !a.w_loc_denseT) return false;
+    if (a.q_part && a.n_part != 256) return false;
+    const int n_tiles = (a.T + ATT_MQ - 1) / ATT_MQ;
+    return a.T <= 512 && (a.enc_dim & 63) == 0 && n_tiles * 64 >= a.enc_dim && a.tag != 0;
+}
 hipError_t t2s_launch_att_energy(const AttArgs& a, hipStream_t stream) {
     // T2S_ATT_VALU set: the VALU kernel (A/B switch, shared with the fused small-batch form)
     static const bool no_mfma = getenv("T2S_ATT_VALU") != nullptr;
@@ -923,7 +1062,12 @@ hipError_t t2s_launch_att_energy(const AttArgs& a, hipStream_t stream) {
         AttArgs aa = a;
         aa.tile_major = plain ? 1 : 0;
         dim3 grid(8 * ((a.B + 7) / 8) * ((a.T + ATT_MQ - 1) / ATT_MQ));
-        hipLaunchKernelGGL(att_energy_mfma_kernel, grid, dim3(512), 0, stream, aa);
+        if (a.xbuf) {
+            if (plain || !t2s_att_energy_ctx_ok(a)) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(att_energy_mfma_kernel<true>, grid, dim3(512), (size_t)a.T * sizeof(float), stream, aa);
+            return hipGetLastError();
+        }
+        hipLaunchKernelGGL(att_energy_mfma_kernel<false>, grid, dim3(512), 0, stream, aa);
         return hipGetLastError();
     }
     if (a.q_part) return hipErrorInvalidValue;          // (only the matrix-core kernel sums partial queries)
