@@ -261,21 +261,6 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
                 ab.ctx = nullptr; ab.dw_carry = p->dw_c; ab.dwc_carry = p->dwc_c; ab.dw_carry_out = nullptr; ab.dwc_carry_out = nullptr;
             }
         }
-        if (fused) {
-            T2S_CHECK_HIP(t2s_launch_att_bwd_fused(ab, stream));
-        } else if (two_streams && conv_main) {
-            T2S_CHECK_HIP(t2s_launch_att_bwd(ab, stream));
-        } else if (two_streams) {
-            if (conv_pending) T2S_CHECK_HIP(hipStreamWaitEvent(stream, ev_conv, 0));   // carries of step t+1 are in place
-            T2S_CHECK_HIP(t2s_launch_att_bwd_front(ab, stream));
-            T2S_CHECK_HIP(hipEventRecord(ev_energy, stream));
-            T2S_CHECK_HIP(hipStreamWaitEvent(side2, ev_energy, 0));
-            T2S_CHECK_HIP(t2s_launch_att_bwd_conv(ab, side2));
-            T2S_CHECK_HIP(hipEventRecord(ev_conv, side2));
-            conv_pending = true;
-        } else {
-            T2S_CHECK_HIP(t2s_launch_att_bwd(ab, stream));
-        }
         // attention LSTMCell: dh = from the decoder cell input + from the query + from step t+1's attention cell
         LstmBwdArgs ca;
         ca.dh1 = p->out_d + (size_t)t * B * KD; ca.s1 = KD;
@@ -291,7 +276,28 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         ca.gates = p->att_gates_all + (size_t)t * B * 4 * A; ca.c_new = p->att_c_all + (size_t)t * B * A;
         ca.c_prev = t > 0 ? p->att_c_all + (size_t)(t - 1) * B * A : nullptr;
         ca.dc_carry = p->dc_a; ca.dgates = p->dg_a + (size_t)t * B * 4 * A; ca.B = B; ca.H = A;
-        T2S_CHECK_HIP(t2s_launch_lstm_cell_bwd(ca, stream));
+        // ... folded into the one-launch attention backward where it runs (t2s_taco_bptt::att_xbuf; T2S_BPTT_FOLD_CELL=0: a launch of its own)
+        static const bool want_fold = !(getenv("T2S_BPTT_FOLD_CELL") && atoi(getenv("T2S_BPTT_FOLD_CELL")) == 0);
+        const bool fold_cell = fused && want_fold && p->att_xbuf && Tin <= 512 && ad == 128;
+        if (fused) {
+            AttBwdFoldArgs fa;
+            memset(&fa, 0, sizeof(fa));
+            if (fold_cell) { fa.cell = ca; fa.xbuf = (unsigned long long*)p->att_xbuf; fa.tag = (unsigned)t + 1u; }
+            T2S_CHECK_HIP(t2s_launch_att_bwd_fused(ab, stream, fold_cell ? &fa : nullptr));
+        } else if (two_streams && conv_main) {
+            T2S_CHECK_HIP(t2s_launch_att_bwd(ab, stream));
+        } else if (two_streams) {
+            if (conv_pending) T2S_CHECK_HIP(hipStreamWaitEvent(stream, ev_conv, 0));   // carries of step t+1 are in place
+            T2S_CHECK_HIP(t2s_launch_att_bwd_front(ab, stream));
+            T2S_CHECK_HIP(hipEventRecord(ev_energy, stream));
+            T2S_CHECK_HIP(hipStreamWaitEvent(side2, ev_energy, 0));
+            T2S_CHECK_HIP(t2s_launch_att_bwd_conv(ab, side2));
+            T2S_CHECK_HIP(hipEventRecord(ev_conv, side2));
+            conv_pending = true;
+        } else {
+            T2S_CHECK_HIP(t2s_launch_att_bwd(ab, stream));
+        }
+        if (!fold_cell) T2S_CHECK_HIP(t2s_launch_lstm_cell_bwd(ca, stream));
         memset(&g, 0, sizeof(g));
         g.W1 = p->W_aT; g.ld1 = 4 * A; g.k1 = 4 * A; g.x1 = ca.dgates; g.n1 = 4 * A; g.sx1 = 4 * A;
         g.y = p->out_a + (size_t)t * B * KA; g.sy_item = KA; g.sy_row = 1; g.rows = KA; g.items = B; g.mask_scale = 1.f;

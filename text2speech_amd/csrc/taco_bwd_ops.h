@@ -47,6 +47,16 @@ struct AttBwdArgs {
     float* dw_carry_out; float* dwc_carry_out;
 };
 
+// Optional second argument of the one-launch attention backward: the attention LSTMCell's pointwise backward (with W_query^T d_q)
+// folded into the same launch.  The chunk workgroups of a batch element exchange their partial d_q through tagged 8-byte granules
+// (xbuf: [B][ceil(T/32)][128] + 1 error word, zero before a BPTT pass; tag = step + 1), each then does the cell backward of its share
+// of the hidden units.  T <= 512.
+struct AttBwdFoldArgs {
+    LstmBwdArgs cell;
+    unsigned long long* xbuf;
+    unsigned tag;
+};
+
 struct BnBwdArgs {
     const float* x;              // conv output [B][C][T] (pre-BN)
     const float* mean; const float* var; const float* gamma; const float* beta; float eps;
@@ -71,7 +81,7 @@ hipError_t t2s_launch_att_bwd_front(const AttBwdArgs& a, hipStream_t stream);
 hipError_t t2s_launch_att_bwd_conv(const AttBwdArgs& a, hipStream_t stream);
 // the three parts in one launch (needs ctx, the second carry pair, dctx_out; d_q is left as per-chunk partials in dq_part)
 bool t2s_att_bwd_fused_ok(const AttBwdArgs& a);
-hipError_t t2s_launch_att_bwd_fused(const AttBwdArgs& a, hipStream_t stream);
+hipError_t t2s_launch_att_bwd_fused(const AttBwdArgs& a, hipStream_t stream, const AttBwdFoldArgs* fold = nullptr);
 hipError_t t2s_launch_bn_bwd(const BnBwdArgs& a, double* partial, hipStream_t stream);
 hipError_t t2s_launch_planes_to_f32(const u16* X_hi, const u16* X_lo, int B, int C, int L, int Lp, int halo, float* out,
                                     int accumulate, hipStream_t stream);

@@ -5,6 +5,7 @@
 // tensors [items][C] are turned into time-major (hi, lo) planes by rows_to_tm_kernel and fed to the same split-K
 // conv_gemm weight-gradient path the WaveGlow backward uses.  What is genuinely sequential - the per-step chain
 // through the two LSTM cells and the location-sensitive attention - is the kernels below, one launch per stage.
+#include <string.h>
 #include "t2s_common.h"
 #include "t2s_kernels.h"
 #include "taco_bwd_ops.h"
@@ -795,7 +796,8 @@ static __device__ __forceinline__ float attf_carry(const float* c, size_t BT, si
     return v;
 }
 #define ATTF_SP 130
-__global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) {
+#define ATTF_SPIN_MAX (1 << 22)
+__global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a, const AttBwdFoldArgs fold) {
     constexpr int AD = 128, F = 32, SP = ATTF_SP, SD = 34, SG = 34;
     __shared__ __attribute__((aligned(16))) float s_all[128 + 64 * 48 + ATTB_CH * 33 + 32 * 144 + ATTB_CH * ATTF_SP + ATTB_CH * 34 + 1024 + 2 * ATTB_CH + 16];
     float* s_cat = s_all;                          // [2][64]    window of [w_prev ; wc_prev]: entry i <-> t0 - pad + i
@@ -812,11 +814,16 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
     float* s_red = s_de + ATTB_CH;                 // [16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    // batch element on blockIdx.x: workgroups go to the 8 XCDs round-robin by linear id, so the chunks of one batch element share an L2
-    const int b = blockIdx.x, chunk = blockIdx.y, t0 = chunk * ATTB_CH;
+    // block number -> (batch element, chunk): id = 8 s + x is chunk s % n_chunks of element 8 (s / n_chunks) + x - the chunks of an
+    // element share one XCD's L2 (workgroups go round the 8 XCDs by block number) and are neighbours in dispatch order (they wait
+    // for one another when the cell backward is folded in, below)
+    const int n_chunks = (a.T + ATTB_CH - 1) / ATTB_CH;
+    const int bsl = blockIdx.x >> 3;
+    const int b = (bsl / n_chunks) * 8 + (blockIdx.x & 7), chunk = bsl - (bsl / n_chunks) * n_chunks, t0 = chunk * ATTB_CH;
+    if (b >= a.B) return;                          // (whole workgroups)
     const int T = a.T, E = a.enc_dim, KS = a.loc_ks, pad = KS >> 1, K2 = 2 * KS;
     const int len = a.lengths ? a.lengths[b] : T;
-    const size_t slot = (size_t)b * gridDim.y + chunk, BT = (size_t)a.B * T;
+    const size_t slot = (size_t)b * n_chunks + chunk, BT = (size_t)a.B * T;
     ATTF_STAMP(0)
     // ---- loads: everything the kernel reads from global memory is requested here, unconditionally (clamped addresses, selects
     //      afterwards) and before the first use of any of it: one round trip to memory, not one per dependent group ----
@@ -1051,6 +1058,9 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
         if (lq == 0) {
             a.dq_part[slot * AD + ach] = dq;
             a.dv_part[slot * AD + ach] = dv_old + dvs;
+            if (fold.xbuf)                         // this chunk's partial d_q for the other chunks of the element (read at the end)
+                __hip_atomic_store(fold.xbuf + slot * AD + ach, ((unsigned long long)fold.tag << 32) | (unsigned long long)__float_as_uint(dq),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     ATTF_STAMP(7)
@@ -1160,6 +1170,86 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a) 
         }
     }
     ATTF_STAMP(11)
+    // ---- folded in: the attention LSTMCell's pointwise backward (lstm_cell_bwd_q_kernel's arithmetic) for this chunk's share of
+    //      the hidden units.  d_q = the sum of every chunk's partial, in chunk order; the partials were published half a kernel ago,
+    //      so the wait below is normally over before it starts.  One dependent launch less per step of the BPTT loop. ----
+    if (fold.xbuf) {                               // (uniform)
+        const LstmBwdArgs& ca = fold.cell;
+        __shared__ int s_fail;
+        if (tid == 0) s_fail = 0;
+        __syncthreads();                           // every stage above is done with the LDS regions reused below
+        float* s_x = s_dp;                         // [n_chunks][128] partials (n_chunks <= 16)
+        float* s_q = s_x + 16 * AD;                // [128] d_q
+        float* s_ee = s_q + AD;                    // [4][128]
+        bool ok = true;
+        for (int i = tid; i < n_chunks * AD; i += 512) {
+            const unsigned long long* g = fold.xbuf + ((size_t)b * n_chunks) * AD + i;
+            bool got = false;
+            for (int it = 0; it < ATTF_SPIN_MAX; ++it) {
+                const unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(v >> 32) == fold.tag) { s_x[i] = __uint_as_float((unsigned)v); got = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            ok = ok && got;
+        }
+        if (!ok) s_fail = 1;
+        __syncthreads();
+        if (s_fail) {
+            if (tid == 0) __hip_atomic_store(fold.xbuf + (size_t)a.B * n_chunks * AD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid < AD) {
+            float qsum = 0.f;
+            for (int c = 0; c < n_chunks; ++c) qsum += s_x[c * AD + tid];
+            s_q[tid] = qsum;
+            if (chunk == 0) a.d_q[(size_t)b * AD + tid] = qsum;
+        }
+        __syncthreads();
+        const int H = ca.H, U = (H + n_chunks - 1) / n_chunks;
+        const int u_lo = chunk * U, u_hi = u_lo + U < H ? u_lo + U : H;
+        const int ul = tid & 127, kq = tid >> 7;
+        for (int ub = u_lo; ub < u_hi; ub += 128) {
+            const int u = ub + ul;
+            const bool valid = u < u_hi;
+            const int uc = valid ? u : u_lo;
+            float w[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) w[i] = ca.wq[(size_t)(kq * 32 + i) * H + uc];
+            const size_t idx = (size_t)b * H + uc;
+            float dh = 0.f, gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, cn = 0.f, cp = 0.f, dcc = 0.f;
+            bool keep = true;
+            if (kq == 0) {
+                dh = sum3(ca.dh1, ca.s1, ca.dh2, ca.s2, ca.dh3, ca.s3, b, uc);
+                const float* g4 = ca.gates + (size_t)b * 4 * H + uc;
+                gi = g4[0]; gf = g4[H]; gg = g4[2 * H]; go = g4[3 * H];
+                cn = ca.c_new[idx];
+                cp = ca.c_prev ? ca.c_prev[idx] : 0.f;
+                dcc = ca.dc_carry[idx];
+                if (ca.drop_mask) keep = ca.drop_mask[idx] != 0;
+            }
+            float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; i += 2) {
+                e0 += s_q[kq * 32 + i] * w[i];
+                e1 += s_q[kq * 32 + i + 1] * w[i + 1];
+            }
+            s_ee[kq * AD + ul] = e0 + e1;
+            __syncthreads();
+            if (kq == 0 && valid) {
+                dh += (s_ee[ul] + s_ee[AD + ul]) + (s_ee[2 * AD + ul] + s_ee[3 * AD + ul]);
+                if (ca.drop_mask) dh = keep ? dh * ca.drop_scale : 0.f;
+                const float tc = tanhf(cn);
+                const float dc = dcc + dh * go * (1.f - tc * tc);
+                float* dg = ca.dgates + (size_t)b * 4 * H + u;
+                dg[0] = dc * gg * gi * (1.f - gi);
+                dg[H] = dc * cp * gf * (1.f - gf);
+                dg[2 * H] = dc * gi * (1.f - gg * gg);
+                dg[3 * H] = dh * tc * go * (1.f - go);
+                ca.dc_carry[idx] = dc * gf;
+            }
+            __syncthreads();
+        }
+    }
 }
 
 static bool att_bwd_ok(const AttBwdArgs& a) {
@@ -1194,10 +1284,19 @@ bool t2s_att_bwd_fused_ok(const AttBwdArgs& a) {
     return !off && att_bwd_ok(a) && a.att_dim == 128 && a.loc_f == 32 && a.loc_ks <= 31 && a.ctx && a.dw_carry_out &&
            a.dwc_carry_out && a.dctx_out && !a.d_memory && a.dw_carry_out != a.dw_carry && a.dwc_carry_out != a.dwc_carry;
 }
-hipError_t t2s_launch_att_bwd_fused(const AttBwdArgs& a, hipStream_t stream) {
+hipError_t t2s_launch_att_bwd_fused(const AttBwdArgs& a, hipStream_t stream, const AttBwdFoldArgs* fold) {
     if (!t2s_att_bwd_fused_ok(a)) return hipErrorInvalidValue;
-    const dim3 grid(a.B, (a.T + ATTB_CH - 1) / ATTB_CH);
-    hipLaunchKernelGGL(att_bwd_fused_kernel, grid, dim3(512), 0, stream, a);
+    AttBwdFoldArgs f;
+    memset(&f, 0, sizeof(f));
+    if (fold && fold->xbuf) {
+        const LstmBwdArgs& c = fold->cell;
+        if (a.T > 512 || a.att_dim != 128 || !c.wq || c.q_dim != 128 || c.B != a.B || c.H <= 0 || !c.gates || !c.c_new || !c.dc_carry ||
+            !c.dgates || fold->tag == 0)
+            return hipErrorInvalidValue;
+        f = *fold;
+    }
+    const dim3 grid(8 * ((a.B + 7) / 8) * ((a.T + ATTB_CH - 1) / ATTB_CH));
+    hipLaunchKernelGGL(att_bwd_fused_kernel, grid, dim3(512), 0, stream, a, f);
     return hipGetLastError();
 }
 hipError_t t2s_launch_att_bwd(const AttBwdArgs& a, hipStream_t stream) {

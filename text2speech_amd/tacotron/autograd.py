@@ -47,7 +47,7 @@ class _Bptt(ctypes.Structure):
                 [(n, vp) for n in ("d_hc", "out_d", "out_a", "dg_d", "dg_a", "dq_all", "dc_d", "dc_a", "dw_c",
                                    "dwc_c", "d_pmem", "d_memory", "dD_part", "dK_part", "dv_part", "dw_buf", "df_buf",
                                    "dq_part", "dctx_all", "ctx_all")] +
-                [("s_ctx_step", lng), ("s_ctx_item", lng), ("dw_c2", vp), ("dwc_c2", vp)])
+                [("s_ctx_step", lng), ("s_ctx_item", lng), ("dw_c2", vp), ("dwc_c2", vp), ("att_xbuf", vp)])
 
 
 class _BnBwd(ctypes.Structure):
@@ -364,6 +364,12 @@ class _Bwd:
         if dctx_all is not None:                   # the forward's contexts: hc_all[t][b] = [h_dec | ctx]
             bp.ctx_all, bp.s_ctx_step, bp.s_ctx_item = _p(sv["hc_all"], D), B * (D + E), D + E
             bp.dw_c2, bp.dwc_c2 = _p(dw_c2), _p(dwc_c2)
+            if T_in <= 512 and ad == 128:
+                # exchange buffer of the attention cell's backward folded into the attention backward's launch (t2s_taco_bptt::att_xbuf):
+                # 8-byte granules as f32 pairs, zero = no tag matches
+                att_xbuf = self.zeros(2 * (B * nch * ad + 1))
+                bp.att_xbuf = _p(att_xbuf)
+                self.keep.append(att_xbuf)
         _lib.call("t2s_taco_bptt_steps", ctypes.byref(bp), T, 0, st)        # the whole reversed loop, enqueued from C++
         if dctx_all is not None:
             # d_memory[b] = sum_t w[t][b][:] (x) d_ctx[t][b][:]: one contraction over the decoder steps per batch element
