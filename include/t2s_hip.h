@@ -337,7 +337,7 @@ typedef struct t2s_taco_decoder {
      * cell streams all of [W_ih | W_hh]. */
     float *dec_in_part;
     /* ABI v4.  (B * T_in + 1) 8-byte words, ZERO before step 0 of a sequence (state like gate_part: tags are step numbers), or NULL.
-     * At 9+ items with attention_dim 128, 32 location filters, T_in <= 512 and at least enc_dim / 64 tiles of 32 positions, the
+     * At 9+ items with attention_dim 128, 32 location filters, T_in <= 512 and enc_dim a multiple of 64, the
      * energies launch also does softmax, cumulative weights and context: the workgroups of a batch element exchange their energies
      * through tagged granules here instead of ending the launch.  The last word is raised if a bounded wait expires.  A buffer
      * serves every step INDEX once per zeroing (the tag of step s is s + 1): callers that revisit step indices pass NULL.

@@ -34,9 +34,11 @@ for a, b in zip(cuts[:-1], cuts[1:]):
     seg = rows[a + 1:b + 1]
     t0, t1 = rows[a][2], rows[b][2]
     f0 = next(r[1] for r in seg if "sbgemm_lstm" in r[0])
-    f1 = max(r[2] for r in seg if "att_softmax_ctx" in r[0])
     b0 = next(r[1] for r in seg if "att_bwd_fused" in r[0])
-    b1 = max(r[2] for r in seg if "lstm_cell_bwd_q" in r[0] or "sbgemm_plain" in r[0] and r[1] < max(x[2] for x in seg if "att_bwd_fused" in x[0]) + 50000)
+    # (the attention's last launch of the forward loop: softmax + context, or the energies launch that contains them)
+    f1 = max(r[2] for r in seg if ("att_softmax_ctx" in r[0] or "att_energy" in r[0]) and r[1] < b0)
+    last_att = max(x[2] for x in seg if "att_bwd_fused" in x[0])
+    b1 = max(r[2] for r in seg if ("lstm_cell_bwd_q" in r[0] or "sbgemm_plain" in r[0]) and r[1] < last_att + 50000)
     ph = [(t0, f0), (f0, f1), (f1, b0), (b0, b1), (b1, t1)]
     cells = ["%.2f (%.0f %% busy)" % ((hi - lo) / 1e6, 100.0 * busy(seg, lo, hi) / max(1, hi - lo)) for lo, hi in ph]
     print("| %d | %s | %.2f |" % (cuts.index(a), " | ".join(cells), (t1 - t0) / 1e6))
