@@ -57,6 +57,7 @@ int t2s_operand_format(void);
 /* ABI v4.  sizeof(t2s_taco_decoder) / sizeof(t2s_taco_bptt) as this library was compiled: a binding that mirrors the structs field by
  * field (ctypes, cgo, JNI) checks its own size against these before the first call. */
 int t2s_sizeof_taco_decoder(void);
+int t2s_sizeof_taco_bptt(void);
 const char* t2s_error_string(int code);
 /* last HIP error text seen by a failing entry point on this thread ("" if none) */
 const char* t2s_last_hip_error(void);

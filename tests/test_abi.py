@@ -37,7 +37,9 @@ def test_pure_host_entry_points(lib):
     assert lib.t2s_abi_version() == 4      # round 4: t2s_taco_decoder grew (gate_part, w_pre2T); INTEGRATION.md lists what changed per version
     import ctypes
     from text2speech_amd.tacotron.tacotron import _DecoderStruct
-    assert lib.t2s_sizeof_taco_decoder() == ctypes.sizeof(_DecoderStruct)       # the ctypes mirror against the compiled struct
+    assert lib.t2s_sizeof_taco_decoder() == ctypes.sizeof(_DecoderStruct)       # the ctypes mirrors against the compiled structs
+    from text2speech_amd.tacotron.autograd import _Bptt
+    assert lib.t2s_sizeof_taco_bptt() == ctypes.sizeof(_Bptt)
     assert lib.t2s_plane_rows(2000, 128) == 2048 + 256
     assert lib.t2s_plane_rows(256, 0) == 256
     assert lib.t2s_padded_rows(1024) == 1024 and lib.t2s_padded_rows(130) == 256

@@ -17,6 +17,7 @@ SIGNATURES = {
     "t2s_abi_version": [],
     "t2s_operand_format": [],
     "t2s_sizeof_taco_decoder": [],
+    "t2s_sizeof_taco_bptt": [],
     "t2s_error_string": [c_int],
     "t2s_last_hip_error": [],
     "t2s_plane_rows": [c_int, c_int],

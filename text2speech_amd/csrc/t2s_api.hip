@@ -29,6 +29,7 @@ extern "C" {
 int t2s_abi_version(void) { return 4; }
 
 int t2s_sizeof_taco_decoder(void) { return (int)sizeof(t2s_taco_decoder); }
+int t2s_sizeof_taco_bptt(void) { return (int)sizeof(t2s_taco_bptt); }
 
 int t2s_operand_format(void) {
 #ifdef T2S_SPLIT_F16
