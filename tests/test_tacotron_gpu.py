@@ -242,14 +242,16 @@ def test_streamed_gate_partials_match_unstreamed_decode(model, B, T_in, n):
         assert _rel(x, y) < 2e-5 and _maxrel(x, y) < 1e-4, (name, _rel(x, y), _maxrel(x, y))
 
 
-@pytest.mark.parametrize("B,n_sym,n", [(1, 128, 400), (1, 200, 200), (1, 600, 24), (6, 40, 30)])
+@pytest.mark.parametrize("B,n_sym,n", [(1, 128, 400), (1, 200, 200), (1, 600, 24), (6, 40, 30), (9, 70, 70)])
 def test_inference_long_inputs_vs_oracle(model, B, n_sym, n):
     """The end-to-end bench's shape (tools/bench_e2e.py: 128 symbols) and a longer input, against the CPU oracle over hundreds of
     recurrent steps: the attention's location term comes out of the previous step's projection launch (t2s_taco_decoder::ploc) and
     the attention role reads 128 / 200 encoder positions - neither the 64-symbol goldens nor the A/B test above compare that with
     the oracle.  Then the two small-batch chains the cases above do not reach: 600 positions (beyond the one-workgroup attention's
-    512: query GEMV, energies and softmax + context as three launches behind the wave-per-row cells) and 6 items (one-workgroup
-    attention, but more than the 4 items the streamed gate partials are used for - the round-3 chain)."""
+    512: query GEMV, energies and softmax + context as three launches behind the wave-per-row cells), 6 items (one-workgroup
+    attention, but more than the 4 items the streamed gate partials are used for - the round-3 chain) and 9 items free-running (the
+    matrix-core cells with the one-launch attention of the teacher-forced chain, t2s_taco_decoder::att_xbuf, tags across several
+    t2s_taco_decode_steps calls)."""
     from oracle import tacotron_oracle as O
     gen = torch.Generator().manual_seed(n_sym)
     ids = torch.randint(2, 80, (B, n_sym), generator=gen)
