@@ -344,6 +344,11 @@ typedef struct t2s_taco_decoder {
      * serves every step INDEX once per zeroing (the tag of step s is s + 1): callers that revisit step indices pass NULL.
      * NULL (or T2S_ATT_ONE_LAUNCH=0): energies and softmax + context stay two launches. */
     void *att_xbuf;
+    /* ABI v4.  16 bytes (a step counter and an error word), ZERO before step 0 of a sequence, or NULL.  Teacher forced at 9+ items with
+     * att_h_all: instead of running a chunk of 16 steps behind, the helper stream's decoder cell of step s - 1 is released by a word
+     * the attention cell's launch of step s stores as it starts, so that it runs beside the attention launch of step s (whose
+     * workgroups share a CU with it) and is over when the next attention cell needs the chip.  NULL (or T2S_DECODE_PACED=0): chunks. */
+    void *pace_flag;
 } t2s_taco_decoder;
 
 /* Enqueue decoder steps [step0, step0+n_steps) (Decoder.decode, tacotron.py:355-393, plus in autoregressive mode

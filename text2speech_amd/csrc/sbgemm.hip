@@ -358,6 +358,8 @@ template <int KW>
 __global__ __launch_bounds__(512) void sbgemm_lstm_kernel(const LstmCellArgs a) {
     SB_DECL_PART
     extern __shared__ __attribute__((aligned(16))) char sb_ring[];
+    if (a.sig_ptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)       // "this launch has started" (LstmCellArgs::sig_ptr)
+        __hip_atomic_store(a.sig_ptr, a.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     SbOperands o;
     const int K1 = a.n1 + a.n2;
     o.W1 = a.W_ih; o.ld1 = K1; o.k1 = K1; o.W2 = a.W_hh; o.ld2 = a.H;

@@ -217,7 +217,14 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
     // GEMM kernel re-reads its 16 weight rows per group of 32 items and the 32 input vectors per 16 rows (1.2 GB of L2 reads per
     // 512-item chunk), which costs what the per-step cells save.  Off unless T2S_DECODE_CHUNK_GEMM=1.
     static const bool want_chunk_gemm = getenv("T2S_DECODE_CHUNK_GEMM") && atoi(getenv("T2S_DECODE_CHUNK_GEMM")) != 0;
-    const bool chunk_gemm = split && want_chunk_gemm && d->dec_in_part && B > 8 && !((A | D | E) & 31);
+    // Paced decoder cells (t2s_taco_decoder::pace_flag): the helper stream's cell of step s - 1 is released by a word the attention
+    // cell's launch of step s stores as it STARTS, i.e. when the attention of step s - 1 is complete.  It is enqueued ~4 us later, finds
+    // the chip held by that attention cell, and runs as its workgroups retire - beside the attention launch of step s, whose small
+    // workgroups share a CU with it - and is over when the next attention cell needs the CUs.  In bursts of 16 (the chunked form) the
+    // helper's cells kept the chain's next attention cell from starting: their time ADDED to the chain's.  T2S_DECODE_PACED=0: chunks.
+    static const bool want_paced = !(getenv("T2S_DECODE_PACED") && atoi(getenv("T2S_DECODE_PACED")) == 0);
+    const bool paced = split && want_paced && d->pace_flag && B > 8 && !((uintptr_t)d->pace_flag & 7);
+    const bool chunk_gemm = split && !paced && want_chunk_gemm && d->dec_in_part && B > 8 && !((A | D | E) & 31);
     int part_c0 = 0;                                       // first step of the chunk whose products dec_in_part holds
     auto body = [&](int s, bool do_att, bool do_dec) -> int {
         float* ah_in = (s & 1) ? d->att_h1 : d->att_h0;
@@ -275,6 +282,12 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
             stream_gates = t2s_att_fused_stream_ok(probe, gs);
         }
         if (stream_gates) { ca.h_in = nullptr; ca.pre_a = d->gate_part + 2 * GP; }
+        bool sig_by_kernel = false;
+        if (paced) {
+            ca.sig_ptr = (unsigned*)d->pace_flag; ca.sig_val = (unsigned)s + 1u;
+            sig_by_kernel = t2s_sbgemm_lstm_ok(ca);          // (the matrix-core cell stores the word itself)
+            if (!sig_by_kernel) T2S_CHECK_HIP(t2s_launch_pace_signal(ca.sig_ptr, ca.sig_val, stream));
+        }
         // ... and with it the prenet's second layer folded into this launch (every workgroup recomputes the 256 outputs from
         // pre1 and W_pre2 out of L2) instead of a GEMV launch of its own at the end of the previous step.  T2S_DECODE_FOLD_PRE2=0: off
         static const bool want_fold = !(getenv("T2S_DECODE_FOLD_PRE2") && atoi(getenv("T2S_DECODE_FOLD_PRE2")) == 0);
@@ -406,7 +419,24 @@ int t2s_taco_decode_steps(const t2s_taco_decoder* d, int step0, int n_steps, voi
         }
         return T2S_OK;
     };
-    if (split) {
+    if (paced) {
+        T2S_CHECK_HIP(hipEventRecord(hs.ev_step, stream));            // everything enqueued so far precedes the helper's first cell
+        T2S_CHECK_HIP(hipStreamWaitEvent(hs.side, hs.ev_step, 0));
+        unsigned long long* perr = (unsigned long long*)d->pace_flag + 1;
+        for (int s = step0; s < step0 + n_steps; ++s) {
+            const int rc = body(s, true, false);
+            if (rc != T2S_OK) return rc;
+            if (s > step0) {
+                T2S_CHECK_HIP(t2s_launch_pace_wait((const unsigned*)d->pace_flag, (unsigned)s + 1u, perr, hs.side));
+                const int rd = body(s - 1, false, true);
+                if (rd != T2S_OK) return rd;
+            }
+        }
+        // the last step's cell: after its attention (the chain is over: one event costs nothing now)
+        T2S_CHECK_HIP(hipEventRecord(hs.ev_step, stream));
+        T2S_CHECK_HIP(hipStreamWaitEvent(hs.side, hs.ev_step, 0));
+        { const int rd = body(step0 + n_steps - 1, false, true); if (rd != T2S_OK) return rd; }
+    } else if (split) {
         // the attention chain of `chunk` steps, ONE event, then the decoder cells of those steps on the helper stream while the
         // caller's stream goes on with the next chunk (T2S_DECODE_CHUNK, default 16)
         static const int chunk_env = getenv("T2S_DECODE_CHUNK") ? atoi(getenv("T2S_DECODE_CHUNK")) : 16;

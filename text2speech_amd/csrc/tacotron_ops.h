@@ -62,7 +62,15 @@ struct LstmCellArgs {
     // (modules.py:19-22, the prenet's second Linear + ReLU + always-on dropout; w_p2 = the TRANSPOSED weight, walked sparsely:
     // lstm_cell_p2_kernel)
     const float* w_p2; const float* p1; const unsigned char* p2_mask; long s_p2_mask; float p2_scale;
+    // matrix-core form only: the first thread of the launch stores sig_val to *sig_ptr (agent scope) as the kernel STARTS - i.e. when
+    // everything in front of it on its stream has completed.  A helper stream's t2s_launch_pace_wait on that word then releases work
+    // that should run beside what FOLLOWS this launch (the teacher-forced decoder cell beside the attention launch).
+    unsigned* sig_ptr; unsigned sig_val;
 };
+// one wave that polls *flag (bounded) until it has reached `val`; the launches behind it on `stream` start then.  err: a word that is
+// raised if the wait expires (may be null)
+hipError_t t2s_launch_pace_wait(const unsigned* flag, unsigned val, unsigned long long* err, hipStream_t stream);
+hipError_t t2s_launch_pace_signal(unsigned* flag, unsigned val, hipStream_t stream);
 
 // Role-specialised second half of the fused attention launch (B <= 8): while ONE workgroup per batch element runs the
 // attention of step t (10.7 us with 255 CUs and HBM idle), the other workgroups stream the three [4H][H] weight blocks whose

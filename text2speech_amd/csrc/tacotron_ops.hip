@@ -800,9 +800,12 @@ __global__ __launch_bounds__(512, 2) void att_energy_mfma_kernel(const AttArgs a
     __shared__ float s_cat[2][ATT_MQ + 64];
     // 13 KB of LDS in all, so that a workgroup fits on a CU next to a small-batch GEMM workgroup (144 KB ring): in training the
     // decoder cells run on a helper stream beside this chain
-    __shared__ float s_kb[2 * 64 * 16];        // conv kernel as B operand, one half per filter tile: [f / 16][k = c * KS + j][f % 16], rows >= 2 KS zero
-    __shared__ float s_f[ATT_MQ * 33];
+    // (round 4: the 8 KB of partial-query sums share the conv kernel's buffer - with a buffer of their own the kernel had 21 KB and
+    // no longer fitted beside the GEMM: profiles/r04_taco_timeline_paced_before.md, the attention launch ran AFTER the decoder cell)
+    __shared__ __attribute__((aligned(16))) float s_kb[2 * 64 * 16];        // conv kernel as B operand, one half per filter tile: [f / 16][k = c * KS + j][f % 16], rows >= 2 KS zero
+    __shared__ __attribute__((aligned(16))) float s_f[ATT_MQ * 33];
     float (*s_e)[ATT_MQ] = (float (*)[ATT_MQ])s_kb;      // [8][32] partial energies (after the features: s_kb is free)
+    float (*s_qp)[128] = (float (*)[128])s_kb;           // [16][128] partial-query sums (before the conv kernel is put there)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     // Block -> (item, tile of 32 positions): all tiles of one item on ONE XCD (workgroups go round the 8 XCDs by block number), so
@@ -815,18 +818,19 @@ __global__ __launch_bounds__(512, 2) void att_energy_mfma_kernel(const AttArgs a
     if (b >= a.B) return;
     const int t0 = tile * ATT_MQ;
     const int T = a.T, KS = a.loc_ks, pad = KS >> 1, K2 = 2 * KS;
-    for (int i = tid; i < 2 * 64 * 16; i += 512) s_kb[i] = 0.f;
     for (int i = tid; i < 2 * (ATT_MQ + KS - 1); i += 512) {
         const int c = i / (ATT_MQ + KS - 1), j = i - c * (ATT_MQ + KS - 1);
         const int t = t0 + j - pad;
         const float* src = c ? a.w_cum : a.w_prev;
         s_cat[c][j] = (t >= 0 && t < T) ? src[(size_t)b * T + t] : 0.f;
     }
+    // entry tid + 512 j of the B-operand buffer: (filter tile ft, row k, filter f % 16) <- K[f][k], zero rows k >= 2 KS
     float rk[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int i = tid + j * 512;
-        rk[j] = i < 32 * K2 ? a.w_loc_conv[i] : 0.f;
+        const int ft = i >> 10, k = (i >> 4) & 63, f = ft * 16 + (i & 15);
+        rk[j] = k < K2 ? a.w_loc_conv[f * K2 + k] : 0.f;
     }
     const int ach = 16 * wave + lr;
     float bd[8];
@@ -835,7 +839,6 @@ __global__ __launch_bounds__(512, 2) void att_energy_mfma_kernel(const AttArgs a
     // The query: given (a.q), or the sum of the per-workgroup partials the attention cell's launch left (a.q_part, n_part = 256:
     // thread = (four consecutive channels, one of 16 slices of 16 partials), 16 float4 loads in flight at once next to the loads
     // above - one round trip for the 128 KB -, then a 16-way sum through LDS in a fixed order).
-    __shared__ __attribute__((aligned(16))) float s_qp[16][AD];
     const bool parts = a.q_part != nullptr;
     if (parts) {
         const int aq = tid & 31, part = tid >> 5;
@@ -860,14 +863,6 @@ __global__ __launch_bounds__(512, 2) void att_energy_mfma_kernel(const AttArgs a
             pm[tt][r] = t < T ? a.pmem[((size_t)b * T + t) * AD + ach] : 0.f;
         }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = tid + j * 512;
-        if (i < 32 * K2) {
-            const int f = i / K2, k = i - f * K2;
-            s_kb[(f >> 4) * 1024 + k * 16 + (f & 15)] = rk[j];
-        }
-    }
     if (parts) {
         float q = 0.f;
 #pragma unroll
@@ -877,7 +872,10 @@ __global__ __launch_bounds__(512, 2) void att_energy_mfma_kernel(const AttArgs a
             if (a.q_out) a.q_out[(size_t)b * AD + ach] = q;
             if (a.q_save) a.q_save[(size_t)b * AD + ach] = q;
         }
+        __syncthreads();                                     // (uniform) the partial sums are read: their buffer takes the conv kernel
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s_kb[tid + j * 512] = rk[j];
     __syncthreads();
     if (wave < 4) {
         const int tt = wave >> 1, ft = wave & 1;
@@ -927,7 +925,7 @@ __global__ __launch_bounds__(512, 2) void att_energy_mfma_kernel(const AttArgs a
         extern __shared__ float s_w[];                       // [T] energies, then weights
         __shared__ float s_red[8];
         __shared__ int s_fail;
-        __shared__ __attribute__((aligned(16))) float s_cpart[8][64];
+        float (*s_cpart)[64] = (float (*)[64])s_f;              // [8][64] (the features are consumed by now)
         unsigned long long* xrow = a.xbuf + (size_t)b * T;
         if (tid == 0) s_fail = 0;
         if (tid < ATT_MQ) {
@@ -2115,6 +2113,30 @@ hipError_t t2s_launch_lstm_seq_split(const float* gx, const float* whhT_f, const
     if (T >= 4095) return hipErrorInvalidValue;              // (12 tag bits for the step)
     hipLaunchKernelGGL(lstm_seq_split_kernel, dim3(((2 * B + 7) / 8) * 32), dim3(1024), 0, stream, gx, whhT_f, whhT_r, lengths, out,
                        B, T, T_out, gates_save, c_save, xbuf, epoch & 0xFFFFFu);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pacing a helper stream by a device word instead of events (an event record between two launches of the serial chain opens a
+// ~7 us gap on it; a word stored by the first thread of a chain launch costs nothing there).  One wave polls, bounded.
+__global__ void pace_wait_kernel(const unsigned* flag, unsigned val, unsigned long long* err) {
+    if (threadIdx.x != 0) return;
+    for (int it = 0; it < (1 << 22); ++it) {
+        const unsigned v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(v - val) >= 0) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (err) __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void pace_signal_kernel(unsigned* flag, unsigned val) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+hipError_t t2s_launch_pace_wait(const unsigned* flag, unsigned val, unsigned long long* err, hipStream_t stream) {
+    hipLaunchKernelGGL(pace_wait_kernel, dim3(1), dim3(64), 0, stream, flag, val, err);
+    return hipGetLastError();
+}
+hipError_t t2s_launch_pace_signal(unsigned* flag, unsigned val, hipStream_t stream) {
+    hipLaunchKernelGGL(pace_signal_kernel, dim3(1), dim3(64), 0, stream, flag, val);
     return hipGetLastError();
 }
 

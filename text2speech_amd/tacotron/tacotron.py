@@ -178,6 +178,7 @@ class Decoder(OwnedModule):
             extra = dict(pre_all=pre, hc_all=hc)
             d, S = eng._decoder_struct(mem, len32, 2, True, extra)
             d.att_xbuf = None       # (its tags are step numbers, used once per sequence: the two step slots here repeat them)
+            d.pace_flag = None
             self.__dict__["_step"] = dict(d=d, S=S, n=0, len32=len32, B=B, T_in=T_in, E=E)
             self.memory, self.processed_memory, self.mask = memory, S["pmem"], mask
             self._publish_state()
@@ -242,7 +243,7 @@ class _DecoderStruct(ctypes.Structure):
     _F = ["att_drop_scale", "dec_drop_scale"]
     _P2 = ["att_h0", "att_h1", "att_c", "dec_h0", "dec_h1", "dec_c", "att_w", "att_wcum", "ctx", "q", "energies",
            "pre1", "pre2", "q_part", "mel_gate_out", "align_out", "hc_all", "att_gates_all", "att_c_all",
-           "dec_gates_all", "dec_c_all", "att_h_all", "q_all", "wcum_all", "gate_part", "w_pre2T", "ploc", "dec_in_part", "att_xbuf"]
+           "dec_gates_all", "dec_c_all", "att_h_all", "q_all", "wcum_all", "gate_part", "w_pre2T", "ploc", "dec_in_part", "att_xbuf", "pace_flag"]
     _fields_ = ([(n, ctypes.c_int) for n in _I] + [(n, ctypes.c_void_p) for n in _P1] +
                 [(n, ctypes.c_float) for n in _F] + [(n, ctypes.c_void_p) for n in _P2])
 
@@ -603,6 +604,8 @@ class _TacoEngine:
                       pre1=(B, Pd), pre2=(B, Pd), q_part=(A // 2, B, ad))
         if B > 8 and T_in <= 512:
             shapes["att_xbuf"] = (2 * (B * T_in + 1),)      # (8-byte granules + error word, as f32 pairs; zero = no tag matches)
+        if B > 8 and teacher:
+            shapes["pace_flag"] = (4,)                      # step counter + error word of the paced decoder cells
         if not teacher:
             shapes["align_out"] = (B, T_cap, T_in)          # rows past the stop step stay zero
             if B <= 8 and A == 1024 and D == 1024 and getattr(self, "decode_stream", True):
