@@ -811,6 +811,11 @@ __global__ __launch_bounds__(512, 2) void att_energy_mfma_kernel(const AttArgs a
     // Block -> (item, tile of 32 positions): all tiles of one item on ONE XCD (workgroups go round the 8 XCDs by block number), so
     // that the item's 128 KB of partial queries cross the fabric once and its other tiles find them in that XCD's L2 - with the
     // plain (tile, item) grid every XCD pulled every item's partials (32 MB per launch at B = 32, T = 256 instead of 4 MB).
+    // this kernel is the serial chain; what shares its CUs (a decoder cell's GEMM workgroup on the helper stream) is not: its waves
+    // ask for issue priority (T2S_ATT_SETPRIO=0 at build time: -DT2S_ATT_NO_SETPRIO)
+#ifndef T2S_ATT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const int n_tiles = (a.T + ATT_MQ - 1) / ATT_MQ;
     const int slot = blockIdx.x >> 3;
     int b = (slot / n_tiles) * 8 + (blockIdx.x & 7), tile = slot - (slot / n_tiles) * n_tiles;
