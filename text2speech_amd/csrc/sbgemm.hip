@@ -342,7 +342,7 @@ hipError_t t2s_launch_sbgemm_plain(const GemvArgs& a, hipStream_t stream) {
     // 16 items per workgroup where twice the workgroups still fit one round of the chip (T2S_SB_HALF=0: never): the attention
     // cell's transposed GEMM of the BPTT loop (1792 rows = 112 workgroups at 32 items) pulls 512 instead of 768 KB per CU
     static const bool half_ok = !(getenv("T2S_SB_HALF") && atoi(getenv("T2S_SB_HALF")) == 0);
-    const bool half = half_ok && a.items > 16 && (long)grid.x * ((a.items + 15) / 16) <= 256;
+    const bool half = half_ok && !a.no_half && a.items > 16 && (long)grid.x * ((a.items + 15) / 16) <= 256;
     if (half) grid.y = (a.items + 15) / 16;
     if (!a.narrow_ring && sb_wide_ok(a.n1 + a.n2 + a.n3, a.k1, a.n1, a.n2, a.n3))
         return half ? sb_launch<32, GemvArgs, 1>(sbgemm_plain_kernel<32, true>, a, grid, stream) : sb_launch<32>(sbgemm_plain_kernel<32>, a, grid, stream);

@@ -212,6 +212,10 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         g.W1 = p->W_dT; g.ld1 = 4 * D; g.k1 = 4 * D; g.x1 = cd.dgates; g.n1 = 4 * D; g.sx1 = 4 * D;
         g.y = p->out_d + (size_t)t * B * KD; g.sy_item = KD; g.sy_row = 1; g.rows = KD; g.items = B; g.mask_scale = 1.f;
         g.narrow_ring = side_narrow ? 1 : 0;
+        static const bool side_full = getenv("T2S_BPTT_SIDE_FULL") && atoi(getenv("T2S_BPTT_SIDE_FULL")) != 0;
+        // (A/B: 32 items per workgroup on the helper chain's per-step GEMM - fewer, longer workgroups: 77.1 / 77.6 against
+        // 73.5 / 73.7 ms per train step, profiles/r04_bptt_side_full_ab.txt; off)
+        g.no_half = (side_full && two_streams) ? 1 : 0;
         if (split_rows) {
             // only the rows the NEXT decoder-cell step reads (d h_dec(t-1) = rows A + E .. KD of [W_ih | W_hh]^T dgates) stay per step;
             // the d h_att / d ctx rows, which the attention chain reads a chunk later, are one GEMM over the chunk's items below

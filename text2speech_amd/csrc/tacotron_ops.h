@@ -33,6 +33,8 @@ struct GemvArgs {
     // small-batch GEMM only: the 96 KB operand ring (64-byte fragment rows) instead of the 144 KB one, so that a 61 KB workgroup of
     // another stream's kernel (att_bwd_fused_kernel) fits on the same CU - for launches on a helper stream with slack
     int narrow_ring;
+    // small-batch GEMM only: never the 16-items-per-workgroup form (helper-stream launches: fewer, longer workgroups cost less CU time)
+    int no_half;
 };
 
 struct LstmCellArgs {
