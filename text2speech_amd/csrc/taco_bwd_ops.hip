@@ -817,6 +817,9 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a, 
     // block number -> (batch element, chunk): id = 8 s + x is chunk s % n_chunks of element 8 (s / n_chunks) + x - the chunks of an
     // element share one XCD's L2 (workgroups go round the 8 XCDs by block number) and are neighbours in dispatch order (they wait
     // for one another when the cell backward is folded in, below)
+#ifdef T2S_ATTB_SETPRIO
+    __builtin_amdgcn_s_setprio(3);                 // (A/B build: this kernel is the backward's serial chain)
+#endif
     const int n_chunks = (a.T + ATTB_CH - 1) / ATTB_CH;
     const int bsl = blockIdx.x >> 3;
     const int b = (bsl / n_chunks) * 8 + (blockIdx.x & 7), chunk = bsl - (bsl / n_chunks) * n_chunks, t0 = chunk * ATTB_CH;
