@@ -797,7 +797,14 @@ static __device__ __forceinline__ float attf_carry(const float* c, size_t BT, si
 }
 #define ATTF_SP 130
 #define ATTF_SPIN_MAX (1 << 22)
-__global__ __launch_bounds__(512) void att_bwd_fused_kernel(const AttBwdArgs a, const AttBwdFoldArgs fold) {
+#ifdef T2S_ATTB_LB2             // A/B build: two workgroups per CU by registers (128 VGPRs instead of 185, 188 bytes of scratch per thread):
+                                // 89.3 / 90.3 against 74.1 / 73.8 ms per train step (profiles/r04_attb_lb2_ab.txt) - the spills cost far more
+                                // than sharing CUs with the helper chain's GEMMs could return
+#define ATTB_LB __launch_bounds__(512, 4)
+#else
+#define ATTB_LB __launch_bounds__(512)
+#endif
+__global__ ATTB_LB void att_bwd_fused_kernel(const AttBwdArgs a, const AttBwdFoldArgs fold) {
     constexpr int AD = 128, F = 32, SP = ATTF_SP, SD = 34, SG = 34;
     __shared__ __attribute__((aligned(16))) float s_all[128 + 64 * 48 + ATTB_CH * 33 + 32 * 144 + ATTB_CH * ATTF_SP + ATTB_CH * 34 + 1024 + 2 * ATTB_CH + 16];
     float* s_cat = s_all;                          // [2][64]    window of [w_prev ; wc_prev]: entry i <-> t0 - pad + i
