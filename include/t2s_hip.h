@@ -587,7 +587,7 @@ typedef struct t2s_taco_bptt {
      * a 32-position chunk computes for itself, slots 1 / 2 the parts reaching in from the chunk to the right / left. */
     const float *ctx_all; long s_ctx_step, s_ctx_item;
     float *dw_c2, *dwc_c2;
-    /* ABI v4.  (B * ceil(T_in / 32) * 128 + 1) 8-byte words, ZERO before a BPTT pass, or NULL.  With the one-launch attention backward
+    /* ABI v4.  (B * ceil(T_in / 32) * 128 + 3) 8-byte words (the last three: error word, pace word, pace error word), ZERO before a BPTT pass, or NULL.  With the one-launch attention backward
      * (ctx_all ...) and T_in <= 512: the attention LSTMCell's pointwise backward (with W_query^T d_q) runs inside that launch - the
      * chunk workgroups of a batch element exchange their partial d_q through tagged granules here (tag = step + 1), each then takes its
      * share of the hidden units.  The last word is raised if a bounded wait expires.  NULL (or T2S_BPTT_FOLD_CELL=0): a launch of its own. */

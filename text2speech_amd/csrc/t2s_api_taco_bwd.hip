@@ -192,10 +192,25 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
     static const bool want_narrow = getenv("T2S_BPTT_SIDE_NARROW") && atoi(getenv("T2S_BPTT_SIDE_NARROW")) != 0;
     const bool side_narrow = want_narrow && two_streams;
     const bool split_rows = want_split_rows && two_streams && chunk > 1 && B > 8 && ((A + E) & 15) == 0 && (D & 15) == 0;
+    // Paced helper chain (T2S_BPTT_PACED=1; needs att_xbuf, whose tail holds the word): the decoder-cell chain's step m (counted from
+    // t_hi - 1) is released by a word the attention backward's launch of step m - chunk stores as it starts, and its GEMM takes the
+    // 96 KB ring - so that it runs BESIDE that launch (61 KB of LDS) instead of holding the CUs the chain's next launch needs.
+    // Built after the forward's pacing paid (section 5b of DESIGN.md) and measured NEGATIVE here: 77.8 / 78.0 ms per train step with
+    // the 96 KB ring, 78.9 / 78.7 with the 144 KB one, against 74.2 / 73.9 unpaced (profiles/r04_bptt_paced_ab.txt; every gradient test
+    // green with it on).  The forward pairs a GEMM with a 14 KB kernel; here the partner is a 61 KB / 185-VGPR kernel and the GEMM has to
+    // take the slower ring to fit beside it.  Off.
+    static const bool want_bpaced = getenv("T2S_BPTT_PACED") && atoi(getenv("T2S_BPTT_PACED")) != 0;
+    static const bool bpaced_narrow = !(getenv("T2S_BPTT_PACED_NARROW") && atoi(getenv("T2S_BPTT_PACED_NARROW")) == 0);
+    const bool bpaced = want_bpaced && two_streams && chunk > 1 && p->att_xbuf && p->ctx_all && p->dw_c2 && p->dwc_c2 && conv_main &&
+                        Tin <= 512 && ad == 128;
+    unsigned* const pace_word = bpaced ? (unsigned*)((unsigned long long*)p->att_xbuf + (size_t)B * ((Tin + 31) / 32) * ad + 1) : nullptr;
+    unsigned long long* const pace_err = bpaced ? (unsigned long long*)p->att_xbuf + (size_t)B * ((Tin + 31) / 32) * ad + 2 : nullptr;
     for (int tc = t_hi - 1; tc >= t_lo; tc -= chunk) {
     const int tl = tc - chunk + 1 > t_lo ? tc - chunk + 1 : t_lo;
     for (int t = tc; t >= tl; --t) {
         const bool nxt = t + 1 < T;
+        if (bpaced && t_hi - 1 - t >= chunk)
+            T2S_CHECK_HIP(t2s_launch_pace_wait(pace_word, (unsigned)(t_hi - 1 - t - chunk) + 1u, pace_err, dstream));
         // decoder LSTMCell: dh = d[h_dec] from the projection + from step t+1's decoder cell (through W_hh)
         LstmBwdArgs cd;
         cd.dh1 = p->d_hc + (size_t)t * B * DE; cd.s1 = DE;
@@ -211,7 +226,7 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
         memset(&g, 0, sizeof(g));
         g.W1 = p->W_dT; g.ld1 = 4 * D; g.k1 = 4 * D; g.x1 = cd.dgates; g.n1 = 4 * D; g.sx1 = 4 * D;
         g.y = p->out_d + (size_t)t * B * KD; g.sy_item = KD; g.sy_row = 1; g.rows = KD; g.items = B; g.mask_scale = 1.f;
-        g.narrow_ring = side_narrow ? 1 : 0;
+        g.narrow_ring = (side_narrow || (bpaced && bpaced_narrow)) ? 1 : 0;
         static const bool side_full = getenv("T2S_BPTT_SIDE_FULL") && atoi(getenv("T2S_BPTT_SIDE_FULL")) != 0;
         // (A/B: 32 items per workgroup on the helper chain's per-step GEMM - fewer, longer workgroups: 77.1 / 77.6 against
         // 73.5 / 73.7 ms per train step, profiles/r04_bptt_side_full_ab.txt; off)
@@ -287,8 +302,10 @@ int t2s_taco_bptt_steps(const t2s_taco_bptt* p, int t_hi, int t_lo, void* stream
             AttBwdFoldArgs fa;
             memset(&fa, 0, sizeof(fa));
             if (fold_cell) { fa.cell = ca; fa.xbuf = (unsigned long long*)p->att_xbuf; fa.tag = (unsigned)t + 1u; }
-            T2S_CHECK_HIP(t2s_launch_att_bwd_fused(ab, stream, fold_cell ? &fa : nullptr));
+            if (bpaced) { fa.sig_ptr = pace_word; fa.sig_val = (unsigned)(t_hi - 1 - t) + 1u; }
+            T2S_CHECK_HIP(t2s_launch_att_bwd_fused(ab, stream, (fold_cell || bpaced) ? &fa : nullptr));
         } else if (two_streams && conv_main) {
+            if (bpaced) T2S_CHECK_HIP(t2s_launch_pace_signal(pace_word, (unsigned)(t_hi - 1 - t) + 1u, stream));
             T2S_CHECK_HIP(t2s_launch_att_bwd(ab, stream));
         } else if (two_streams) {
             if (conv_pending) T2S_CHECK_HIP(hipStreamWaitEvent(stream, ev_conv, 0));   // carries of step t+1 are in place

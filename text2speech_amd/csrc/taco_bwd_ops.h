@@ -55,6 +55,9 @@ struct AttBwdFoldArgs {
     LstmBwdArgs cell;
     unsigned long long* xbuf;
     unsigned tag;
+    // optional: the first thread of the launch stores sig_val to *sig_ptr as the kernel starts (pacing of the helper stream's
+    // decoder-cell chain: t2s_launch_pace_wait, csrc/tacotron_ops.h)
+    unsigned* sig_ptr; unsigned sig_val;
 };
 
 struct BnBwdArgs {

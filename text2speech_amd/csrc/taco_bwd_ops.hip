@@ -827,6 +827,8 @@ __global__ ATTB_LB void att_bwd_fused_kernel(const AttBwdArgs a, const AttBwdFol
 #ifdef T2S_ATTB_SETPRIO
     __builtin_amdgcn_s_setprio(3);                 // (A/B build: this kernel is the backward's serial chain)
 #endif
+    if (fold.sig_ptr && blockIdx.x == 0 && threadIdx.x == 0)          // "this launch has started"
+        __hip_atomic_store(fold.sig_ptr, fold.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int n_chunks = (a.T + ATTB_CH - 1) / ATTB_CH;
     const int bsl = blockIdx.x >> 3;
     const int b = (bsl / n_chunks) * 8 + (blockIdx.x & 7), chunk = bsl - (bsl / n_chunks) * n_chunks, t0 = chunk * ATTB_CH;
@@ -1298,6 +1300,7 @@ hipError_t t2s_launch_att_bwd_fused(const AttBwdArgs& a, hipStream_t stream, con
     if (!t2s_att_bwd_fused_ok(a)) return hipErrorInvalidValue;
     AttBwdFoldArgs f;
     memset(&f, 0, sizeof(f));
+    if (fold) { f.sig_ptr = fold->sig_ptr; f.sig_val = fold->sig_val; }
     if (fold && fold->xbuf) {
         const LstmBwdArgs& c = fold->cell;
         if (a.T > 512 || a.att_dim != 128 || !c.wq || c.q_dim != 128 || c.B != a.B || c.H <= 0 || !c.gates || !c.c_new || !c.dc_carry ||

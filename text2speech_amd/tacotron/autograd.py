@@ -367,7 +367,7 @@ class _Bwd:
             if T_in <= 512 and ad == 128:
                 # exchange buffer of the attention cell's backward folded into the attention backward's launch (t2s_taco_bptt::att_xbuf):
                 # 8-byte granules as f32 pairs, zero = no tag matches
-                att_xbuf = self.zeros(2 * (B * nch * ad + 1))
+                att_xbuf = self.zeros(2 * (B * nch * ad + 3))       # (+ error word, pace word, pace error word)
                 bp.att_xbuf = _p(att_xbuf)
                 self.keep.append(att_xbuf)
         _lib.call("t2s_taco_bptt_steps", ctypes.byref(bp), T, 0, st)        # the whole reversed loop, enqueued from C++
