@@ -582,6 +582,14 @@ class _TacoEngine:
         for key, (buf, _) in self.__dict__.get("_xbufs", {}).items():
             if int(buf[-1].item()) != 0:
                 raise _lib.T2SError("split BiLSTM recurrence %s: a hand-off wait expired (results of that launch are invalid)" % (key,))
+        # ... and of the last teacher-forced decode's exchange buffers (t2s_taco_decoder::att_xbuf / pace_flag: their last / second
+        # 8-byte word is raised by a bounded wait that expired)
+        S = self.__dict__.get("_last_decoder_S")
+        if S is not None:
+            for name, words in (("att_xbuf", (-2, -1)), ("pace_flag", (2, 3))):
+                t = S.get(name)
+                if t is not None and any(float(t.view(-1)[w].item()) != 0.0 for w in words):
+                    raise _lib.T2SError("teacher-forced decode: a bounded wait on %s expired (results of that call are invalid)" % name)
 
     def _gemv(self, W, x, rows, items, K, y, act=0, mask=None, smask=0, mask_scale=1.0, bias=None, sy_item=None,
               sx=None):
@@ -887,6 +895,7 @@ class _TacoEngine:
             d.att_drop_scale = 1.0 / (1.0 - dec.p_attention_dropout)
             d.dec_drop_scale = 1.0 / (1.0 - dec.p_decoder_dropout)
         _lib.call("t2s_taco_decode_steps", ctypes.byref(d), 0, T_out, _lib.current_stream())
+        self.__dict__["_last_decoder_S"] = {k: S.get(k) for k in ("att_xbuf", "pace_flag")}     # (check_lstm_xbuf reads their error words)
         # hoisted projection + gate over all steps (reference tacotron.py:387-392)
         proj = torch.empty(T_out * B, n_mel + 1, dtype=torch.float32, device=dev)
         self._gemv(P["w_proj"], hc_all, n_mel + 1, T_out * B, D + E, proj, bias=P["b_proj"])
