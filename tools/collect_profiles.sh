@@ -45,4 +45,9 @@ bash tools/r4_decode_env_ab.sh "T2S_DECODE_PLOC=1" "T2S_DECODE_PLOC=0" > "$OUT/d
 if [ -f build/probe/libt2s_hip.so ]; then
   for n in 64 128 256; do echo "== $n symbols"; T2S_LIB_PATH=$R/build/probe/libt2s_hip.so python3 tools/decode_probe.py $n 2> /dev/null; done > "$OUT/att_role_probe.txt"
 fi
+# late round 4 (Tacotron B = 32 loops): each of these is a same-box alternating A/B that prints a few lines; their outputs are the
+# profiles/r04_*_ab.txt files of the same name
+#   tools/r4_energy_xcd_ab.sh  r4_lstm_split_ab.sh  r4_att_one_launch_ab.sh  r4_bptt_fold_cell_ab.sh  r4_paced_ab.sh  r4_setprio_ab.sh
+#   r4_cache_policy_ab.sh  r4_taco_sched_ab.sh  r4_taco_bptt_streams_ab.sh  r4_taco_chunk_gemm_ab.sh  r4_bptt_paced_ab.sh  r4_bptt_side_full_ab.sh
+# and tools/collect_final_r4.sh re-collects the bench line, the end-to-end number and the Tacotron tables / phases / timeline
 echo "wrote $OUT"
